@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ FROM THE REFERENCE'S OWN MODULES.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py [--skip-full]
+
+What it does
+  1. imports the reference hot-path modules by path (oracle/ref_shim.py; stubs for
+     mmcv / clip, and oracle/tutel_restated.py standing in for the un-vendored tutel),
+  2. builds ``STMoGenTransformer`` / ``SpacedDiffusion`` / ``GaussianDiffusion`` from the
+     reference, loads the deterministic (seed, key) weights of oracle/weights.py and
+     checks the key set + shapes against ``param_shapes``,
+  3. pins oracle/stmogen_oracle.py against the reference (asserts max-abs <= 1e-5),
+  4. writes small .npz fixtures: inputs and REFERENCE outputs only (no source text).
+
+Fixtures
+  schedules.npz         a1/a2 tables for linear-1000 and respace '15,15,8,6,6'
+  small_modules.npz     reduced config (L=16,NL=2,T=24,B=2, one padded sample): denoiser
+                        call at t=777 with per-layer intermediates captured by hooks
+  small_ddim.npz        reduced config: 50-step DDIM trajectory (every 10th x_t) + final
+  small_ddpm.npz        reduced config: 1000-step schedule, first 20 DDPM steps
+  full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
+  full_ddim.npz         0.125b config, B=1: final sample of the 50-step DDIM loop
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim, stmogen_oracle as O, weights as W  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+SMALL = W.default_dims(max_seq_len=24, L=16, NL=2, F=32, Te=64, Dt=32, Nt=8)
+FULL = W.default_dims()
+DIFF_DDIM = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                 model_var_type='fixed_large', respace='15,15,8,6,6')
+DIFF_DDPM = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                 model_var_type='fixed_large')
+
+
+def synth_inputs(dims, B, T, seed, lengths=None):
+    """Same generator recipe as tests/ and bench.py."""
+    g = torch.Generator().manual_seed(seed)
+    x_T = torch.randn(B, T, dims['input_feats'], generator=g)
+    xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],))
+    mask = torch.ones(B, T)
+    if lengths is not None:
+        for b, n in enumerate(lengths):
+            mask[b, n:] = 0
+    return x_T, xf, mask
+
+
+def build_ref(dims, seed=0):
+    m = ref_shim.build_reference_denoiser(W.reference_model_cfg(dims))
+    sd_ref = m.state_dict()
+    shapes = W.param_shapes(dims)
+    assert set(sd_ref.keys()) == set(shapes.keys()), (
+        sorted(set(sd_ref) ^ set(shapes))[:10])
+    for k, v in sd_ref.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    sd = W.make_state_dict(dims, seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def model_kwargs(xf, mask):
+    B, T = mask.shape
+    return dict(xf_out=xf, motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+                num_intervals=1, c=None, y={}, patch_size=1, sample_idx=None)
+
+
+def maxabs(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def schedules():
+    gd = ref_shim.load().gaussian_diffusion
+    out = {}
+    for tag, cfg in (('ddim50', DIFF_DDIM), ('ddpm1000', DIFF_DDPM)):
+        d = ref_shim.build_reference_diffusion(cfg)
+        s = O.Schedule(1000, cfg.get('respace'))
+        tmap = getattr(d, 'timestep_map', list(range(d.num_timesteps)))
+        assert list(tmap) == list(s.timestep_map)
+        fixed_large = np.append(d.posterior_variance[1], d.betas[1:])
+        for name, ref_arr in (('betas', d.betas), ('alphas_cumprod', d.alphas_cumprod),
+                              ('alphas_cumprod_prev', d.alphas_cumprod_prev),
+                              ('sqrt_recip_alphas_cumprod', d.sqrt_recip_alphas_cumprod),
+                              ('sqrt_recipm1_alphas_cumprod', d.sqrt_recipm1_alphas_cumprod),
+                              ('posterior_mean_coef1', d.posterior_mean_coef1),
+                              ('posterior_mean_coef2', d.posterior_mean_coef2),
+                              ('model_log_variance', np.log(fixed_large))):
+            assert np.array_equal(ref_arr, getattr(s, name)), (tag, name)
+            out[f'{tag}.{name}'] = ref_arr
+        out[f'{tag}.timestep_map'] = np.array(tmap, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'schedules.npz'), **out)
+    print('schedules.npz: oracle tables bit-equal to reference')
+
+
+def small_modules():
+    dims, B, T = SMALL, 2, 24
+    m, sd = build_ref(dims)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=11, lengths=[24, 17])
+    t = 777
+    cap = {}
+    hooks = []
+    for i, blk in enumerate(m.temporal_decoder_blocks):
+        hooks.append(blk.ca_block.motion_moe.register_forward_hook(
+            lambda mod, a, o, i=i: cap.__setitem__(f'layer{i}.motion_feat', o.detach().clone())))
+        hooks.append(blk.ca_block.text_moe.register_forward_hook(
+            lambda mod, a, o, i=i: cap.__setitem__(f'layer{i}.text_feat', o.detach().clone())))
+        hooks.append(blk.ca_block.body_d_attn.register_forward_hook(
+            lambda mod, a, o, i=i: cap.__setitem__(f'layer{i}.dyn', o.detach().clone())))
+        hooks.append(blk.ca_block.register_forward_hook(
+            lambda mod, a, o, i=i: cap.__setitem__(f'layer{i}.after_stma', o.detach().clone())))
+        hooks.append(blk.ffn.register_forward_hook(
+            lambda mod, a, o, i=i: cap.__setitem__(f'layer{i}.after_ffn', o.detach().clone())))
+    hooks.append(m.joint_embed.register_forward_hook(
+        lambda mod, a, o: cap.__setitem__('pose_enc', o.detach().clone())))
+    hooks.append(m.time_embed.register_forward_hook(
+        lambda mod, a, o: cap.__setitem__('emb', o.detach().clone())))
+    hooks.append(m.out.register_forward_hook(
+        lambda mod, a, o: cap.__setitem__('out2', o.detach().clone())))
+    with torch.no_grad():
+        x0_ref = m(x_T, torch.full((B,), t, dtype=torch.long), **model_kwargs(xf, mask))
+    for h in hooks:
+        h.remove()
+    ocap = {}
+    x0_or = O.denoise(sd, dims, x_T, t, xf, mask, cap=ocap)
+    errs = {'x0': maxabs(x0_ref, x0_or), 'out2': maxabs(cap['out2'], ocap['out2']),
+            'emb': maxabs(cap['emb'], ocap['emb'])}
+    for i in range(dims['NL']):
+        for k in ('motion_feat', 'text_feat', 'after_stma', 'after_ffn'):
+            errs[f'layer{i}.{k}'] = maxabs(cap[f'layer{i}.{k}'], ocap[f'layer{i}'][k])
+    print('small_modules: oracle vs reference max-abs:', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert max(errs.values()) <= 1e-5, errs
+    # routing statistics (capacity overflow must be exercised)
+    from oracle import tutel_restated as TR
+    drops = {}
+    for i in range(dims['NL']):
+        pre = f'temporal_decoder_blocks.{i}.ca_block.'
+        _, r = O.moe_wrapper(sd, pre + 'motion_moe.', torch.nn.functional.layer_norm(
+            (ocap['h0'].repeat(2, 1, 1) if i == 0 else ocap[f'layer{i-1}']['after_ffn']).reshape(2 * B, T, 12, -1),
+            (dims['L'],), sd[pre + 'norm.weight'], sd[pre + 'norm.bias']), return_routing=True)
+        drops[i] = [int((~k).sum()) for k in r['keeps']]
+    print('small_modules: dropped (choice0, choice1) per layer:', drops)
+    save = dict(x_t=x_T, xf_out=xf, motion_mask=mask, t=np.int64(t), x0=x0_ref, out2=cap['out2'],
+                emb=cap['emb'], pose_enc=cap['pose_enc'])
+    for i in range(dims['NL']):
+        for k in ('motion_feat', 'text_feat', 'dyn', 'after_stma', 'after_ffn'):
+            save[f'layer{i}.{k}'] = cap[f'layer{i}.{k}']
+        save[f'layer{i}.dropped'] = np.array(drops[i])
+    np.savez_compressed(os.path.join(OUT, 'small_modules.npz'),
+                        **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in save.items()})
+
+
+def run_ref_loop(m, diff, mode, x_T, xf, mask, seed, num_steps=None):
+    traj = []
+    torch.manual_seed(seed)
+    B, T, C = x_T.shape
+    gen = (diff.p_sample_loop_progressive if mode == 'ddpm' else diff.ddim_sample_loop_progressive)
+    kw = dict(noise=x_T.clone(), clip_denoised=False, model_kwargs=model_kwargs(xf, mask))
+    if mode == 'ddim':
+        kw['eta'] = 0
+    with torch.no_grad():
+        for n, s in enumerate(gen(m, (B, T, C), **kw)):
+            traj.append(s['sample'].clone())
+            if num_steps is not None and n + 1 >= num_steps:
+                break
+    return traj
+
+
+def run_oracle_loop(sd, dims, sched, mode, x_T, xf, mask, seed, num_steps=None):
+    traj = []
+    torch.manual_seed(seed)
+    O.sample_loop(sd, dims, sched, mode, x_T, xf, mask, num_steps=num_steps, trajectory=traj)
+    return [t[1] for t in traj]
+
+
+def small_loops():
+    dims, B, T = SMALL, 2, 24
+    m, sd = build_ref(dims)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=12, lengths=[20, 24])
+    # DDIM 50
+    diff = ref_shim.build_reference_diffusion(DIFF_DDIM)
+    tr = run_ref_loop(m, diff, 'ddim', x_T, xf, mask, seed=5)
+    to = run_oracle_loop(sd, dims, O.Schedule(1000, DIFF_DDIM['respace']), 'ddim', x_T, xf, mask, seed=5)
+    e = [maxabs(a, b) for a, b in zip(tr, to)]
+    print(f'small_ddim: oracle vs reference over 50 steps: max {max(e):.2e} final {e[-1]:.2e}')
+    assert max(e) <= 1e-5
+    np.savez_compressed(os.path.join(OUT, 'small_ddim.npz'), x_T=x_T.numpy(), xf_out=xf.numpy(),
+                        motion_mask=mask.numpy(), noise_seed=np.int64(5),
+                        traj=np.stack([t.numpy() for t in tr[9::10]]), final=tr[-1].numpy())
+    # DDPM, first 20 of 1000
+    diff = ref_shim.build_reference_diffusion(DIFF_DDPM)
+    tr = run_ref_loop(m, diff, 'ddpm', x_T, xf, mask, seed=6, num_steps=20)
+    to = run_oracle_loop(sd, dims, O.Schedule(1000, None), 'ddpm', x_T, xf, mask, seed=6, num_steps=20)
+    e = [maxabs(a, b) for a, b in zip(tr, to)]
+    print(f'small_ddpm: oracle vs reference over 20 steps: max {max(e):.2e}')
+    assert max(e) <= 1e-5
+    np.savez_compressed(os.path.join(OUT, 'small_ddpm.npz'), x_T=x_T.numpy(), xf_out=xf.numpy(),
+                        motion_mask=mask.numpy(), noise_seed=np.int64(6),
+                        traj=np.stack([t.numpy() for t in tr[4::5]]))
+
+
+def full():
+    dims, B, T = FULL, 1, 196
+    t0 = time.time()
+    m, sd = build_ref(dims)
+    print(f'full: built reference 0.125b in {time.time()-t0:.1f}s, '
+          f'{sum(p.numel() for p in m.parameters())/1e6:.1f} M params')
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=21)
+    save = dict(input_seed=np.int64(21))
+    for t in (999, 57):
+        with torch.no_grad():
+            r = m(x_T, torch.full((B,), t, dtype=torch.long), **model_kwargs(xf, mask))
+        o = O.denoise(sd, dims, x_T, t, xf, mask)
+        print(f'full_denoise t={t}: oracle vs reference {maxabs(r, o):.2e}  |x0| mean {float(r.abs().mean()):.3f}')
+        assert maxabs(r, o) <= 1e-5
+        save[f'x0_t{t}'] = r.numpy()
+    # padded sample
+    _, _, mask2 = synth_inputs(dims, B, T, seed=21, lengths=[150])
+    with torch.no_grad():
+        r = m(x_T, torch.full((B,), 500, dtype=torch.long), **model_kwargs(xf, mask2))
+    o = O.denoise(sd, dims, x_T, 500, xf, mask2)
+    print(f'full_denoise t=500 len=150: oracle vs reference {maxabs(r, o):.2e}')
+    assert maxabs(r, o) <= 1e-5
+    save['x0_t500_len150'] = r.numpy()
+    np.savez_compressed(os.path.join(OUT, 'full_denoise.npz'), **save)
+
+    diff = ref_shim.build_reference_diffusion(DIFF_DDIM)
+    t0 = time.time()
+    tr = run_ref_loop(m, diff, 'ddim', x_T, xf, mask, seed=7)
+    t_ref = time.time() - t0
+    t0 = time.time()
+    to = run_oracle_loop(sd, dims, O.Schedule(1000, DIFF_DDIM['respace']), 'ddim', x_T, xf, mask, seed=7)
+    t_or = time.time() - t0
+    e = [maxabs(a, b) for a, b in zip(tr, to)]
+    print(f'full_ddim: reference {t_ref:.1f}s, oracle {t_or:.1f}s; oracle vs reference max {max(e):.2e} '
+          f'final {e[-1]:.2e}')
+    assert e[-1] <= 1e-4
+    np.savez_compressed(os.path.join(OUT, 'full_ddim.npz'), input_seed=np.int64(21), noise_seed=np.int64(7),
+                        final=tr[-1].numpy())
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--skip-full', action='store_true')
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    schedules()
+    small_modules()
+    small_loops()
+    if not a.skip_full:
+        full()
+    print('golden fixtures written to', OUT)

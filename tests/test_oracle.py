@@ -1,0 +1,123 @@
+"""CPU: the oracle restatement against the committed golden vectors (generated from the
+reference's own modules by tests/golden/make_golden.py)."""
+import numpy as np
+import torch
+
+from oracle import stmogen_oracle as O, tutel_restated as TR, weights as W
+from helpers import SMALL, FULL, load, synth_inputs
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_schedule_tables_match_reference():
+    g = load('schedules.npz')
+    for tag, respace in (('ddim50', '15,15,8,6,6'), ('ddpm1000', None)):
+        s = O.Schedule(1000, respace)
+        assert list(g[f'{tag}.timestep_map']) == list(s.timestep_map)
+        for name in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
+                     'sqrt_recipm1_alphas_cumprod', 'posterior_mean_coef1', 'posterior_mean_coef2',
+                     'model_log_variance'):
+            assert np.array_equal(g[f'{tag}.{name}'], getattr(s, name)), (tag, name)
+    s = O.Schedule(1000, '15,15,8,6,6')
+    assert s.num_timesteps == 50 and s.timestep_map[:5] == [0, 14, 28, 43, 57]
+    assert s.timestep_map[-5:] == [840, 880, 919, 959, 999]
+
+
+def test_small_denoiser_modules():
+    g = load('small_modules.npz')
+    sd = W.make_state_dict(SMALL, 0)
+    cap = {}
+    x0 = O.denoise(sd, SMALL, T_(g['x_t']), int(g['t']), T_(g['xf_out']), T_(g['motion_mask']), cap=cap)
+    assert float((x0 - T_(g['x0'])).abs().max()) <= 1e-5
+    assert float((cap['emb'] - T_(g['emb'])).abs().max()) <= 1e-5
+    assert float((cap['out2'] - T_(g['out2'])).abs().max()) <= 1e-5
+    for i in range(SMALL['NL']):
+        for k in ('motion_feat', 'text_feat', 'after_stma', 'after_ffn'):
+            assert float((cap[f'layer{i}'][k] - T_(g[f'layer{i}.{k}'])).abs().max()) <= 1e-5, (i, k)
+    # the fixture exercises capacity overflow (dropped second choices)
+    assert int(g['layer0.dropped'][1]) > 0
+
+
+def test_text_hoist_is_identical():
+    g = load('small_modules.npz')
+    sd = W.make_state_dict(SMALL, 0)
+    xf = T_(g['xf_out'])
+    tf = O.precompute_text(sd, xf, SMALL)
+    a = O.denoise(sd, SMALL, T_(g['x_t']), int(g['t']), xf, T_(g['motion_mask']), text_feats=tf)
+    assert torch.equal(a, O.denoise(sd, SMALL, T_(g['x_t']), int(g['t']), xf, T_(g['motion_mask'])))
+
+
+def test_small_ddim_trajectory():
+    g = load('small_ddim.npz')
+    sd = W.make_state_dict(SMALL, 0)
+    traj = []
+    torch.manual_seed(int(g['noise_seed']))
+    out = O.sample_loop(sd, SMALL, O.Schedule(1000, '15,15,8,6,6'), 'ddim', T_(g['x_T']), T_(g['xf_out']),
+                        T_(g['motion_mask']), trajectory=traj)
+    assert float((out - T_(g['final'])).abs().max()) <= 1e-5
+    for n, ref in zip(range(9, 50, 10), g['traj']):
+        assert float((traj[n][1] - T_(ref)).abs().max()) <= 1e-5
+
+
+def test_small_ddpm_truncated():
+    g = load('small_ddpm.npz')
+    sd = W.make_state_dict(SMALL, 0)
+    traj = []
+    torch.manual_seed(int(g['noise_seed']))
+    O.sample_loop(sd, SMALL, O.Schedule(1000, None), 'ddpm', T_(g['x_T']), T_(g['xf_out']),
+                  T_(g['motion_mask']), num_steps=20, trajectory=traj)
+    for n, ref in zip(range(4, 20, 5), g['traj']):
+        assert float((traj[n][1] - T_(ref)).abs().max()) <= 1e-5
+
+
+def test_full_size_denoise_against_golden():
+    g = load('full_denoise.npz')
+    sd = W.make_state_dict(FULL, 0)
+    x_T, xf, mask = synth_inputs(FULL, 1, 196, int(g['input_seed']))
+    x0 = O.denoise(sd, FULL, x_T, 999, xf, mask)
+    assert float((x0 - T_(g['x0_t999'])).abs().max()) <= 1e-4
+    _, _, mask2 = synth_inputs(FULL, 1, 196, int(g['input_seed']), lengths=[150])
+    x0 = O.denoise(sd, FULL, x_T, 500, xf, mask2)
+    assert float((x0 - T_(g['x0_t500_len150'])).abs().max()) <= 1e-4
+
+
+def test_moe_capacity_and_ties():
+    """tutel boundary (a16): capacity formula, BPR drop order, stable tie order for duplicated tokens."""
+    assert TR.capacity_of(301056, 16, 2, 1.5) == 56448
+    assert TR.capacity_of(4, 16, 2, 1.5) == 2
+    torch.manual_seed(0)
+    E, D, N = 4, 8, 64
+    x = torch.randn(N // 2, D).repeat(2, 1)                       # CFG-style exact duplicates
+    pw, pb = torch.randn(256, D), torch.randn(256) * 0.1
+    sim, temp = torch.randn(256, E), torch.tensor([0.7])
+    w1, b1 = torch.randn(E, 4 * D, D) * 0.3, torch.randn(E, 4 * D) * 0.1
+    w2, b2 = torch.randn(E, 4 * D, D) * 0.3, torch.randn(E, D) * 0.1
+    y, r = TR.moe_forward(x, pw, pb, sim, temp, w1, b1, w2, b2, return_routing=True)
+    cap = r['capacity']
+    assert cap == 2 * int(1.5 * 16)
+    # brute-force the spec: rank by (-max score, index) among same expert, second choices offset
+    imp = r['scores'].max(1)[0]
+    order = sorted(range(N), key=lambda i: (-float(imp[i]), i))
+    cnt0 = [0] * E
+    loc = [[None, None] for _ in range(N)]
+    for i in order:
+        e = int(r['indices'][0][i]); loc[i][0] = cnt0[e]; cnt0[e] += 1
+    cnt1 = list(cnt0)
+    for i in order:
+        e = int(r['indices'][1][i]); loc[i][1] = cnt1[e]; cnt1[e] += 1
+    for k in range(2):
+        assert [int(v) for v in r['locations'][k]] == [loc[i][k] for i in range(N)]
+    # duplicates: the lower index ranks first
+    for i in range(N // 2):
+        assert int(r['locations'][0][i]) < int(r['locations'][0][i + N // 2])
+    # direct evaluation
+    yy = torch.zeros(N, D)
+    for i in range(N):
+        for k in range(2):
+            if loc[i][k] < cap:
+                e = int(r['indices'][k][i])
+                h = torch.nn.functional.gelu(w1[e] @ x[i] + b1[e])
+                yy[i] += r['gates'][k][i] * (h @ w2[e] + b2[e])
+    assert float((y - yy).abs().max()) < 1e-4
