@@ -1,0 +1,115 @@
+/* C-ABI of libmotioncraft_amd.so -- the MI355X (gfx950) STMoGen sampling hot path.
+ *
+ * This is the drop-in boundary for the per-step denoising path of cure-lab/MotionCraft
+ * (SURVEY.md section 8b).  The reference is pure Python/PyTorch and has no FFI of its own; the
+ * entry points below are what a binding for that path replaces, each citing the reference
+ * interface (paths relative to the reference root):
+ *
+ *   mc_model_*            weights of  STMoGenTransformer               mogen/models/transformers/stmogen.py:626-653
+ *                         (state dict as loaded by mmcv load_checkpoint, tools/test.py:99)
+ *   mc_ctx_set_timesteps  timestep_map of SpacedDiffusion/_WrappedModel  mogen/models/utils/gaussian_diffusion.py:1416-1463
+ *                         + time_embed / emb_layers hoists             diffusion_transformer.py:89-93,206-208; stylization_block.py:17-20
+ *   mc_ctx_set_condition  model_kwargs {xf_out, motion_mask}           mogen/models/architectures/diffusion_architecture.py:166-174
+ *                         + per-layer text_moe K/V hoist               mogen/models/attentions/st_attention.py:116-118
+ *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
+ *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
+ *
+ * Conventions: plain pointers and sizes only.  `*_dev` pointers are device (HBM) addresses owned
+ * by the caller (e.g. torch allocations); `stream` is a hipStream_t passed as void*.  All tensors
+ * are fp32, contiguous, row-major.  Every function returns 0 on success or an MC_ERR_* code;
+ * mc_last_error() returns a thread-local description.  A handle is re-entrant across handles but
+ * not thread-safe per handle.  No call synchronises the device except mc_model_set_param
+ * (synchronous H2D upload) and the *_create/_destroy functions.
+ */
+#ifndef MOTIONCRAFT_AMD_H
+#define MOTIONCRAFT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_OK 0
+#define MC_ERR_ARG 1
+#define MC_ERR_HIP 2
+#define MC_ERR_STATE 3
+
+typedef struct mc_model mc_model;
+typedef struct mc_ctx mc_ctx;
+
+/* configs/stmogen/*.py: model=dict(type='STMoGenTransformer', ...) */
+typedef struct mc_model_config {
+    int32_t input_feats;      /* 322 (SMPL-X motionx layout)                       */
+    int32_t max_seq_len;      /* 196                                               */
+    int32_t latent_dim;       /* L: per-part latent (ca_block_cfg.latent_dim)      */
+    int32_t num_parts;        /* H: 12 body parts (ca_block_cfg.num_heads)         */
+    int32_t num_layers;       /* NL                                                */
+    int32_t ffn_dim;          /* F: SFFN hidden (ffn_cfg.ffn_dim)                  */
+    int32_t time_embed_dim;   /* Te                                                */
+    int32_t text_latent_dim;  /* Dt                                                */
+    int32_t max_text_len;     /* Nt = 77                                           */
+    int32_t num_experts;      /* E = 16                                            */
+    int32_t topk;             /* 2                                                 */
+    int32_t dyn_heads;        /* 8 (st_attention.py:95)                            */
+    float capacity_factor;    /* 1.5 (st_attention.py:33)                          */
+    float cfg_scale;          /* scale_func_cfg.scale = 6.5                        */
+} mc_model_config;
+
+/* per-step scalars of the sampler, fp64 schedule tables cast to fp32 like _extract_into_tensor
+ * (gaussian_diffusion.py:1330-1343) */
+typedef struct mc_step_coefs {
+    int32_t mode;             /* 0 = DDPM p_sample, 1 = DDIM ddim_sample           */
+    float text_coef;          /* w = 1 + scale * t_orig / 1000 (stmogen.py:655-659) */
+    float none_coef;          /* 1 - w                                             */
+    float c1, c2;             /* posterior_mean_coef1/2[i]                          */
+    float log_var;            /* log(append(posterior_variance[1], betas[1:]))[i]   */
+    float sqrt_recip, sqrt_recipm1, ab, ab_prev, eta;   /* DDIM                     */
+    float nonzero;            /* (t != 0)                                           */
+} mc_step_coefs;
+
+const char* mc_last_error(void);
+int mc_device_count(int* n);
+int mc_set_device(int dev);
+
+/* ---- model (weights) -------------------------------------------------------------- */
+int mc_model_create(const mc_model_config* cfg, mc_model** out);
+void mc_model_destroy(mc_model* m);
+/* Upload one packed fp32 parameter from host memory.  Names and layouts: motioncraft_amd/weights.py */
+int mc_model_set_param(mc_model* m, const char* name, const float* host, int64_t numel);
+int mc_model_finalize(mc_model* m);
+
+/* ---- context = workspace for one (batch, frames) shape ------------------------------ */
+int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps, mc_ctx** out);
+void mc_ctx_destroy(mc_ctx* c);
+int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
+int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t num_steps, void* stream);
+int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_dev, void* stream);
+
+/* x_t_dev [B,T,C] at schedule index step_index -> out2_dev [2B,T,C] (text half, then uncond half);
+ * out2_dev may be NULL (result stays in the context, buffer "out2").
+ * stop_after_layers < 0: full model; >= 0: run only that many decoder layers and skip the pose
+ * decoder (tests read intermediates through mc_ctx_get_buffer). */
+int mc_denoise(mc_ctx* c, const float* x_t_dev, int32_t step_index, float* out2_dev,
+               int32_t stop_after_layers, void* stream);
+/* denoise + CFG combine + sampler update in one call; x0_dev may be NULL; x_prev_dev may alias x_t_dev */
+int mc_sample_step(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
+                   const float* noise_dev, float* x_prev_dev, float* x0_dev, void* stream);
+
+/* ---- introspection for tests --------------------------------------------------------- */
+/* named context buffers: "h","z","proj","mf","qkv","ys","yt","a","z2","out2","emb","ss","tf",
+ * "idx","gate","comb_w","key" (layer selects tf / ss slices) */
+int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr, int64_t* numel);
+
+/* op-level entry points (kernel parity tests call these through the same ABI) */
+int mc_op_gemm(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
+               float* c_dev, int32_t M, int32_t N, int32_t K, int32_t ldw, int32_t act, void* stream);
+int mc_op_ln_rows(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev,
+                  const float* add_dev, int32_t add_mod, float* y_dev, int64_t rows, int32_t L, void* stream);
+int mc_op_sampler_update(const float* x_t_dev, const float* out_text_dev, const float* out_none_dev,
+                         const float* noise_dev, float* x_prev_dev, float* x0_dev, int64_t n,
+                         const mc_step_coefs* coefs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTIONCRAFT_AMD_H */

@@ -1,0 +1,43 @@
+// Argument block + launcher of the fp32 MFMA GEMM family (mc_gemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { GM_PLAIN = 0, GM_EXP1 = 1, GM_EXP2 = 2, GM_COMB = 3 };
+
+struct GemmArgs {
+    // A operand: element (r,k) at A[grp*a_gstride + row(r)*lda + a_col + k]
+    const float* A = nullptr;
+    long lda = 0;
+    int a_col = 0;
+    long a_gstride = 0;
+    int a_scalar = 0;  // rows not 16-byte aligned (K = 322 pose vectors): scalar loads
+    // W operand [N][ldw], ldw % 4 == 0, rows zero padded to ldw
+    const float* W = nullptr;
+    long ldw = 0;
+    long w_gstride = 0;
+    const float* bias = nullptr;
+    long b_gstride = 0;
+    // output / residual: element (r,n) at C[grp*c_gstride + drow(r)*ldc + c_col + n]
+    float* C = nullptr;
+    long ldc = 0;
+    int c_col = 0;
+    long c_gstride = 0;
+    const float* R = nullptr;
+    long ldr = 0;
+    int act = 0;
+    const float* add = nullptr;  // C += add[(r % add_mod) * ld_add + n]
+    int add_mod = 1;
+    long ld_add = 0;
+    long dup_rows = 0;  // also write row r + dup_rows (CFG halves share the encoder output)
+    int M = 0, N = 0, K = 0;
+    // expert-grouped tile map (device arrays)
+    const int* tile_group = nullptr;
+    const int* tile_row0 = nullptr;
+    const int* tile_nrows = nullptr;
+    const int* num_tiles = nullptr;
+    const int* src_row = nullptr;
+    const int* dst_row = nullptr;
+    const float* comb_w = nullptr;  // [M][2]
+};
+
+int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream);

@@ -1,0 +1,60 @@
+// Launchers of the non-GEMM kernels (mc_kernels.hip, mc_route.hip, mc_attn.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- mc_kernels.hip -------------------------------------------------------------------
+// Y[r][0:L] = LN_L(X[r*ldx + x_col : +L]) * gamma + beta (+ add[(r % add_mod)*L + c])
+int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, const float* beta,
+                      const float* add, int add_mod, float* Y, long ldy, long rows, int L, hipStream_t s);
+// A[r][0:D] = silu( LN_D(Y1[r] (+ Y2[r])) * gamma + beta ) * (1 + ss[0:D]) + ss[D:2D] ) -- StylizationBlock prologue
+int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
+                        const float* ss, float* A, long rows, int D, hipStream_t s);
+// te[s][0:D] = cat(cos(t_s f), sin(t_s f))
+int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s);
+int mc_launch_silu(const float* X, float* Y, long n, hipStream_t s);
+// out = softmax(W[H][H], dim=1)
+int mc_launch_softmax_rows_small(const float* W, float* out, int rows, int cols, hipStream_t s);
+
+struct SamplerCoefs {
+    int mode;          // 0 ddpm, 1 ddim
+    float text_coef, none_coef;
+    float c1, c2;      // ddpm: posterior_mean_coef1/2
+    float log_var;     // ddpm: model_log_variance (FIXED_LARGE)
+    float sqrt_recip, sqrt_recipm1, ab, ab_prev, eta;   // ddim
+    float nonzero;     // 0 at i == 0
+};
+// x_prev = sampler(x_t, x0 = text_coef*out_text + none_coef*out_none, noise); optionally also writes x0
+int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none,
+                             const float* noise, float* x_prev, float* x0_out, long n,
+                             SamplerCoefs c, hipStream_t s);
+
+// ---- mc_route.hip ---------------------------------------------------------------------
+struct RouteBufs {
+    // per (token, choice)
+    int* idx;          // [N][2] expert index
+    float* gate;       // [N][2] normalised gate
+    uint32_t* key;     // [N]    float bits of max score (importance)
+    float* comb_w;     // [N][2] gate if kept else 0
+    int* src_row;      // [2N]   slot -> token
+    int* dst_row;      // [2N]   slot -> 2*token + choice
+    // tile map
+    int* tile_group; int* tile_row0; int* tile_nrows;
+    int* state;        // small int block, layout in mc_route.hip
+    int max_tiles;
+};
+size_t mc_route_state_ints(int E);
+// proj [N][256] (cosine_projector output incl. bias) -> idx/gate/key + per-expert choice counts
+int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
+                          RouteBufs rb, hipStream_t s);
+// capacity/BPR drop decision + slot compaction + tile map (tile rows = 128)
+int mc_launch_route(long N, int E, int capacity, RouteBufs rb, hipStream_t s);
+const int* mc_route_num_tiles_ptr(const RouteBufs& rb);
+
+// ---- mc_attn.hip ----------------------------------------------------------------------
+// static + dynamic body topology: ys[(b,t)][h*L + c]
+int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* wsm, float* ys,
+                   long frames, int H, int L, int G, hipStream_t s);
+// temporal linear attention over text (+) motion tokens: yt[(b,t)][h*L + c]
+int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
+                       int B2, int B, int T, int Nt, int H, int L, hipStream_t s);

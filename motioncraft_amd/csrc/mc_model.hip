@@ -1,0 +1,508 @@
+// Host side of libmotioncraft_amd.so: model/context handles, workspace layout in HBM and the
+// per-step kernel schedule of the STMoGen denoiser (C-ABI declared in include/motioncraft_amd.h).
+//
+// HBM layout (all fp32, row-major; B2 = 2B CFG-doubled batch, N = B2*T*H tokens, rows = B2*T):
+//   h    [rows, D]      residual stream (text-conditioned half first, stmogen.py:736-744)
+//   z    [N, L]         LN(x) + motion_moe.embedding            proj [N, 256] cosine projector out
+//   hbuf [2N, 4L]       expert hidden, slot-major               y2   [N, 2, L] expert outputs per choice
+//   mf   [N, 4L]        [body_value | key | value | query]      qkv  [N, 3L]   dynamic-topology q,k,v
+//   ys/yt/a/z2 [rows,D] static+dynamic / temporal / FiLM prologue / SFFN output
+//   fh   [rows, H*F]    SFFN hidden                             out2 [rows, C]  pose decoder output
+//   tf[layer] [B2*Nt, 2L]  step-invariant text K/V              ss[layer][blk][S][2D] FiLM scale|shift
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/motioncraft_amd.h"
+#include "mc_common.h"
+#include "mc_gemm.h"
+#include "mc_kernels.h"
+
+struct mc_model {
+    mc_model_config cfg;
+    std::map<std::string, std::pair<float*, int64_t>> params;
+    bool finalized = false;
+    int Cp = 0;  // input_feats padded to a multiple of 4 (row stride of enc.w)
+};
+
+struct MoeW {
+    const float *emb, *gate_w, *gate_b, *sim_n, *scale, *fc1_w, *fc1_b, *fc2_wt, *fc2_b, *proj_w, *proj_b;
+    int din, dout;
+};
+
+struct LayerW {
+    const float *norm_g, *norm_b, *tnorm_g, *tnorm_b, *wsm;
+    MoeW mm, tm;
+    const float *dyn_g, *dyn_b, *qkv_w, *qkv_b;
+    const float *ca_film_w, *ca_film_b, *ca_ln_g, *ca_ln_b, *ca_out_w, *ca_out_b;
+    const float *ffn_w1, *ffn_b1, *ffn_w2, *ffn_b2;
+    const float *ffn_film_w, *ffn_film_b, *ffn_ln_g, *ffn_ln_b, *ffn_out_w, *ffn_out_b;
+};
+
+struct mc_ctx {
+    mc_model* m = nullptr;
+    int B = 0, T = 0, S = 0, maxS = 0;
+    long N = 0, rows = 0, Ntxt = 0;
+    std::vector<LayerW> lw;
+    const float *enc_w, *enc_b, *seq_emb, *time_w0, *time_b0, *time_w2, *time_b2, *dec_w, *dec_b;
+    // workspace
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2;
+    float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
+    const float* mask = nullptr;
+    int* t_orig;
+    float *te, *e1, *emb, *semb, *ss;   // ss: [NL][2][maxS][2D]
+    RouteBufs rb;
+    bool have_cond = false;
+};
+
+namespace {
+
+template <class T>
+int ws_alloc(mc_ctx* c, T** p, size_t n) {
+    void* d = nullptr;
+    size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    MC_HIP(hipMalloc(&d, bytes));
+    c->allocs.push_back(d);
+    c->bytes += (int64_t)bytes;
+    *p = (T*)d;
+    return MC_OK;
+}
+
+int get_param(mc_model* m, const std::string& name, int64_t numel, const float** out) {
+    auto it = m->params.find(name);
+    if (it == m->params.end()) {
+        mc_set_error("missing parameter '%s'", name.c_str());
+        return MC_ERR_STATE;
+    }
+    if (it->second.second != numel) {
+        mc_set_error("parameter '%s' has %ld elements, expected %ld", name.c_str(), (long)it->second.second, (long)numel);
+        return MC_ERR_STATE;
+    }
+    *out = it->second.first;
+    return MC_OK;
+}
+
+#define GP(ptr, name, numel)                                         \
+    do {                                                             \
+        int _r = get_param(m, (name), (int64_t)(numel), &(ptr));     \
+        if (_r != MC_OK) return _r;                                  \
+    } while (0)
+
+int bind_moe(mc_model* m, const std::string& pre, int din, int dout, int seq_rows, MoeW* w) {
+    const int E = m->cfg.num_experts;
+    w->din = din;
+    w->dout = dout;
+    GP(w->emb, pre + "emb", (int64_t)seq_rows * din);
+    GP(w->gate_w, pre + "gate_w", 256 * din);
+    GP(w->gate_b, pre + "gate_b", 256);
+    GP(w->sim_n, pre + "sim_n", 256 * E);
+    GP(w->scale, pre + "scale", 1);
+    GP(w->fc1_w, pre + "fc1_w", (int64_t)E * 4 * din * din);
+    GP(w->fc1_b, pre + "fc1_b", (int64_t)E * 4 * din);
+    GP(w->fc2_wt, pre + "fc2_wt", (int64_t)E * din * 4 * din);
+    GP(w->fc2_b, pre + "fc2_b", (int64_t)E * din);
+    GP(w->proj_w, pre + "proj_w", (int64_t)dout * din);
+    GP(w->proj_b, pre + "proj_b", dout);
+    return MC_OK;
+}
+
+int bind_weights(mc_ctx* c) {
+    mc_model* m = c->m;
+    const mc_model_config& g = m->cfg;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim, Te = g.time_embed_dim;
+    GP(c->enc_w, "enc.w", (int64_t)D * m->Cp);
+    GP(c->enc_b, "enc.b", D);
+    GP(c->seq_emb, "seq_emb", (int64_t)g.max_seq_len * D);
+    GP(c->time_w0, "time.w0", (int64_t)Te * D);
+    GP(c->time_b0, "time.b0", Te);
+    GP(c->time_w2, "time.w2", (int64_t)Te * Te);
+    GP(c->time_b2, "time.b2", Te);
+    GP(c->dec_w, "dec.w", (int64_t)g.input_feats * D);
+    GP(c->dec_b, "dec.b", g.input_feats);
+    c->lw.resize(g.num_layers);
+    for (int i = 0; i < g.num_layers; ++i) {
+        LayerW& w = c->lw[i];
+        const std::string p = "l" + std::to_string(i) + ".";
+        GP(w.norm_g, p + "norm.g", L);
+        GP(w.norm_b, p + "norm.b", L);
+        GP(w.tnorm_g, p + "text_norm.g", g.text_latent_dim);
+        GP(w.tnorm_b, p + "text_norm.b", g.text_latent_dim);
+        GP(w.wsm, p + "body_wsm", H * H);
+        int r = bind_moe(m, p + "mm.", L, 4 * L, g.max_seq_len * H, &w.mm);
+        if (r != MC_OK) return r;
+        r = bind_moe(m, p + "tm.", g.text_latent_dim, 2 * L, g.max_text_len, &w.tm);
+        if (r != MC_OK) return r;
+        GP(w.dyn_g, p + "dyn.norm.g", L);
+        GP(w.dyn_b, p + "dyn.norm.b", L);
+        GP(w.qkv_w, p + "dyn.qkv_w", 3 * L * L);
+        GP(w.qkv_b, p + "dyn.qkv_b", 3 * L);
+        GP(w.ca_film_w, p + "ca.film_w", (int64_t)2 * D * Te);
+        GP(w.ca_film_b, p + "ca.film_b", 2 * D);
+        GP(w.ca_ln_g, p + "ca.ln_g", D);
+        GP(w.ca_ln_b, p + "ca.ln_b", D);
+        GP(w.ca_out_w, p + "ca.out_w", (int64_t)D * D);
+        GP(w.ca_out_b, p + "ca.out_b", D);
+        GP(w.ffn_w1, p + "ffn.w1", (int64_t)H * F * L);
+        GP(w.ffn_b1, p + "ffn.b1", H * F);
+        GP(w.ffn_w2, p + "ffn.w2", (int64_t)H * L * F);
+        GP(w.ffn_b2, p + "ffn.b2", H * L);
+        GP(w.ffn_film_w, p + "ffn.film_w", (int64_t)2 * D * Te);
+        GP(w.ffn_film_b, p + "ffn.film_b", 2 * D);
+        GP(w.ffn_ln_g, p + "ffn.ln_g", D);
+        GP(w.ffn_ln_b, p + "ffn.ln_b", D);
+        GP(w.ffn_out_w, p + "ffn.out_w", (int64_t)D * D);
+        GP(w.ffn_out_b, p + "ffn.out_b", D);
+    }
+    return MC_OK;
+}
+
+int dense(const float* A, long lda, const float* W, long ldw, const float* bias, const float* R, long ldr,
+          float* C, long ldc, long M, int N, int K, int act, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R = R; g.ldr = ldr;
+    g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
+    return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
+}
+
+// One tutel MoE layer + GELU + proj (class MOE, st_attention.py:49-56) over Ntok tokens whose
+// gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
+int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, hipStream_t s) {
+    const mc_model_config& g = c->m->cfg;
+    const int E = g.num_experts, din = w.din, hid = 4 * w.din;
+    int r;
+    // cosine projector (tutel/gates/cosine_top.py): proj = z Wp^T + bp
+    if ((r = dense(z, din, w.gate_w, din, w.gate_b, nullptr, 0, c->proj, 256, Ntok, 256, din, ACT_NONE, s))) return r;
+    if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
+    const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
+    if ((r = mc_launch_route(Ntok, E, capacity, c->rb, s))) return r;
+    const int max_tiles = cdiv(2 * Ntok, 128) + E;
+    GemmArgs a;
+    a.A = z; a.lda = din; a.src_row = c->rb.src_row;
+    a.W = w.fc1_w; a.ldw = din; a.w_gstride = (long)hid * din;
+    a.bias = w.fc1_b; a.b_gstride = hid; a.act = ACT_GELU;
+    a.C = c->hbuf; a.ldc = hid; a.N = hid; a.K = din;
+    a.tile_group = c->rb.tile_group; a.tile_row0 = c->rb.tile_row0; a.tile_nrows = c->rb.tile_nrows;
+    a.num_tiles = mc_route_num_tiles_ptr(c->rb);
+    if ((r = mc_launch_gemm(GM_EXP1, a, 1, max_tiles, s))) return r;
+    GemmArgs b;
+    b.A = c->hbuf; b.lda = hid; b.W = w.fc2_wt; b.ldw = hid; b.w_gstride = (long)din * hid;
+    b.bias = w.fc2_b; b.b_gstride = din; b.dst_row = c->rb.dst_row;
+    b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
+    b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
+    if ((r = mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s))) return r;
+    GemmArgs p;
+    p.A = c->y2; p.lda = din; p.comb_w = c->rb.comb_w;
+    p.W = w.proj_w; p.ldw = din; p.bias = w.proj_b;
+    p.C = out; p.ldc = ldout; p.M = (int)Ntok; p.N = w.dout; p.K = din;
+    return mc_launch_gemm(GM_COMB, p, 1, 0, s);
+}
+
+int film_block(mc_ctx* c, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
+               const float* ss, const float* out_w, const float* out_b, hipStream_t s) {
+    const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
+    int r;
+    if ((r = mc_launch_film_rows(y1, y2, ln_g, ln_b, ss, c->a, c->rows, D, s))) return r;
+    // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
+    return dense(c->a, D, out_w, D, out_b, c->h, D, c->h, D, c->rows, D, D, ACT_NONE, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mc_device_count(int* n) {
+    MC_HIP(hipGetDeviceCount(n));
+    return MC_OK;
+}
+int mc_set_device(int dev) {
+    MC_HIP(hipSetDevice(dev));
+    return MC_OK;
+}
+
+int mc_model_create(const mc_model_config* cfg, mc_model** out) {
+    MC_REQUIRE(cfg && out, "null argument");
+    MC_REQUIRE(cfg->latent_dim == 32 || cfg->latent_dim == 64 || cfg->latent_dim == 128,
+               "latent_dim=%d unsupported (32, 64, 128)", cfg->latent_dim);
+    MC_REQUIRE(cfg->topk == 2, "topk=%d unsupported (reference configs use 2)", cfg->topk);
+    MC_REQUIRE(cfg->num_experts >= 2 && cfg->num_experts <= 16, "num_experts=%d unsupported", cfg->num_experts);
+    MC_REQUIRE(cfg->latent_dim % cfg->dyn_heads == 0, "latent_dim %% dyn_heads != 0");
+    MC_REQUIRE(cfg->ffn_dim % 4 == 0 && cfg->time_embed_dim % 4 == 0 && cfg->text_latent_dim % 4 == 0, "dims must be multiples of 4");
+    {
+        const int q = cfg->text_latent_dim / 4;
+        MC_REQUIRE(q >= 1 && q <= 64 && (q & (q - 1)) == 0, "text_latent_dim=%d unsupported", cfg->text_latent_dim);
+    }
+    mc_model* m = new mc_model();
+    m->cfg = *cfg;
+    m->Cp = (cfg->input_feats + 3) / 4 * 4;
+    *out = m;
+    return MC_OK;
+}
+
+void mc_model_destroy(mc_model* m) {
+    if (!m) return;
+    for (auto& kv : m->params) (void)hipFree(kv.second.first);
+    delete m;
+}
+
+int mc_model_set_param(mc_model* m, const char* name, const float* host, int64_t numel) {
+    MC_REQUIRE(m && name && host && numel > 0, "bad argument");
+    float* d = nullptr;
+    MC_HIP(hipMalloc(&d, (size_t)numel * sizeof(float)));
+    MC_HIP(hipMemcpy(d, host, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+    auto it = m->params.find(name);
+    if (it != m->params.end()) (void)hipFree(it->second.first);
+    m->params[name] = std::make_pair(d, numel);
+    return MC_OK;
+}
+
+int mc_model_finalize(mc_model* m) {
+    MC_REQUIRE(m, "null model");
+    mc_ctx probe;
+    probe.m = m;
+    int r = bind_weights(&probe);
+    if (r != MC_OK) return r;
+    m->finalized = true;
+    return MC_OK;
+}
+
+int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps, mc_ctx** out) {
+    MC_REQUIRE(m && out, "null argument");
+    MC_REQUIRE(m->finalized, "model not finalized");
+    MC_REQUIRE(batch >= 1 && frames >= 1 && frames <= m->cfg.max_seq_len, "bad batch/frames (%d, %d)", batch, frames);
+    MC_REQUIRE(max_steps >= 1, "max_steps < 1");
+    const mc_model_config& g = m->cfg;
+    mc_ctx* c = new mc_ctx();
+    c->m = m;
+    c->B = batch;
+    c->T = frames;
+    c->maxS = max_steps;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim, Te = g.time_embed_dim, Dt = g.text_latent_dim;
+    const long B2 = 2L * batch;
+    c->rows = B2 * frames;
+    c->N = c->rows * H;
+    c->Ntxt = B2 * g.max_text_len;
+    int r = bind_weights(c);
+    if (r != MC_OK) { delete c; return r; }
+    const long Nmax = c->N > c->Ntxt ? c->N : c->Ntxt;
+    const size_t zsz = (size_t)(c->N * L > c->Ntxt * Dt ? c->N * L : c->Ntxt * Dt);
+    const size_t hsz = (size_t)(2 * c->N * 4 * L > 2 * c->Ntxt * 4 * Dt ? 2 * c->N * 4 * L : 2 * c->Ntxt * 4 * Dt);
+#define WS(p, n) do { if ((r = ws_alloc(c, &(p), (size_t)(n))) != MC_OK) { mc_ctx_destroy(c); return r; } } while (0)
+    WS(c->h, c->rows * D);
+    WS(c->z, zsz);
+    WS(c->proj, Nmax * 256);
+    WS(c->hbuf, hsz);
+    WS(c->y2, 2 * zsz);
+    WS(c->mf, c->N * 4 * L);
+    WS(c->qkv, c->N * 3 * L);
+    WS(c->ys, c->rows * D);
+    WS(c->yt, c->rows * D);
+    WS(c->a, c->rows * D);
+    WS(c->z2, c->rows * D);
+    WS(c->fh, c->rows * H * F);
+    WS(c->out2, c->rows * g.input_feats);
+    WS(c->xfn, c->Ntxt * Dt);
+    WS(c->tf, (long)g.num_layers * c->Ntxt * 2 * L);
+    WS(c->t_orig, max_steps);
+    WS(c->te, (long)max_steps * D);
+    WS(c->e1, (long)max_steps * Te);
+    WS(c->emb, (long)max_steps * Te);
+    WS(c->semb, (long)max_steps * Te);
+    WS(c->ss, (long)g.num_layers * 2 * max_steps * 2 * D);
+    WS(c->rb.idx, 2 * Nmax);
+    WS(c->rb.gate, 2 * Nmax);
+    WS(c->rb.key, Nmax);
+    WS(c->rb.comb_w, 2 * Nmax);
+    WS(c->rb.src_row, 2 * Nmax);
+    WS(c->rb.dst_row, 2 * Nmax);
+    c->rb.max_tiles = cdiv(2 * Nmax, 128) + g.num_experts;
+    WS(c->rb.tile_group, c->rb.max_tiles);
+    WS(c->rb.tile_row0, c->rb.max_tiles);
+    WS(c->rb.tile_nrows, c->rb.max_tiles);
+    WS(c->rb.state, mc_route_state_ints(g.num_experts));
+#undef WS
+    *out = c;
+    return MC_OK;
+}
+
+void mc_ctx_destroy(mc_ctx* c) {
+    if (!c) return;
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+int64_t mc_ctx_workspace_bytes(const mc_ctx* c) { return c ? c->bytes : 0; }
+
+// time_embed (diffusion_transformer.py:89-93,206-208) and every StylizationBlock.emb_layers
+// (stylization_block.py:17-20,34-35) depend only on the timestep, which is identical for the whole
+// batch -> evaluated once for all S steps of the schedule as M = S row GEMMs.
+int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t S, void* stream) {
+    MC_REQUIRE(c && t_orig_host, "null argument");
+    MC_REQUIRE(S >= 1 && S <= c->maxS, "num_steps=%d exceeds context max_steps=%d", S, c->maxS);
+    hipStream_t s = (hipStream_t)stream;
+    const mc_model_config& g = c->m->cfg;
+    const int D = g.latent_dim * g.num_parts, Te = g.time_embed_dim;
+    MC_HIP(hipMemcpyAsync(c->t_orig, t_orig_host, sizeof(int) * S, hipMemcpyHostToDevice, s));
+    MC_HIP(hipStreamSynchronize(s));  // t_orig_host may be a temporary of the caller
+    int r;
+    if ((r = mc_launch_timestep_embedding(c->t_orig, c->te, S, D, s))) return r;
+    if ((r = dense(c->te, D, c->time_w0, D, c->time_b0, nullptr, 0, c->e1, Te, S, Te, D, ACT_SILU, s))) return r;
+    if ((r = dense(c->e1, Te, c->time_w2, Te, c->time_b2, nullptr, 0, c->emb, Te, S, Te, Te, ACT_NONE, s))) return r;
+    if ((r = mc_launch_silu(c->emb, c->semb, (long)S * Te, s))) return r;
+    for (int i = 0; i < g.num_layers; ++i) {
+        const LayerW& w = c->lw[i];
+        float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS) * 2 * D;
+        float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS) * 2 * D;
+        if ((r = dense(c->semb, Te, w.ca_film_w, Te, w.ca_film_b, nullptr, 0, ss0, 2 * D, S, 2 * D, Te, ACT_NONE, s))) return r;
+        if ((r = dense(c->semb, Te, w.ffn_film_w, Te, w.ffn_film_b, nullptr, 0, ss1, 2 * D, S, 2 * D, Te, ACT_NONE, s))) return r;
+    }
+    c->S = S;
+    return MC_OK;
+}
+
+// Step-invariant text K/V of every layer (st_attention.py:116-118): text_moe over the CFG-doubled
+// condition batch (the MoE capacity couples both halves, so both are routed together).
+int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_dev, void* stream) {
+    MC_REQUIRE(c && xf_out_dev && mask_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const mc_model_config& g = c->m->cfg;
+    const int L = g.latent_dim, Dt = g.text_latent_dim, Nt = g.max_text_len;
+    const long half = (long)c->B * Nt;
+    c->mask = mask_dev;
+    int r;
+    for (int i = 0; i < g.num_layers; ++i) {
+        const LayerW& w = c->lw[i];
+        if ((r = mc_launch_ln_rows(xf_out_dev, Dt, 0, w.tnorm_g, w.tnorm_b, w.tm.emb, Nt, c->xfn, Dt, half, Dt, s))) return r;
+        MC_HIP(hipMemcpyAsync(c->xfn + half * Dt, c->xfn, sizeof(float) * half * Dt, hipMemcpyDeviceToDevice, s));
+        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, s))) return r;
+    }
+    c->have_cond = true;
+    return MC_OK;
+}
+
+int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32_t stop_after, void* stream) {
+    MC_REQUIRE(c && x_t, "null argument");
+    MC_REQUIRE(c->have_cond, "mc_ctx_set_condition not called");
+    MC_REQUIRE(step >= 0 && step < c->S, "step_index %d outside the %d-step schedule", step, c->S);
+    hipStream_t s = (hipStream_t)stream;
+    const mc_model_config& g = c->m->cfg;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim, C = g.input_feats;
+    const long BT = (long)c->B * c->T;
+    int r;
+    // PoseEncoder as one dense [C -> D] GEMM with the scattered weight, + sequence_embedding[:T],
+    // written to both CFG halves (stmogen.py:336-353; diffusion_transformer.py:215-218; stmogen.py:740)
+    {
+        GemmArgs e;
+        e.A = x_t; e.lda = C; e.a_scalar = 1;
+        e.W = c->enc_w; e.ldw = c->m->Cp; e.bias = c->enc_b;
+        e.add = c->seq_emb; e.add_mod = c->T; e.ld_add = D;
+        e.C = c->h; e.ldc = D; e.dup_rows = BT;
+        e.M = (int)BT; e.N = D; e.K = C;
+        if ((r = mc_launch_gemm(GM_PLAIN, e, 1, 0, s))) return r;
+    }
+    const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
+    for (int i = 0; i < nl; ++i) {
+        const LayerW& w = c->lw[i];
+        // ---- STMA ----
+        if ((r = mc_launch_ln_rows(c->h, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
+        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, s))) return r;
+        if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
+        if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
+        if ((r = mc_launch_body(c->mf, 4 * L, c->qkv, w.wsm, c->ys, c->rows, H, L, g.dyn_heads, s))) return r;
+        if ((r = mc_launch_temporal(c->mf, c->tf + (long)i * c->Ntxt * 2 * L, c->mask, c->yt, 2 * c->B, c->B, c->T,
+                                    g.max_text_len, H, L, s))) return r;
+        const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
+        if ((r = film_block(c, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, s))) return r;
+        // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
+        {
+            GemmArgs f1;
+            f1.A = c->h; f1.lda = D; f1.a_gstride = L;
+            f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
+            f1.bias = w.ffn_b1; f1.b_gstride = F; f1.act = ACT_GELU;
+            f1.C = c->fh; f1.ldc = (long)H * F; f1.c_gstride = F;
+            f1.M = (int)c->rows; f1.N = F; f1.K = L;
+            if ((r = mc_launch_gemm(GM_PLAIN, f1, H, 0, s))) return r;
+            GemmArgs f2;
+            f2.A = c->fh; f2.lda = (long)H * F; f2.a_gstride = F;
+            f2.W = w.ffn_w2; f2.ldw = F; f2.w_gstride = (long)L * F;
+            f2.bias = w.ffn_b2; f2.b_gstride = L;
+            f2.C = c->z2; f2.ldc = D; f2.c_gstride = L;
+            f2.M = (int)c->rows; f2.N = L; f2.K = F;
+            if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
+        }
+        const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
+        if ((r = film_block(c, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, s))) return r;
+    }
+    if (stop_after >= 0) return MC_OK;
+    // PoseDecoder as one dense [D -> C] GEMM (stmogen.py:505-544), /2 folded into the packed weight
+    float* o = out2_dev ? out2_dev : c->out2;
+    return dense(c->h, D, c->dec_w, D, c->dec_b, nullptr, 0, o, C, c->rows, C, D, ACT_NONE, s);
+}
+
+static SamplerCoefs to_coefs(const mc_step_coefs* k) {
+    SamplerCoefs c;
+    c.mode = k->mode; c.text_coef = k->text_coef; c.none_coef = k->none_coef; c.c1 = k->c1; c.c2 = k->c2;
+    c.log_var = k->log_var; c.sqrt_recip = k->sqrt_recip; c.sqrt_recipm1 = k->sqrt_recipm1; c.ab = k->ab;
+    c.ab_prev = k->ab_prev; c.eta = k->eta; c.nonzero = k->nonzero;
+    return c;
+}
+
+int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
+                   float* x_prev, float* x0, void* stream) {
+    MC_REQUIRE(c && x_t && k && noise && x_prev, "null argument");
+    int r = mc_denoise(c, x_t, step, nullptr, -1, stream);
+    if (r != MC_OK) return r;
+    const long n = (long)c->B * c->T * c->m->cfg.input_feats;
+    return mc_launch_sampler_update(x_t, c->out2, c->out2 + n, noise, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
+}
+
+int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr, int64_t* numel) {
+    MC_REQUIRE(c && name && dev_ptr && numel, "null argument");
+    const mc_model_config& g = c->m->cfg;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H;
+    const std::string n(name);
+    void* p = nullptr;
+    int64_t cnt = 0;
+    if (n == "h") { p = c->h; cnt = c->rows * D; }
+    else if (n == "z") { p = c->z; cnt = c->N * L; }
+    else if (n == "proj") { p = c->proj; cnt = c->N * 256; }
+    else if (n == "mf") { p = c->mf; cnt = c->N * 4 * L; }
+    else if (n == "qkv") { p = c->qkv; cnt = c->N * 3 * L; }
+    else if (n == "ys") { p = c->ys; cnt = c->rows * D; }
+    else if (n == "yt") { p = c->yt; cnt = c->rows * D; }
+    else if (n == "a") { p = c->a; cnt = c->rows * D; }
+    else if (n == "z2") { p = c->z2; cnt = c->rows * D; }
+    else if (n == "out2") { p = c->out2; cnt = c->rows * g.input_feats; }
+    else if (n == "emb") { p = c->emb; cnt = (int64_t)c->S * g.time_embed_dim; }
+    else if (n == "ss") { p = c->ss + (long)layer * c->maxS * 2 * D; cnt = (int64_t)c->S * 2 * D; }
+    else if (n == "tf") { p = c->tf + (long)layer * c->Ntxt * 2 * L; cnt = c->Ntxt * 2 * L; }
+    else if (n == "idx") { p = c->rb.idx; cnt = 2 * c->N; }
+    else if (n == "gate") { p = c->rb.gate; cnt = 2 * c->N; }
+    else if (n == "comb_w") { p = c->rb.comb_w; cnt = 2 * c->N; }
+    else if (n == "key") { p = c->rb.key; cnt = c->N; }
+    else { mc_set_error("unknown buffer '%s'", name); return MC_ERR_ARG; }
+    *dev_ptr = p;
+    *numel = cnt;
+    return MC_OK;
+}
+
+int mc_op_gemm(const float* a, const float* w, const float* bias, const float* res, float* cdev, int32_t M, int32_t N,
+               int32_t K, int32_t ldw, int32_t act, void* stream) {
+    MC_REQUIRE(a && w && cdev && M > 0 && N > 0 && K > 0 && K % 4 == 0 && ldw % 4 == 0 && ldw >= K, "bad gemm args");
+    return dense(a, K, w, ldw, bias, res, N, cdev, N, M, N, K, act, (hipStream_t)stream);
+}
+
+int mc_op_ln_rows(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* add, int32_t add_mod,
+                  float* y, int64_t rows, int32_t L, void* stream) {
+    return mc_launch_ln_rows(x, ldx, 0, gamma, beta, add, add_mod, y, L, rows, L, (hipStream_t)stream);
+}
+
+int mc_op_sampler_update(const float* x_t, const float* ot, const float* on, const float* noise, float* x_prev, float* x0,
+                         int64_t n, const mc_step_coefs* k, void* stream) {
+    MC_REQUIRE(x_t && ot && on && noise && x_prev && k, "null argument");
+    return mc_launch_sampler_update(x_t, ot, on, noise, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// MoE routing for the tutel `cosine_top` gate as the reference configures it
+// (st_attention.py:28-45; semantics restated in oracle/tutel_restated.py):
+// top-2 of softmax(cosine logits), renormalised gates, batch-prioritised routing with
+// capacity_factor 1.5 and token dropping.
+//
+// MI355X design: tutel materialises an [E, capacity, D] slot buffer addressed by the BPR
+// "location" of every (token, choice).  The result only depends on the location through the
+// drop test `location < capacity`, so this implementation never sorts: per (expert, choice)
+// problem it radix-selects the capacity-th largest composite key
+//        V = (float_bits(max score) << 32) | ~token_index        (all V distinct)
+// which is exactly "rank by descending importance, stable in token order", and keeps the
+// (token, choice) pairs with V >= V*.  Kept pairs are then compacted into contiguous per-expert
+// slot ranges (order inside an expert is irrelevant: every row is an independent GEMM row) and
+// a 128-row tile map is emitted for the grouped expert GEMMs.  Everything stays on the device:
+// no host sync, graph-capturable.
+#include "mc_common.h"
+#include "mc_kernels.h"
+
+namespace {
+
+constexpr int MAXE = 16;          // experts (lanes per token in the gate kernel)
+constexpr int MAXP = 2 * MAXE;    // selection problems = (choice, expert)
+constexpr int TILE_ROWS = 128;
+
+// int state block layout
+enum {
+    ST_CNT = 0,                   // [2][MAXE]   tokens per (choice, expert)
+    ST_KEPT = ST_CNT + MAXP,      // [MAXE]      kept pairs per expert
+    ST_FILL = ST_KEPT + MAXE,     // [MAXE]      compaction cursors
+    ST_OFF = ST_FILL + MAXE,      // [MAXE+1]    slot range starts
+    ST_ACTIVE = ST_OFF + MAXE + 1,  // [MAXP]    1: overflowed, needs selection; 0: keep all; -1: keep none
+    ST_RANK = ST_ACTIVE + MAXP,   // [MAXP]      remaining rank during selection
+    ST_ANY = ST_RANK + MAXP,      // [1]         any problem active
+    ST_NTILES = ST_ANY + 1,       // [1]
+    ST_PREFIX = ST_NTILES + 1,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
+    ST_HIST = ST_PREFIX + 2 * MAXP,  // [MAXP][256]
+    ST_TOTAL = ST_HIST + MAXP * 256
+};
+
+__device__ __forceinline__ unsigned long long composite(uint32_t key, uint32_t tok) {
+    return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tok);
+}
+
+// ---------------------------------------------------------------------------------------
+// gate finish: 16 lanes per token (lane = expert).  tutel/gates/cosine_top.py + softmax + top-2.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_finish_k(const float* __restrict__ proj, const float* __restrict__ sim_n,
+                                                     const float* __restrict__ logit_scale, long N, int E,
+                                                     int* __restrict__ idx, float* __restrict__ gate,
+                                                     uint32_t* __restrict__ key, int* __restrict__ state) {
+    __shared__ float s_sim[256 * MAXE];
+    __shared__ int s_cnt[MAXP];
+    for (int i = threadIdx.x; i < 256 * MAXE; i += 256) {
+        const int j = i / MAXE, e = i % MAXE;
+        s_sim[i] = e < E ? sim_n[j * E + e] : 0.f;
+    }
+    if (threadIdx.x < MAXP) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int e = threadIdx.x & 15;
+    const float scale = logit_scale[0];
+    for (long tok = (long)blockIdx.x * 16 + (threadIdx.x >> 4); tok < N; tok += (long)gridDim.x * 16) {
+        const float* p = proj + tok * 256;
+        float ss = 0.f, dot = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < 256; j += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + j);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            dot += v[0] * s_sim[(j + 0) * MAXE + e] + v[1] * s_sim[(j + 1) * MAXE + e] +
+                   v[2] * s_sim[(j + 2) * MAXE + e] + v[3] * s_sim[(j + 3) * MAXE + e];
+        }
+        const float denom = fmaxf(sqrtf(ss), 1e-12f);                 // F.normalize(dim=1)
+        const float logit = e < E ? (dot / denom) * scale : -INFINITY;
+        const float mx = group_max(logit, 16);
+        const float ex = e < E ? expf(logit - mx) : 0.f;
+        const float score = ex / group_sum(ex, 16);
+        // top-2, lowest index wins ties
+        const float m1 = group_max(score, 16);
+        int c1 = (score == m1 && e < E) ? e : 99;
+        for (int o = 8; o > 0; o >>= 1) c1 = min(c1, __shfl_xor(c1, o, 64));
+        const float sc2 = (e == c1 || e >= E) ? -1.f : score;
+        const float m2 = group_max(sc2, 16);
+        int c2 = (sc2 == m2 && e < E && e != c1) ? e : 99;
+        for (int o = 8; o > 0; o >>= 1) c2 = min(c2, __shfl_xor(c2, o, 64));
+        if (e == 0) {
+            const float den = fmaxf(m1 + m2, 1.1920928955078125e-07f);  // normalize_gate, finfo(float32).eps
+            idx[tok * 2] = c1;
+            idx[tok * 2 + 1] = c2;
+            gate[tok * 2] = m1 / den;
+            gate[tok * 2 + 1] = m2 / den;
+            key[tok] = __float_as_uint(m1);
+            atomicAdd(&s_cnt[c1], 1);
+            atomicAdd(&s_cnt[MAXE + c2], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < MAXP && s_cnt[threadIdx.x]) atomicAdd(&state[ST_CNT + threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// problem setup: limit per (choice, expert); active when the expert overflows.
+__global__ void route_init_k(int* __restrict__ state, int E, int capacity) {
+    const int p = threadIdx.x;  // 0..MAXP-1
+    __shared__ int any;
+    if (p == 0) any = 0;
+    __syncthreads();
+    if (p < MAXP) {
+        const int choice = p / MAXE, e = p % MAXE;
+        int act = 0, rank = 0;
+        if (e < E) {
+            const int c0 = state[ST_CNT + e];
+            const int cnt = state[ST_CNT + p];
+            const int limit = choice == 0 ? capacity : capacity - c0;   // second choices start at count_0[e]
+            if (limit <= 0) act = cnt > 0 ? -1 : 0;
+            else if (cnt > limit) { act = 1; rank = limit; }
+        }
+        state[ST_ACTIVE + p] = act;
+        state[ST_RANK + p] = rank;
+        state[ST_PREFIX + 2 * p] = 0;
+        state[ST_PREFIX + 2 * p + 1] = 0;
+        if (act == 1) atomicOr(&any, 1);
+    }
+    for (int i = threadIdx.x; i < MAXP * 256; i += blockDim.x) state[ST_HIST + i] = 0;
+    if (threadIdx.x < MAXE) { state[ST_KEPT + threadIdx.x] = 0; state[ST_FILL + threadIdx.x] = 0; }
+    __syncthreads();
+    if (p == 0) state[ST_ANY] = any;
+}
+
+// one radix pass (byte `pass` from the top of the 64-bit composite key)
+__global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx, const uint32_t* __restrict__ key,
+                                                    long N, int* __restrict__ state, int pass) {
+    if (state[ST_ANY] == 0) return;
+    __shared__ int h[MAXP * 256];
+    __shared__ int s_act[MAXP];
+    __shared__ unsigned long long s_pre[MAXP];
+    for (int i = threadIdx.x; i < MAXP * 256; i += 256) h[i] = 0;
+    if (threadIdx.x < MAXP) {
+        s_act[threadIdx.x] = state[ST_ACTIVE + threadIdx.x];
+        s_pre[threadIdx.x] = ((unsigned long long)(uint32_t)state[ST_PREFIX + 2 * threadIdx.x] << 32) |
+                             (uint32_t)state[ST_PREFIX + 2 * threadIdx.x + 1];
+    }
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    for (long a = (long)blockIdx.x * 256 + threadIdx.x; a < 2 * N; a += (long)gridDim.x * 256) {
+        const long tok = a >> 1;
+        const int p = (int)(a & 1) * MAXE + idx[a];
+        if (s_act[p] != 1) continue;
+        const unsigned long long V = composite(key[tok], (uint32_t)tok);
+        if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
+        atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MAXP * 256; i += 256)
+        if (h[i]) atomicAdd(&state[ST_HIST + i], h[i]);
+}
+
+// pick the bin holding the rank-th largest element; one workgroup per problem
+__global__ __launch_bounds__(256) void route_pick_k(int* __restrict__ state) {
+    if (state[ST_ANY] == 0) return;
+    const int p = blockIdx.x;
+    if (state[ST_ACTIVE + p] != 1) return;
+    __shared__ int suf[257];
+    const int b = threadIdx.x;
+    const int c = state[ST_HIST + p * 256 + b];
+    suf[b] = c;
+    if (b == 0) suf[256] = 0;
+    __syncthreads();
+    // suffix sums (inclusive): suf[b] = sum_{j >= b} hist[j]
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (b + o < 256) ? suf[b + o] : 0;
+        __syncthreads();
+        suf[b] += v;
+        __syncthreads();
+    }
+    const int rank = state[ST_RANK + p];
+    // the chosen bin is the largest b with suf[b] >= rank  (suf is non-increasing in b)
+    const bool here = suf[b] >= rank && suf[b + 1] < rank;
+    state[ST_HIST + p * 256 + b] = 0;
+    if (here) {
+        unsigned long long pre = ((unsigned long long)(uint32_t)state[ST_PREFIX + 2 * p] << 32) |
+                                 (uint32_t)state[ST_PREFIX + 2 * p + 1];
+        pre = (pre << 8) | (unsigned long long)b;
+        state[ST_PREFIX + 2 * p] = (int)(uint32_t)(pre >> 32);
+        state[ST_PREFIX + 2 * p + 1] = (int)(uint32_t)pre;
+        state[ST_RANK + p] = rank - suf[b + 1];
+    }
+}
+
+// keep/drop + combine weights + per-expert kept counts
+__global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx, const float* __restrict__ gate,
+                                                    const uint32_t* __restrict__ key, long N,
+                                                    float* __restrict__ comb_w, int* __restrict__ state) {
+    __shared__ int s_act[MAXP];
+    __shared__ unsigned long long s_thr[MAXP];
+    __shared__ int s_kept[MAXE];
+    if (threadIdx.x < MAXP) {
+        s_act[threadIdx.x] = state[ST_ACTIVE + threadIdx.x];
+        s_thr[threadIdx.x] = ((unsigned long long)(uint32_t)state[ST_PREFIX + 2 * threadIdx.x] << 32) |
+                             (uint32_t)state[ST_PREFIX + 2 * threadIdx.x + 1];
+    }
+    if (threadIdx.x < MAXE) s_kept[threadIdx.x] = 0;
+    __syncthreads();
+    for (long a = (long)blockIdx.x * 256 + threadIdx.x; a < 2 * N; a += (long)gridDim.x * 256) {
+        const long tok = a >> 1;
+        const int e = idx[a];
+        const int p = (int)(a & 1) * MAXE + e;
+        bool keep = true;
+        if (s_act[p] == -1) keep = false;
+        else if (s_act[p] == 1) keep = composite(key[tok], (uint32_t)tok) >= s_thr[p];
+        comb_w[a] = keep ? gate[a] : 0.f;
+        if (keep) atomicAdd(&s_kept[e], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < MAXE && s_kept[threadIdx.x]) atomicAdd(&state[ST_KEPT + threadIdx.x], s_kept[threadIdx.x]);
+}
+
+// slot ranges + 128-row tile map
+__global__ void route_plan_k(int* __restrict__ state, int E, int* __restrict__ tile_group,
+                             int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
+    __shared__ int s_off[MAXE + 1], s_t0[MAXE + 1];
+    if (threadIdx.x == 0) {
+        int off = 0, nt = 0;
+        for (int e = 0; e < E; ++e) {
+            s_off[e] = off;
+            s_t0[e] = nt;
+            state[ST_OFF + e] = off;
+            const int cnt = state[ST_KEPT + e];
+            off += cnt;
+            nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+        }
+        s_off[E] = off;
+        s_t0[E] = nt;
+        state[ST_OFF + E] = off;
+        state[ST_NTILES] = min(nt, max_tiles);
+    }
+    __syncthreads();
+    const int nt = min(s_t0[E], max_tiles);
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+        int e = 0;
+        while (e + 1 < E && s_t0[e + 1] <= t) ++e;
+        const int r = (t - s_t0[e]) * TILE_ROWS;
+        tile_group[t] = e;
+        tile_row0[t] = s_off[e] + r;
+        tile_nrows[t] = min(TILE_ROWS, s_off[e + 1] - s_off[e] - r);
+    }
+}
+
+// compaction: workgroup-local cursors in LDS, one global reservation per (workgroup, expert)
+__global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx, const float* __restrict__ comb_w,
+                                                    long N, int* __restrict__ state, int* __restrict__ src_row,
+                                                    int* __restrict__ dst_row) {
+    constexpr int PER = 8;  // pairs per thread
+    __shared__ int s_cnt[MAXE];
+    __shared__ int s_base[MAXE];
+    if (threadIdx.x < MAXE) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long a0 = ((long)blockIdx.x * 256 + threadIdx.x) * PER;
+    int le[PER], lp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long a = a0 + i;
+        le[i] = -1;
+        if (a < 2 * N && comb_w[a] != 0.f) {
+            le[i] = idx[a];
+            lp[i] = atomicAdd(&s_cnt[le[i]], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < MAXE && s_cnt[threadIdx.x])
+        s_base[threadIdx.x] = state[ST_OFF + threadIdx.x] + atomicAdd(&state[ST_FILL + threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (le[i] >= 0) {
+            const long a = a0 + i;
+            const int slot = s_base[le[i]] + lp[i];
+            src_row[slot] = (int)(a >> 1);
+            dst_row[slot] = (int)a;
+        }
+    }
+}
+
+}  // namespace
+
+size_t mc_route_state_ints(int) { return ST_TOTAL; }
+const int* mc_route_num_tiles_ptr(const RouteBufs& rb) { return rb.state + ST_NTILES; }
+
+int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
+                          RouteBufs rb, hipStream_t s) {
+    MC_REQUIRE(E >= 2 && E <= MAXE, "gate: num_experts=%d unsupported (2..16)", E);
+    MC_HIP(hipMemsetAsync(rb.state, 0, sizeof(int) * (ST_CNT + MAXP), s));
+    int blocks = cdiv(N, 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gate_finish_k, dim3(blocks), dim3(256), 0, s, proj, sim_n, logit_scale, N, E, rb.idx, rb.gate,
+                       rb.key, rb.state);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_route(long N, int E, int capacity, RouteBufs rb, hipStream_t s) {
+    hipLaunchKernelGGL(route_init_k, dim3(1), dim3(256), 0, s, rb.state, E, capacity);
+    int blocks = cdiv(2 * N, 256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, rb.state, pass);
+        hipLaunchKernelGGL(route_pick_k, dim3(MAXP), dim3(256), 0, s, rb.state);
+    }
+    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, rb.comb_w, rb.state);
+    hipLaunchKernelGGL(route_plan_k, dim3(1), dim3(256), 0, s, rb.state, E, rb.tile_group, rb.tile_row0, rb.tile_nrows,
+                       rb.max_tiles);
+    hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * N, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, N, rb.state,
+                       rb.src_row, rb.dst_row);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

@@ -1,0 +1,210 @@
+"""Sampler host side: schedule tables + DDPM / DDIM loops driving the native denoiser.
+
+Mirrors the sampling half of the reference's ``mogen/models/utils/gaussian_diffusion.py`` API
+(``get_named_beta_schedule`` :235-260, ``space_timesteps`` :1346-1404, ``GaussianDiffusion`` tables
+:336-387, ``p_sample_loop`` :698-797, ``ddim_sample_loop`` :925-1049, ``SpacedDiffusion`` :1407-1448)
+so callers written against it keep working; the per-step arithmetic itself (network, CFG combine,
+posterior / DDIM update) runs in libmotioncraft_amd.so.  Training losses, learned variances,
+cond_fn guidance and the RePaint/outpainting mode are outside this path and raise loudly.
+"""
+import enum
+import math
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
+    if schedule_name == 'linear':
+        k = 1000 / num_diffusion_timesteps
+        return np.linspace(k * 0.0001, k * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == 'cosine':
+        f = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        n = num_diffusion_timesteps
+        return np.array([min(1 - f((i + 1) / n) / f(i / n), 0.999) for i in range(n)], dtype=np.float64)
+    raise NotImplementedError(f'unknown beta schedule: {schedule_name}')
+
+
+def space_timesteps(num_timesteps, section_counts):
+    """Retained original timesteps for a respacing spec ('15,15,8,6,6', [..] or 'ddimN')."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith('ddim'):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return set(range(0, num_timesteps, stride))
+            raise ValueError(f'cannot create exactly {num_timesteps} steps with an integer stride')
+        section_counts = [int(v) for v in section_counts.split(',')]
+    base, extra = divmod(num_timesteps, len(section_counts))
+    kept, start = [], 0
+    for i, count in enumerate(section_counts):
+        size = base + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f'cannot divide section of {size} steps into {count}')
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        pos = 0.0
+        for _ in range(count):
+            kept.append(start + round(pos))
+            pos += stride
+        start += size
+    return set(kept)
+
+
+class GaussianDiffusion:
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type=None, rescale_timesteps=False,
+                 opt=None):
+        self.opt = opt
+        self.model_mean_type, self.model_var_type, self.loss_type = model_mean_type, model_var_type, loss_type
+        self.rescale_timesteps = rescale_timesteps
+        betas = np.array(betas, dtype=np.float64)
+        if betas.ndim != 1 or not ((betas > 0).all() and (betas <= 1).all()):
+            raise ValueError('betas must be a 1-D array in (0, 1]')
+        self.betas = betas
+        self.num_timesteps = int(betas.shape[0])
+        if not hasattr(self, 'timestep_map'):
+            self.timestep_map = list(range(self.num_timesteps))
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod = ac
+        self.alphas_cumprod_prev = np.append(1.0, ac[:-1])
+        self.alphas_cumprod_next = np.append(ac[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(ac)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - ac)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / ac)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / ac - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - ac)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - ac)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - ac)
+
+    # ------------------------------------------------------------------------------------------
+    def _check_supported(self, clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq=None, transl_req=None):
+        if self.model_mean_type != ModelMeanType.START_X:
+            raise NotImplementedError('the MI355X path implements model_mean_type="start_x" (all stmogen configs)')
+        if self.model_var_type != ModelVarType.FIXED_LARGE:
+            raise NotImplementedError('the MI355X path implements model_var_type="fixed_large" (all stmogen configs)')
+        if clip_denoised or denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError('clip_denoised / denoised_fn / cond_fn are not on the MotionDiffusion eval path '
+                                      '(diffusion_architecture.py:177-191 passes clip_denoised=False)')
+        if pre_seq is not None or transl_req is not None:
+            raise NotImplementedError('pre_seq / transl_req seeding is not on this path (SURVEY.md section 8f)')
+        y = (model_kwargs or {}).get('y', {}) or {}
+        if 'outpainting_mask' in y:
+            raise NotImplementedError('RePaint / outpainting mode is listed as "next" (SURVEY.md section 8f.1)')
+
+    def step_coefs(self, i, mode, scale, eta=0.0):
+        """fp64 tables -> fp32 scalars exactly like _extract_into_tensor(...).float()."""
+        t_orig = self.timestep_map[i]
+        w = (1 - (1000 - int(t_orig)) / 1000) * scale + 1
+        c = _lib.StepCoefs()
+        c.mode = 0 if mode == 'ddpm' else 1
+        c.text_coef, c.none_coef = w, 1 - w
+        c.c1, c.c2 = self.posterior_mean_coef1[i], self.posterior_mean_coef2[i]
+        c.log_var = math.log(self.posterior_variance[1] if i == 0 else self.betas[i])
+        c.sqrt_recip, c.sqrt_recipm1 = self.sqrt_recip_alphas_cumprod[i], self.sqrt_recipm1_alphas_cumprod[i]
+        c.ab, c.ab_prev, c.eta = self.alphas_cumprod[i], self.alphas_cumprod_prev[i], eta
+        c.nonzero = 0.0 if i == 0 else 1.0
+        return c
+
+    def _loop(self, mode, model, shape, noise, model_kwargs, device, progress, eta, step_noise, generator,
+              num_steps=None, trajectory=None):
+        if model_kwargs is None:
+            model_kwargs = {}
+        if not isinstance(shape, (tuple, list)):
+            raise AssertionError('shape must be a tuple or list')
+        B, T, C = shape
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        ctx = model.sampling_context(B, T, self.timestep_map, model_kwargs, device)
+        if noise is not None:
+            img = noise.to(device=device, dtype=torch.float32).contiguous().clone()
+        else:
+            img = torch.randn(*shape, device=device, generator=generator)
+        indices = list(range(self.num_timesteps))[::-1]
+        if num_steps is not None:
+            indices = indices[:num_steps]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        nxt = torch.empty_like(img)
+        x0 = torch.empty_like(img) if trajectory is not None else None
+        for i in indices:
+            if step_noise is None:
+                eps = torch.randn(*shape, device=device, generator=generator)   # drawn every step, DDIM too
+            else:
+                eps = step_noise(i) if callable(step_noise) else step_noise[i]
+                eps = eps.to(device=device, dtype=torch.float32).contiguous()
+            ctx.sample_step(img, i, self.step_coefs(i, mode, model.cfg_scale, eta), eps, x_prev=nxt, x0=x0)
+            img, nxt = nxt, img
+            if trajectory is not None:
+                trajectory.append((i, img.clone(), x0.clone()))
+        return img
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, pre_seq=None, transl_req=None, progress=False,
+                      step_noise=None, generator=None, num_steps=None, trajectory=None):
+        self._check_supported(clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq, transl_req)
+        return self._loop('ddpm', model, shape, noise, model_kwargs, device, progress, 0.0, step_noise, generator,
+                          num_steps, trajectory)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, pre_seq=None,
+                         step_noise=None, generator=None, num_steps=None, trajectory=None):
+        self._check_supported(clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq)
+        if self.opt is not None and getattr(self.opt, 'same_overlap_noisy', False):
+            raise NotImplementedError('same_overlap_noisy belongs to the RePaint mode (SURVEY.md section 8f.1)')
+        return self._loop('ddim', model, shape, noise, model_kwargs, device, progress, float(eta), step_noise,
+                          generator, num_steps, trajectory)
+
+
+class SpacedDiffusion(GaussianDiffusion):
+    """Skips steps of a base process: betas re-derived from the retained alpha-bars; the network is
+    fed ``timestep_map[i]`` (the original timestep), as the reference's ``_WrappedModel`` does."""
+
+    def __init__(self, use_timesteps, **kwargs):
+        self.use_timesteps = set(use_timesteps)
+        self.original_num_steps = len(kwargs['betas'])
+        base_ac = np.cumprod(1.0 - np.array(kwargs['betas'], dtype=np.float64), axis=0)
+        self.timestep_map, new_betas, last = [], [], 1.0
+        for i, a in enumerate(base_ac):
+            if i in self.use_timesteps:
+                new_betas.append(1 - a / last)
+                last = a
+                self.timestep_map.append(i)
+        kwargs['betas'] = np.array(new_betas)
+        super().__init__(**kwargs)
+
+
+def build_diffusion(cfg, opt=None):
+    """cfg = diffusion_test / diffusion_train dict of the configs (diffusion_architecture.py:25-54)."""
+    betas = get_named_beta_schedule(cfg['beta_scheduler'], cfg['diffusion_steps'])
+    mean_type = {'start_x': ModelMeanType.START_X, 'previous_x': ModelMeanType.PREVIOUS_X,
+                 'epsilon': ModelMeanType.EPSILON}[cfg['model_mean_type']]
+    var_type = {'learned': ModelVarType.LEARNED, 'fixed_small': ModelVarType.FIXED_SMALL,
+                'fixed_large': ModelVarType.FIXED_LARGE, 'learned_range': ModelVarType.LEARNED_RANGE}[cfg['model_var_type']]
+    if cfg.get('respace', None) is not None:
+        return SpacedDiffusion(use_timesteps=space_timesteps(cfg['diffusion_steps'], cfg['respace']), betas=betas,
+                               model_mean_type=mean_type, model_var_type=var_type, loss_type=LossType.MSE, opt=opt)
+    return GaussianDiffusion(betas=betas, model_mean_type=mean_type, model_var_type=var_type, loss_type=LossType.MSE)

@@ -1,0 +1,142 @@
+"""Thin Python owner of the native handles: ``NativeModel`` (weights in HBM) and ``NativeContext``
+(workspace + schedule tables + condition K/V for one (batch, frames) shape).
+
+PyTorch is used only for device memory and the stream handle; every compute step is a call into
+libmotioncraft_amd.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .weights import pack_state_dict
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f'{name} must be a contiguous float32 tensor in device (HBM) memory')
+    return t
+
+
+class NativeModel:
+    def __init__(self, dims, state_dict, cfg_scale=6.5, capacity_factor=1.5, dyn_heads=8, device=None):
+        self.lib = _lib.load(require_gpu=True)
+        if device is not None:
+            torch.cuda.set_device(device)
+            _lib.check(self.lib.mc_set_device(torch.cuda.current_device()), 'mc_set_device')
+        self.dims = dict(dims)
+        cfg = _lib.ModelConfig(
+            input_feats=dims['input_feats'], max_seq_len=dims['max_seq_len'], latent_dim=dims['L'],
+            num_parts=dims['H'], num_layers=dims['NL'], ffn_dim=dims['F'], time_embed_dim=dims['Te'],
+            text_latent_dim=dims['Dt'], max_text_len=dims['Nt'], num_experts=dims['E'], topk=dims.get('topk', 2),
+            dyn_heads=dyn_heads, capacity_factor=capacity_factor, cfg_scale=cfg_scale)
+        self.cfg_scale = float(cfg_scale)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mc_model_create(ctypes.byref(cfg), ctypes.byref(h)), 'mc_model_create')
+        self.handle = h
+        for name, arr in pack_state_dict(state_dict, dims).items():
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            _lib.check(self.lib.mc_model_set_param(self.handle, name.encode(), arr.ctypes.data_as(ctypes.c_void_p),
+                                                   arr.size), f'mc_model_set_param({name})')
+        _lib.check(self.lib.mc_model_finalize(self.handle), 'mc_model_finalize')
+
+    def context(self, batch, frames, max_steps=1000):
+        return NativeContext(self, batch, frames, max_steps)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.mc_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeContext:
+    def __init__(self, model, batch, frames, max_steps):
+        self.model, self.lib = model, model.lib
+        self.B, self.T, self.C = int(batch), int(frames), model.dims['input_feats']
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mc_ctx_create(model.handle, self.B, self.T, int(max_steps), ctypes.byref(h)), 'mc_ctx_create')
+        self.handle = h
+        self.timesteps = None
+        self._keep = []
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.mc_ctx_workspace_bytes(self.handle))
+
+    def set_timesteps(self, t_orig):
+        t = np.ascontiguousarray(np.asarray(t_orig, dtype=np.int32))
+        _lib.check(self.lib.mc_ctx_set_timesteps(self.handle, t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                 len(t), _stream()), 'mc_ctx_set_timesteps')
+        self.timesteps = [int(v) for v in t]
+
+    def set_condition(self, xf_out, motion_mask):
+        xf = _dev_f32(xf_out, 'xf_out')
+        mask = _dev_f32(motion_mask, 'motion_mask')
+        d = self.model.dims
+        if tuple(xf.shape) != (self.B, d['Nt'], d['Dt']):
+            raise ValueError(f'xf_out shape {tuple(xf.shape)} != {(self.B, d["Nt"], d["Dt"])}')
+        if mask.numel() != self.B * self.T:
+            raise ValueError(f'motion_mask has {mask.numel()} elements, expected {self.B * self.T}')
+        self._keep = [xf, mask]        # the library reads the mask every step: keep it alive
+        _lib.check(self.lib.mc_ctx_set_condition(self.handle, _ptr(xf), _ptr(mask), _stream()), 'mc_ctx_set_condition')
+
+    def denoise(self, x_t, step_index, out2=None, stop_after_layers=-1):
+        x = _dev_f32(x_t, 'x_t')
+        if tuple(x.shape) != (self.B, self.T, self.C):
+            raise ValueError(f'x_t shape {tuple(x.shape)} != {(self.B, self.T, self.C)}')
+        if out2 is None and stop_after_layers < 0:
+            out2 = torch.empty(2 * self.B, self.T, self.C, device=x.device, dtype=torch.float32)
+        _lib.check(self.lib.mc_denoise(self.handle, _ptr(x), int(step_index), _ptr(out2), int(stop_after_layers),
+                                       _stream()), 'mc_denoise')
+        return out2
+
+    def sample_step(self, x_t, step_index, coefs, noise, x_prev=None, x0=None):
+        x = _dev_f32(x_t, 'x_t')
+        n = _dev_f32(noise, 'noise')
+        if x_prev is None:
+            x_prev = torch.empty_like(x)
+        _lib.check(self.lib.mc_sample_step(self.handle, _ptr(x), int(step_index), ctypes.byref(coefs), _ptr(n),
+                                           _ptr(x_prev), _ptr(x0), _stream()), 'mc_sample_step')
+        return x_prev
+
+    def buffer(self, name, layer=0, dtype=torch.float32):
+        """Copy of a named workspace buffer (tests)."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_int64()
+        _lib.check(self.lib.mc_ctx_get_buffer(self.handle, name.encode(), int(layer), ctypes.byref(p), ctypes.byref(n)),
+                   'mc_ctx_get_buffer')
+        out = torch.empty(n.value, device='cuda', dtype=dtype)
+        torch.cuda.current_stream().synchronize()
+        import ctypes as _c
+        hip = _c.CDLL('libamdhip64.so')
+        hip.hipMemcpy.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int]
+        rc = hip.hipMemcpy(_c.c_void_p(out.data_ptr()), p, n.value * out.element_size(), 3)
+        if rc != 0:
+            raise RuntimeError(f'hipMemcpy failed: {rc}')
+        return out
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.mc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,89 @@
+"""ctypes binding of libmotioncraft_amd.so (C-ABI in include/motioncraft_amd.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  Importing this module
+succeeds without the library (so configs/registries can be used on a CPU box), but any attempt
+to run the path raises ``RuntimeError`` when the HIP library is missing or no MI355X is visible.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmotioncraft_amd.so')
+
+MC_OK = 0
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+class ModelConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'input_feats', 'max_seq_len', 'latent_dim', 'num_parts', 'num_layers', 'ffn_dim',
+        'time_embed_dim', 'text_latent_dim', 'max_text_len', 'num_experts', 'topk', 'dyn_heads')] + [
+        ('capacity_factor', ctypes.c_float), ('cfg_scale', ctypes.c_float)]
+
+
+class StepCoefs(ctypes.Structure):
+    _fields_ = [('mode', ctypes.c_int32)] + [(n, ctypes.c_float) for n in (
+        'text_coef', 'none_coef', 'c1', 'c2', 'log_var', 'sqrt_recip', 'sqrt_recipm1', 'ab', 'ab_prev',
+        'eta', 'nonzero')]
+
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    'mc_last_error': (ctypes.c_char_p, []),
+    'mc_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'mc_set_device': (ctypes.c_int, [ctypes.c_int]),
+    'mc_model_create': (ctypes.c_int, [ctypes.POINTER(ModelConfig), ctypes.POINTER(_P)]),
+    'mc_model_destroy': (None, [_P]),
+    'mc_model_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),
+    'mc_model_finalize': (ctypes.c_int, [_P]),
+    'mc_ctx_create': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    'mc_ctx_destroy': (None, [_P]),
+    'mc_ctx_workspace_bytes': (ctypes.c_int64, [_P]),
+    'mc_ctx_set_timesteps': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, _P]),
+    'mc_ctx_set_condition': (ctypes.c_int, [_P, _P, _P, _P]),
+    'mc_denoise': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
+    'mc_sample_step': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, _P, _P, _P]),
+    'mc_ctx_get_buffer': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P),
+                                         ctypes.POINTER(ctypes.c_int64)]),
+    'mc_op_gemm': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                  ctypes.c_int32, ctypes.c_int32, _P]),
+    'mc_op_ln_rows': (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int32, _P, ctypes.c_int64,
+                                     ctypes.c_int32, _P]),
+    'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load(require_gpu=False):
+    """Load the shared library (no compute call).  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python -m motioncraft_amd.build` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if require_gpu:
+        n = ctypes.c_int(0)
+        rc = _lib.mc_device_count(ctypes.byref(n))
+        if rc != MC_OK or n.value < 1:
+            raise RuntimeError('motioncraft_amd: no HIP device visible (the hot path runs on MI355X only): '
+                               + last_error())
+    return _lib
+
+
+def last_error():
+    return (_lib.mc_last_error() or b'').decode() if _lib is not None else ''
+
+
+def check(rc, what=''):
+    if rc != MC_OK:
+        raise RuntimeError(f'motioncraft_amd {what} failed (code {rc}): {last_error()}')

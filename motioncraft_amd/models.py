@@ -1,0 +1,290 @@
+"""Host-side mirrors of the reference classes on the hot path, registered under the SAME names so
+``configs/stmogen/*.py`` build unchanged:
+
+  MotionDiffusion      mogen/models/architectures/diffusion_architecture.py:57-204 (eval branch)
+  STMoGenTransformer   mogen/models/transformers/stmogen.py:626-761
+  STMA                 mogen/models/attentions/st_attention.py:64-103 (config holder; the arithmetic
+                       is inside libmotioncraft_amd.so)
+  MSELoss              mogen/models/losses (training only: accepted, inert)
+
+They own no arithmetic: weights are packed once into HBM (``weights.py``), every denoiser call goes
+through the C-ABI.  Training entry points raise: training is not part of this path.
+"""
+import torch
+
+from .builder import ARCHITECTURES, ATTENTIONS, LOSSES, SUBMODULES, build_attention, build_loss, build_submodule
+from .diffusion import build_diffusion
+from .engine import NativeModel
+
+
+@ATTENTIONS.register_module()
+class STMA:
+    """Configuration of one MC-Attn block (kwargs exactly as in ca_block_cfg of the configs)."""
+
+    def __init__(self, latent_dim, text_latent_dim, num_heads, num_text_heads, num_experts, topk, gate_type,
+                 gate_noise, ffn_dim, time_embed_dim, max_seq_len, max_text_seq_len, temporal_comb, dropout,
+                 static_body=True, dynamic_body=False, patch_size=1):
+        if gate_type != 'cosine_top':
+            raise NotImplementedError(f"gate_type={gate_type!r}: the stmogen configs use 'cosine_top'")
+        if num_text_heads != 1 or not static_body or not dynamic_body or patch_size != 1:
+            raise NotImplementedError('the MI355X path covers num_text_heads=1, static_body=True, dynamic_body=True, '
+                                      'patch_size=1 (every shipped stmogen motionx config)')
+        if dropout != 0:
+            raise NotImplementedError('dropout != 0 is a training setting')
+        self.latent_dim, self.text_latent_dim, self.num_heads = latent_dim, text_latent_dim, num_heads
+        self.num_experts, self.topk, self.max_seq_len, self.max_text_seq_len = num_experts, topk, max_seq_len, max_text_seq_len
+        self.time_embed_dim, self.ffn_dim = time_embed_dim, ffn_dim
+
+
+@LOSSES.register_module()
+class MSELoss:
+    def __init__(self, reduction='mean', loss_weight=1.0):
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+
+@SUBMODULES.register_module()
+class STMoGenTransformer:
+    def __init__(self, input_feats, max_seq_len=240, latent_dim=512, time_embed_dim=2048, num_layers=8,
+                 sa_block_cfg=None, ca_block_cfg=None, ffn_cfg=None, text_encoder=None, use_pos_embedding=True,
+                 use_residual_connection=False, time_embedding_type='sinusoidal', post_process_cfg=None,
+                 init_cfg=None, patch_size=1, scale_func_cfg=None, pose_encoder_cfg=None, pose_decoder_cfg=None,
+                 moe_route_loss_weight=1.0, template_kl_loss_weight=0.0001):
+        if sa_block_cfg is not None or not use_pos_embedding or use_residual_connection or patch_size != 1 \
+                or time_embedding_type != 'sinusoidal':
+            raise NotImplementedError('option outside the shipped stmogen configs')
+        for c in (pose_encoder_cfg, pose_decoder_cfg):
+            if c.get('dataset_name') != 'motionx' or c.get('joints', False) or c.get('body_graph', False):
+                raise NotImplementedError("the MI355X path covers dataset_name='motionx' (12 parts, 322-d SMPL-X); "
+                                          'human_ml3d is listed as "next" (SURVEY.md section 8f.4)')
+        if isinstance(ffn_cfg, list):
+            raise NotImplementedError('per-layer ffn_cfg lists are not used by the shipped configs')
+        self.ca_block = build_attention(ca_block_cfg)
+        a = self.ca_block
+        if latent_dim != a.latent_dim * a.num_heads:
+            raise ValueError('latent_dim must equal ca_block_cfg.latent_dim * num_heads')
+        self.input_feats, self.max_seq_len, self.latent_dim = input_feats, max_seq_len, latent_dim
+        self.num_layers, self.time_embed_dim = num_layers, time_embed_dim
+        self.scale_func_cfg = scale_func_cfg
+        self.cfg_scale = float(scale_func_cfg['scale'])
+        self.post_process_cfg = post_process_cfg
+        self.text_encoder_cfg = text_encoder
+        self.use_text_proj = bool(text_encoder.get('use_text_proj', False)) if text_encoder else False
+        if self.use_text_proj:
+            raise NotImplementedError('use_text_proj=True is not used by the shipped configs')
+        self.dims = dict(input_feats=input_feats, max_seq_len=max_seq_len, L=a.latent_dim, H=a.num_heads,
+                         NL=num_layers, F=ffn_cfg['ffn_dim'], Te=time_embed_dim, Dt=a.text_latent_dim,
+                         Nt=a.max_text_seq_len, E=a.num_experts, topk=a.topk)
+        self.training = False
+        self._native = None
+        self._ctx = {}
+        self._state = None
+
+    # ---- nn.Module-ish surface used by the tools ---------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('training is outside the MI355X sampling path')
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._state = dict(state_dict)
+        self.release()
+        return self
+
+    def to(self, device=None, *a, **k):
+        if device is not None and torch.device(device).type == 'cpu':
+            raise RuntimeError('motioncraft_amd has no CPU path: the denoiser runs on MI355X only')
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def release(self):
+        for c in self._ctx.values():
+            c.close()
+        self._ctx = {}
+        if self._native is not None:
+            self._native.close()
+        self._native = None
+
+    # ---- native plumbing ------------------------------------------------------------------------
+    @property
+    def native(self):
+        if self._native is None:
+            if self._state is None:
+                raise RuntimeError('load_state_dict() has not been called: no weights to run')
+            self._native = NativeModel(self.dims, self._state, cfg_scale=self.cfg_scale)
+        return self._native
+
+    def sampling_context(self, B, T, timestep_map, model_kwargs, device=None):
+        """Context with FiLM tables for ``timestep_map`` and text K/V for ``model_kwargs['xf_out']``."""
+        key = (int(B), int(T))
+        ctx = self._ctx.get(key)
+        if ctx is None or ctx.max_steps < len(timestep_map):
+            if ctx is not None:
+                ctx.close()
+            ctx = self.native.context(B, T, max_steps=max(len(timestep_map), 50))
+            ctx.max_steps = max(len(timestep_map), 50)
+            self._ctx[key] = ctx
+        if ctx.timesteps != [int(t) for t in timestep_map]:
+            ctx.set_timesteps(timestep_map)
+        if model_kwargs.get('c', None) is not None:
+            raise NotImplementedError('control-branch condition `c` needs ControlT2MHalf (SURVEY.md a15)')
+        xf = model_kwargs.get('xf_out', None)
+        if xf is None:
+            raise ValueError("model_kwargs['xf_out'] is required (see get_precompute_condition)")
+        mask = model_kwargs.get('motion_mask', None)
+        if mask is None:
+            raise ValueError("model_kwargs['motion_mask'] is required")
+        dev = device or torch.device('cuda', torch.cuda.current_device())
+        xf = xf.to(device=dev, dtype=torch.float32).contiguous()
+        mask = mask.to(device=dev, dtype=torch.float32).reshape(B, T).contiguous()
+        ctx.set_condition(xf, mask)
+        return ctx
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def get_precompute_condition(self, text=None, motion_length=None, xf_out=None, re_dict=None, device=None,
+                                 sample_idx=None, clip_feat=None, **kwargs):
+        if xf_out is None:
+            raise NotImplementedError(
+                'the CLIP text tower + textTransEncoder run once per batch, off the per-step path, and need external '
+                'weights (SURVEY.md section 8f.2): pass the frozen condition embedding as xf_out [B, 77, text_latent_dim]')
+        return {'xf_out': xf_out}
+
+    def post_process(self, motion):
+        if self.post_process_cfg is not None:
+            import numpy as np
+            mean = torch.from_numpy(np.load(self.post_process_cfg['mean_path'])).type_as(motion)
+            std = torch.from_numpy(np.load(self.post_process_cfg['std_path'])).type_as(motion)
+            motion = motion * std + mean
+        return motion
+
+    def scale_func(self, timestep):
+        w = (1 - (1000 - timestep) / 1000) * self.cfg_scale + 1
+        return {'text_coef': w, 'none_coef': 1 - w}
+
+    def forward(self, motion, timesteps, motion_mask=None, motion_length=None, num_intervals=1, patch_size=1,
+                **kwargs):
+        """One denoiser evaluation ``model(x, ts, **model_kwargs)`` -> CFG-combined x0 [B,T,C]."""
+        t = int(timesteps[0])
+        if not bool((timesteps == t).all()):
+            raise NotImplementedError('per-sample timesteps differ: the sampler always uses one t per batch')
+        B, T, _ = motion.shape
+        kw = dict(kwargs)
+        kw['motion_mask'] = motion_mask
+        ctx = self.sampling_context(B, T, [t], kw, motion.device if motion.is_cuda else None)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        out2 = ctx.denoise(motion.to(device=dev, dtype=torch.float32).contiguous(), 0)
+        c = self.scale_func(t)
+        return out2[:B] * c['text_coef'] + out2[B:] * c['none_coef']
+
+    __call__ = forward
+
+
+def to_cpu(x):
+    return x.detach().cpu() if isinstance(x, torch.Tensor) else x
+
+
+@ARCHITECTURES.register_module()
+class MotionDiffusion:
+    def __init__(self, model=None, loss_recon=None, loss_reduction='frame', diffusion_train=None, diffusion_test=None,
+                 sampler_type='uniform', init_cfg=None, inference_type='ddpm', opt=None, hand_loss_factor=1.0,
+                 face_no_loss=False, hand_no_loss=False, **kwargs):
+        self.inference_type = inference_type
+        self.opt = opt
+        if self.inference_type != 'gt':
+            self.model = build_submodule(model)
+        self.loss_recon = build_loss(loss_recon)
+        self.diffusion_train_cfg = diffusion_train
+        self.diffusion_test = build_diffusion(diffusion_test, opt=opt)
+        self.training = False
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('training is outside the MI355X sampling path')
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        if self.inference_type != 'gt':
+            self.model.load_state_dict(state_dict, strict=strict)
+        return self
+
+    def forward(self, **kwargs):
+        """Eval branch of the reference's MotionDiffusion.forward (diffusion_architecture.py:163-204)."""
+        if self.training:
+            raise NotImplementedError('training is outside the MI355X sampling path')
+        motion = kwargs['motion'].float()
+        motion_mask = kwargs['motion_mask'].float()
+        motion_length = kwargs['motion_length']
+        num_intervals = kwargs.get('num_intervals', 1)
+        sample_idx = kwargs.get('sample_idx', None)
+        patch_size = kwargs.get('patch_size', 1)
+        c = kwargs.get('c', None)
+        y = kwargs.get('y', {})
+        B, T = motion.shape[:2]
+        text = [kwargs['motion_metas'][i]['text'] for i in range(B)] if 'motion_metas' in kwargs else None
+        dim_pose = kwargs['motion'].shape[-1]
+        if self.inference_type != 'gt':
+            cond_kw = {k: v for k, v in kwargs.items() if k not in ('text', 'device')}
+            model_kwargs = self.model.get_precompute_condition(device=motion.device, text=text, **cond_kw)
+            model_kwargs.update(motion_mask=motion_mask, sample_idx=sample_idx, motion_length=motion_length,
+                                num_intervals=num_intervals, c=c, y=y, patch_size=patch_size)
+            inference_kwargs = kwargs.get('inference_kwargs', {})
+        if self.inference_type == 'ddpm':
+            output = self.diffusion_test.p_sample_loop(self.model, (B, T, dim_pose), clip_denoised=False,
+                                                       progress=False, model_kwargs=model_kwargs, **inference_kwargs)
+        elif self.inference_type == 'ddim':
+            output = self.diffusion_test.ddim_sample_loop(self.model, (B, T, dim_pose), clip_denoised=False,
+                                                          progress=False, model_kwargs=model_kwargs, eta=0,
+                                                          **inference_kwargs)
+        elif self.inference_type == 'gt':
+            output = motion
+        else:
+            raise KeyError(self.inference_type)
+        results = kwargs
+        if self.inference_type != 'gt':
+            output = self.model.post_process(output)
+        results['pred_motion'] = output
+        return self.split_results(results)
+
+    __call__ = forward
+
+    @staticmethod
+    def split_results(results):
+        """base_architecture.py:112-140."""
+        B = results['motion'].shape[0]
+        output = []
+        for i in range(B):
+            o = dict()
+            o['motion'] = to_cpu(results['motion'][i])
+            o['pred_motion'] = to_cpu(results['pred_motion'][i])
+            o['motion_length'] = to_cpu(results['motion_length'][i])
+            o['motion_mask'] = to_cpu(results['motion_mask'][i])
+            o['pred_motion_length'] = to_cpu(results['pred_motion_length'][i]) if 'pred_motion_length' in results \
+                else to_cpu(results['motion_length'][i])
+            o['pred_motion_mask'] = to_cpu(results['pred_motion_mask'][i]) if 'pred_motion_mask' in results \
+                else to_cpu(results['motion_mask'][i])
+            if 'motion_metas' in results:
+                metas = results['motion_metas'][i]
+                if 'text' in metas:
+                    o['text'] = metas['text']
+                if 'token' in metas:
+                    o['token'] = metas['token']
+            output.append(o)
+        return output

@@ -16,7 +16,7 @@ What it does
 
 Fixtures
   schedules.npz         a1/a2 tables for linear-1000 and respace '15,15,8,6,6'
-  small_modules.npz     reduced config (L=16,NL=2,T=24,B=2, one padded sample): denoiser
+  small_modules.npz     reduced config (L=32,NL=2,T=24,B=2, one padded sample): denoiser
                         call at t=777 with per-layer intermediates captured by hooks
   small_ddim.npz        reduced config: 50-step DDIM trajectory (every 10th x_t) + final
   small_ddpm.npz        reduced config: 1000-step schedule, first 20 DDPM steps
@@ -38,8 +38,9 @@ from oracle import ref_shim, stmogen_oracle as O, weights as W  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
-SMALL = W.default_dims(max_seq_len=24, L=16, NL=2, F=32, Te=64, Dt=32, Nt=8)
+SMALL = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
 FULL = W.default_dims()
+SMALL_SEED = 2   # weight seed whose routing overflows the expert capacity in both layers (drops are exercised)
 DIFF_DDIM = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
                  model_var_type='fixed_large', respace='15,15,8,6,6')
 DIFF_DDPM = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
@@ -106,7 +107,7 @@ def schedules():
 
 def small_modules():
     dims, B, T = SMALL, 2, 24
-    m, sd = build_ref(dims)
+    m, sd = build_ref(dims, SMALL_SEED)
     x_T, xf, mask = synth_inputs(dims, B, T, seed=11, lengths=[24, 17])
     t = 777
     cap = {}
@@ -186,7 +187,7 @@ def run_oracle_loop(sd, dims, sched, mode, x_T, xf, mask, seed, num_steps=None):
 
 def small_loops():
     dims, B, T = SMALL, 2, 24
-    m, sd = build_ref(dims)
+    m, sd = build_ref(dims, SMALL_SEED)
     x_T, xf, mask = synth_inputs(dims, B, T, seed=12, lengths=[20, 24])
     # DDIM 50
     diff = ref_shim.build_reference_diffusion(DIFF_DDIM)

@@ -7,8 +7,9 @@ import torch
 from oracle import weights as W
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
-SMALL = W.default_dims(max_seq_len=24, L=16, NL=2, F=32, Te=64, Dt=32, Nt=8)
+SMALL = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
 FULL = W.default_dims()
+SMALL_SEED = 2
 
 
 def synth_inputs(dims, B, T, seed, lengths=None):

@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""One-shot GPU diagnostic ladder (run on the MI355X box): prints max-abs errors of the HIP path
+against the CPU oracle stage by stage, so a single `gpurun` call localises a bug.  Not a test
+(the asserting versions live in tests/test_gpu_*.py)."""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from helpers import FULL, SMALL, SMALL_SEED, load, synth_inputs  # noqa: E402
+from motioncraft_amd import lib as L_  # noqa: E402
+from motioncraft_amd.engine import NativeModel, _ptr, _stream  # noqa: E402
+from oracle import stmogen_oracle as O, weights as W  # noqa: E402
+
+
+def err(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).abs().max()), float(b.abs().max())
+
+
+def show(name, a, b):
+    e, s = err(a, b)
+    flag = '' if e <= 2e-4 * max(1.0, s) else '   <-- LARGE'
+    print(f'  {name:28s} max|d| {e:.3e}   (ref max {s:.3e}){flag}', flush=True)
+    return e
+
+
+def check_ops():
+    lib = L_.load(require_gpu=True)
+    print('== op: gemm')
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K, act, res) in [(128, 128, 32, 0, False), (300, 200, 64, 1, True), (77, 322, 1536, 0, False),
+                                (1000, 64, 192, 2, False), (5, 3072, 2048, 0, False), (257, 129, 20, 0, True)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = a.double() @ w.double().t() + b.double()
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if act == 2:
+            ref = torch.nn.functional.silu(ref)
+        if res:
+            ref = ref + r.double()
+        ad, wd, bd, rd = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+        c = torch.empty(M, N, device='cuda')
+        L_.check(lib.mc_op_gemm(_ptr(ad), _ptr(wd), _ptr(bd), _ptr(rd if res else None), _ptr(c), M, N, K, K, act, _stream()))
+        torch.cuda.synchronize()
+        show(f'gemm {M}x{N}x{K} act{act} res{int(res)}', c, ref)
+    print('== op: ln_rows')
+    for Lw in (32, 128, 256):
+        x = torch.randn(1000, Lw, generator=g) * 2 + 0.5
+        ga, be = torch.randn(Lw, generator=g), torch.randn(Lw, generator=g)
+        add = torch.randn(24, Lw, generator=g)
+        ref = torch.nn.functional.layer_norm(x, (Lw,), ga, be) + add.repeat(42, 1)[:1000]
+        y = torch.empty(1000, Lw, device='cuda')
+        L_.check(lib.mc_op_ln_rows(_ptr(x.cuda()), Lw, _ptr(ga.cuda()), _ptr(be.cuda()), _ptr(add.cuda()), 24, _ptr(y),
+                                   1000, Lw, _stream()))
+        torch.cuda.synchronize()
+        show(f'ln_rows L={Lw}', y, ref)
+
+
+def model_and_ctx(dims, seed, B, T, steps):
+    sd = W.make_state_dict(dims, seed)
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    ctx = nm.context(B, T, max_steps=max(steps, 1))
+    return sd, nm, ctx
+
+
+def check_small():
+    print('== small config, stage by stage (t=777, B=2, T=24, one padded sample)')
+    dims = SMALL
+    g = load('small_modules.npz')
+    x_t, xf, mask = (torch.from_numpy(g[k]) for k in ('x_t', 'xf_out', 'motion_mask'))
+    B, T = 2, 24
+    sd, nm, ctx = model_and_ctx(dims, SMALL_SEED, B, T, 1)
+    cap = {}
+    x0_or = O.denoise(sd, dims, x_t, 777, xf, mask, cap=cap)
+    ctx.set_timesteps([777])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    show('emb (time MLP)', ctx.buffer('emb')[:dims['Te']], cap['emb'][0])
+    for i in range(dims['NL']):
+        show(f'text_feat layer{i}', ctx.buffer('tf', i), cap[f'layer{i}']['text_feat'])
+    xd = x_t.cuda()
+    ctx.denoise(xd, 0, stop_after_layers=0)
+    show('h0 (encoder + pos)', ctx.buffer('h'), cap['h0'].repeat(2, 1, 1))
+    for i in range(dims['NL']):
+        ctx.denoise(xd, 0, stop_after_layers=i + 1)
+        lc = cap[f'layer{i}']
+        # routing
+        pre = f'temporal_decoder_blocks.{i}.ca_block.'
+        hin = cap['h0'].repeat(2, 1, 1) if i == 0 else cap[f'layer{i-1}']['after_ffn']
+        zin = torch.nn.functional.layer_norm(hin.reshape(2 * B, T, dims['H'], dims['L']), (dims['L'],),
+                                             sd[pre + 'norm.weight'], sd[pre + 'norm.bias'])
+        _, r = O.moe_wrapper(sd, pre + 'motion_moe.', zin, return_routing=True)
+        idx = ctx.buffer('idx', dtype=torch.int32).view(-1, 2).cpu()
+        oidx = torch.stack(r['indices'], 1).int()
+        print(f'  layer{i} routing: idx mismatches {int((idx != oidx).sum())} / {idx.numel()}', flush=True)
+        cw = ctx.buffer('comb_w').view(-1, 2).cpu()
+        ocw = torch.stack([gt * k.float() for gt, k in zip(r['gates'], r['keeps'])], 1)
+        show(f'comb_w layer{i}', cw, ocw)
+        print(f'  layer{i} dropped: hip {int((cw == 0).sum())} oracle {int((ocw == 0).sum())}', flush=True)
+        show(f'motion_feat layer{i}', ctx.buffer('mf'), lc['motion_feat'])
+        show(f'y_s layer{i}', ctx.buffer('ys'), lc['y_s'])
+        show(f'y_t layer{i}', ctx.buffer('yt'), lc['y_t'])
+        show(f'ffn_z layer{i}', ctx.buffer('z2'), lc['ffn_z'])
+        show(f'h after layer{i}', ctx.buffer('h'), lc['after_ffn'])
+    out2 = ctx.denoise(xd, 0)
+    torch.cuda.synchronize()
+    show('out2 (decoder)', out2, cap['out2'])
+    show('out2 vs golden(reference)', out2, torch.from_numpy(g['out2']))
+    w = (1 - (1000 - 777) / 1000) * dims['scale'] + 1
+    show('x0 CFG', out2[:B] * w + out2[B:] * (1 - w), torch.from_numpy(g['x0']))
+
+
+def check_full(bench_b=(1, 8)):
+    print('== full 0.125b config, B=1, T=196 vs golden (reference)')
+    dims = FULL
+    g = load('full_denoise.npz')
+    x_T, xf, mask = synth_inputs(dims, 1, 196, int(g['input_seed']))
+    t0 = time.time()
+    sd, nm, ctx = model_and_ctx(dims, 0, 1, 196, 3)
+    print(f'  weights packed+uploaded in {time.time()-t0:.1f}s; workspace {ctx.workspace_bytes/2**20:.0f} MiB')
+    ctx.set_timesteps([999, 57, 500])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    for s, t in ((0, 999), (1, 57)):
+        out2 = ctx.denoise(x_T.cuda(), s)
+        w = (1 - (1000 - t) / 1000) * dims['scale'] + 1
+        show(f'x0 t={t}', out2[:1] * w + out2[1:] * (1 - w), torch.from_numpy(g[f'x0_t{t}']))
+    _, _, mask2 = synth_inputs(dims, 1, 196, int(g['input_seed']), lengths=[150])
+    ctx.set_condition(xf.cuda(), mask2.cuda())
+    out2 = ctx.denoise(x_T.cuda(), 2)
+    w = (1 - (1000 - 500) / 1000) * dims['scale'] + 1
+    show('x0 t=500 len=150', out2[:1] * w + out2[1:] * (1 - w), torch.from_numpy(g['x0_t500_len150']))
+    ctx.close()
+    print('== timing (denoiser call, CFG-doubled)')
+    for B in bench_b:
+        x_T, xf, mask = synth_inputs(dims, B, 196, 3)
+        ctx = nm.context(B, 196, max_steps=4)
+        ctx.set_timesteps([999, 500, 57, 0])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        xd = x_T.cuda()
+        out2 = torch.empty(2 * B, 196, 322, device='cuda')
+        for _ in range(2):
+            ctx.denoise(xd, 0, out2=out2)
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.time()
+        for _ in range(n):
+            ctx.denoise(xd, 1, out2=out2)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / n
+        gf = 37.1e9 * B
+        print(f'  B={B:3d}: {dt*1e3:8.2f} ms/step  -> {gf/dt/1e12:6.2f} TFLOP/s algorithmic, '
+              f'{B*196/(dt*1000):8.1f} frames/s @1000 steps, ws {ctx.workspace_bytes/2**30:.2f} GiB', flush=True)
+        ctx.close()
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--what', default='ops,small,full')
+    ap.add_argument('--bench-b', default='1,8,64')
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    print('device:', torch.cuda.get_device_name(0), flush=True)
+    what = a.what.split(',')
+    if 'ops' in what:
+        check_ops()
+    if 'small' in what:
+        check_small()
+    if 'full' in what:
+        check_full(tuple(int(v) for v in a.bench_b.split(',')))
