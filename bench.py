@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Headline benchmark: sampled SMPL-X frames/s of the STMoGen 0.125b denoiser, 196-frame sequences,
+1000-step DDPM with classifier-free guidance, synthetic inputs (BASELINE.json configs[1]:
+batch=64 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: denoiser (CFG-doubled) + CFG combine +
+p_sample update, including the per-step noise draw.  K steps are timed between barriers +
+device syncs; MAX over ranks.  `value` = whole-job frames/s of the COMPLETE 1000-step loop:
+
+    value = N * B * T / (t_setup + 1000 * t_step + t_gather)
+
+where t_setup = once-per-batch work that the loop needs (RCCL broadcast of the condition
+embeddings, FiLM/time tables for all 1000 steps, per-layer text K/V) and t_gather = RCCL
+all-gather of the finished sequences; both are measured here and reported in `config`.
+Inputs are resident in HBM when the timed region starts.
+
+Extra objects on the JSON line:
+  roofline      bound "mfma": algorithmic FLOPs of one step (SURVEY.md section 8d figure x samples)
+                / mean step duration from HIP events on the launch stream, vs the 157.3 TFLOP/s
+                fp32-matrix peak (v_mfma_f32_32x32x2_f32; MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (oracle/stmogen_oracle.py, kind "port") timed on this host's cores,
+                rank 0, N=1 only, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+TOTAL_DDPM_STEPS = 1000
+
+DIMS = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77, E=16, topk=2,
+            scale=6.5)
+
+
+def algorithmic_flops_per_sample_step(d, T):
+    """multiply-add = 2 flops; per CFG half per layer, then x2 x NL + enc/dec."""
+    L, H, F, Nt, E = d['L'], d['H'], d['F'], d['Nt'], d['E']
+    D = L * H
+    TH = T * H
+    layer = (TH * (2 * L * 256 + 2 * 256 * E) + TH * d['topk'] * 16 * L * L + TH * 8 * L * L + T * 2 * H * H * L
+             + TH * 6 * L * L + T * 8 * (2 * 12 * (L // 8) ** 2) * 2 + H * (2 * (Nt + T) * L * L + 2 * T * L * L)
+             + 2 * T * 2 * D * D + TH * 4 * L * F)
+    return 2 * d['NL'] * layer + T * 2 * 644 * L + 2 * T * 2 * 644 * L
+
+
+def synth_condition(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    xf = torch.nn.functional.layer_norm(torch.randn(B, DIMS['Nt'], DIMS['Dt'], generator=g), (DIMS['Dt'],))
+    return xf
+
+
+def cpu_baseline(B=4, T=196, steps=3):
+    """The oracle on the host cores: `steps` DDPM steps at batch B, same synthetic inputs/weights.
+    torch-CPU does not scale to every core of a many-core host (256-thread runs are >100x slower
+    than 16-32 threads), so the thread count is calibrated first on one B=1 denoiser call and the
+    fastest setting is used and reported as `cores`."""
+    from oracle import stmogen_oracle as O, weights as W
+    dims = W.default_dims()
+    sd = W.make_state_dict(dims, 0)
+    g = torch.Generator().manual_seed(0)
+    x_T = torch.randn(B, T, 322, generator=g)
+    xf = synth_condition(B, 1)
+    mask = torch.ones(B, T)
+    sched = O.Schedule(1000, None)
+    ncpu = os.cpu_count() or 1
+    best, best_t = 1, float('inf')
+    tf1 = None
+    for nt in sorted({min(ncpu, v) for v in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        if tf1 is None:
+            tf1 = O.precompute_text(sd, xf[:1], dims)
+        O.denoise(sd, dims, x_T[:1], 999, xf[:1], mask[:1], text_feats=tf1)       # warm
+        t0 = time.time()
+        O.denoise(sd, dims, x_T[:1], 999, xf[:1], mask[:1], text_feats=tf1)
+        dt = time.time() - t0
+        if dt < best_t:
+            best, best_t = nt, dt
+        if dt > 4 * best_t or dt > 20:
+            break
+    torch.set_num_threads(best)
+    t0 = time.time()
+    tf = O.precompute_text(sd, xf, dims)
+    t_text = time.time() - t0
+    x = x_T
+    t0 = time.time()
+    for n in range(steps):
+        i = 999 - n
+        x0 = O.denoise(sd, dims, x, sched.timestep_map[i], xf, mask, text_feats=tf)
+        x = O.ddpm_step(sched, i, x, x0, torch.randn(x.shape, generator=g))
+    t_step = (time.time() - t0) / steps
+    return dict(value=round(B * T / (t_text + TOTAL_DDPM_STEPS * t_step), 4), unit='frames/s',
+                cores=best, kind='port',
+                sample=f'oracle/stmogen_oracle.py (torch-CPU fp32, {best} threads = fastest of 8/16/32/64 on a '
+                       f'{ncpu}-CPU host), batch {B}, {steps} of 1000 DDPM steps timed ({t_step:.2f} s/step) + text '
+                       f'K/V hoist ({t_text:.2f} s), extrapolated to the full loop')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='samples per GPU (BASELINE configs[1]: 64)')
+    ap.add_argument('--frames', type=int, default=196)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from motioncraft_amd import dist as mcd
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from motioncraft_amd.synthetic import make_state_dict   # random-init weights (data only, no oracle import)
+
+    B, T, C = a.batch, a.frames, DIMS['input_feats']
+    GB = B * world
+    sd = make_state_dict(DIMS, 0)
+    nm = NativeModel(DIMS, sd, cfg_scale=DIMS['scale'], device=local_rank)
+    del sd
+    ctx = nm.context(B, T, max_steps=TOTAL_DDPM_STEPS)
+    diff = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                                model_var_type='fixed_large'))
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    # ---- once-per-batch setup: condition broadcast (RCCL), FiLM tables, text K/V ----
+    xf_global = torch.empty(GB, DIMS['Nt'], DIMS['Dt'], device=dev)
+    mask_global = torch.ones(GB, T, device=dev)
+    if rank == 0:
+        xf_global.copy_(synth_condition(GB, 1))
+    barrier()
+    t0 = time.perf_counter()
+    xf, mask = mcd.broadcast_condition(xf_global, mask_global, src=0)
+    ctx.set_timesteps(diff.timestep_map)
+    ctx.set_condition(xf, mask)
+    barrier()
+    t_setup = time.perf_counter() - t0
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(B, T, C, device=dev, generator=gen)
+    nxt = torch.empty_like(x)
+    coefs = {i: diff.step_coefs(i, 'ddpm', DIMS['scale']) for i in range(TOTAL_DDPM_STEPS)}
+
+    def one_step(i):
+        nonlocal x, nxt
+        eps = torch.randn(B, T, C, device=dev, generator=gen)
+        ctx.sample_step(x, i, coefs[i], eps, x_prev=nxt)
+        x, nxt = nxt, x
+
+    i = TOTAL_DDPM_STEPS - 1
+    for _ in range(a.warmup):
+        one_step(i)
+        i = i - 1 if i > 0 else TOTAL_DDPM_STEPS - 1
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        one_step(i)
+        ev[k][1].record()
+        i = i - 1 if i > 0 else TOTAL_DDPM_STEPS - 1
+    barrier()
+    t_loop = time.perf_counter() - t0
+    ev_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+
+    # ---- finish: all-gather of the finished sequences (RCCL) ----
+    barrier()
+    t0 = time.perf_counter()
+    out = mcd.gather_results(x)
+    barrier()
+    t_gather = time.perf_counter() - t0
+    assert out.shape[0] == GB and bool(torch.isfinite(out).all())
+
+    t = torch.tensor([t_loop, t_setup, t_gather, ev_ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_loop, t_setup, t_gather, ev_ms = (float(v) for v in t)
+    t_step = t_loop / a.steps
+    value = GB * T / (t_setup + TOTAL_DDPM_STEPS * t_step + t_gather)
+
+    if rank == 0:
+        flops_step = algorithmic_flops_per_sample_step(DIMS, T) * B
+        ach = flops_step / (ev_ms * 1e-3) / 1e12
+        line = {
+            'metric': 'sampled SMPL-X frames/sec (196-frame seq, 1000-step DDPM)',
+            'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(t_step * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: stmogen 0.125b text-to-motion (L=128, 12 parts, 4 layers, 16 experts '
+                                   'top-2), CFG scale 6.5, batch 64 per GPU, 196 frames, 1000-step DDPM',
+                       'batch_per_gpu': B, 'global_batch': GB, 'frames': T, 'parallelism': f'dp{world}',
+                       'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
+                       'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
+                       'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)'},
+            'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_k fp32 MFMA GEMMs)',
+                         'algorithmic_gflop_per_sample_step': round(algorithmic_flops_per_sample_step(DIMS, T) / 1e9, 3),
+                         'event_ms_per_step': round(ev_ms, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -82,6 +82,9 @@ int mc_model_finalize(mc_model* m);
 int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps, mc_ctx** out);
 void mc_ctx_destroy(mc_ctx* c);
 int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
+/* tests: keep the routing decisions (expert ids, combine weights; 0 = dropped) of every layer of the
+ * last mc_denoise call in buffers "cap_idx" / "cap_w" */
+int mc_ctx_enable_capture(mc_ctx* c);
 int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t num_steps, void* stream);
 int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_dev, void* stream);
 
@@ -97,7 +100,7 @@ int mc_sample_step(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc
 
 /* ---- introspection for tests --------------------------------------------------------- */
 /* named context buffers: "h","z","proj","mf","qkv","ys","yt","a","z2","out2","emb","ss","tf",
- * "idx","gate","comb_w","key" (layer selects tf / ss slices) */
+ * "idx","gate","comb_w","key","cap_idx","cap_w" (layer selects tf / ss / cap slices) */
 int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr, int64_t* numel);
 
 /* op-level entry points (kernel parity tests call these through the same ABI) */

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { GM_PLAIN = 0, GM_EXP1 = 1, GM_EXP2 = 2, GM_COMB = 3 };
+enum { GM_PLAIN = 0, GM_EXP1 = 1, GM_EXP2 = 2, GM_COMB = 3, GM_ENC = 4 };
 
 struct GemmArgs {
     // A operand: element (r,k) at A[grp*a_gstride + row(r)*lda + a_col + k]
@@ -10,7 +10,6 @@ struct GemmArgs {
     long lda = 0;
     int a_col = 0;
     long a_gstride = 0;
-    int a_scalar = 0;  // rows not 16-byte aligned (K = 322 pose vectors): scalar loads
     // W operand [N][ldw], ldw % 4 == 0, rows zero padded to ldw
     const float* W = nullptr;
     long ldw = 0;

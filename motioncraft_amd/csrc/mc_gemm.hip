@@ -11,19 +11,168 @@
 // k order applied identically to A and W (the dot product is order-independent up to rounding).
 // The +4 pad makes both the b128 reads and the b128 staging writes bank-conflict free.
 //
+// The W tile is fed as the MFMA "A" operand and the activation tile as "B", i.e. each wave
+// computes C^T fragments: lane l then owns output row m = l & 31 and, per accumulator quad,
+// FOUR CONSECUTIVE output columns -> the epilogue is 16 float4 stores per lane (bias / residual
+// loaded as float4 too) instead of 64 scalar ones.
+//
 // Modes (one kernel instantiation each):
-//   GM_PLAIN  dense / part-grouped (blockIdx.y = group) with optional activation, residual,
-//             row-periodic add table (positional embedding) and duplicate-row write (CFG halves)
+//   GM_PLAIN  dense / part-grouped (blockIdx.y = group) with optional activation and residual
 //   GM_EXP1   expert FC1 over device-built slot tiles: A row = src_row[slot], C row = slot
 //   GM_EXP2   expert FC2: A row = slot, C row = dst_row[slot]  (= 2*token + choice)
 //   GM_COMB   A[r][k] = gelu(w0[r]*Y[2r][k] + w1[r]*Y[2r+1][k]) (post-score combine of the two
 //             expert outputs of a token, dropped choices have w = 0), then dense GEMM
+//   GM_ENC    pose encoder: unaligned K=322 rows (scalar loads), + row-periodic add table
+//             (positional embedding) and duplicate-row write (the two CFG halves share h0)
 #include "mc_common.h"
 #include "mc_gemm.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 4;
+
+struct Stage {
+    long aoff[4], woff[4];
+    bool aok[4], wok[4];
+    float cw0[4], cw1[4];
+};
+
+template <int MODE, bool GUARD>
+__device__ __forceinline__ void load_tile(const GemmArgs& g, const float* __restrict__ Ab, const float* __restrict__ Wb,
+                                          const Stage& st, int k, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
+    const bool kin = !GUARD || k < g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((!GUARD || st.aok[i]) && kin) {
+            if constexpr (MODE == GM_COMB) {
+                f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+                if (st.cw0[i] != 0.f) y0 = *reinterpret_cast<const f32x4*>(Ab + st.aoff[i] + k);
+                if (st.cw1[i] != 0.f) y1 = *reinterpret_cast<const f32x4*>(Ab + st.aoff[i] + g.lda + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_exact(st.cw0[i] * y0[j] + st.cw1[i] * y1[j]);
+            } else if constexpr (MODE == GM_ENC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j < g.K) v[j] = Ab[st.aoff[i] + k + j];
+            } else {
+                v = *reinterpret_cast<const f32x4*>(Ab + st.aoff[i] + k);
+            }
+        }
+        ra[i] = v;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if ((!GUARD || st.wok[i]) && kin) w = *reinterpret_cast<const f32x4*>(Wb + st.woff[i] + k);
+        rb[i] = w;
+    }
+}
+
+template <int MODE, bool GUARD>
+__device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restrict__ Ab, const float* __restrict__ Wb,
+                                         const Stage& st, float* As, float* Bs, int sr, int sk, int wm, int wn, int lane,
+                                         f32x16 (&acc)[2][2]) {
+    f32x4 ra[4], rb[4];
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(As + buf * BM * LD + (sr + 32 * i) * LD + sk) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (sr + 32 * i) * LD + sk) = rb[i];
+        }
+    };
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile<MODE, GUARD>(g, Ab, Wb, st, sk, ra, rb);
+    store_tile(0);
+    __syncthreads();
+    const int frow = lane & 31;
+    const int fk = (lane >> 5) * 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 1) * BK + sk, ra, rb);
+        const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
+        const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ap + j * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ap + 32 * LD + j * 8);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bp + j * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bp + 32 * LD + j * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // D[n][m] += W[n][k] * A[m][k]   (W is the MFMA "A" operand)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[i], a0[i], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[i], a0[i], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[i], a1[i], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[i], a1[i], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// vector epilogue: lane owns row m = (lane & 31) of each 32-row block and 4 consecutive columns per quad
+template <int MODE, bool GUARD, int ACT>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs& g, int grp, int row0, int nrows, int tn, int wm, int wn,
+                                             int lane, f32x16 (&acc)[2][2]) {
+    const float* __restrict__ bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
+    float* __restrict__ Cb = g.C + (long)grp * g.c_gstride + g.c_col;
+    const float* __restrict__ Rb = g.R ? g.R + (long)grp * g.c_gstride + g.c_col : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = wm * 64 + mi * 32 + (lane & 31);
+        if (GUARD && m >= nrows) continue;
+        long drow = row0 + m;
+        if constexpr (MODE == GM_EXP2) drow = g.dst_row[row0 + m];
+        float* crow = Cb + drow * g.ldc;
+        const float* rrow = Rb ? Rb + drow * g.ldr : nullptr;
+        const float* arow = nullptr;
+        if constexpr (MODE == GM_ENC) arow = g.add + (long)((row0 + m) % g.add_mod) * g.ld_add;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tn * BN + wn * 64 + ni * 32 + 8 * q + 4 * (lane >> 5);
+                if (GUARD && n >= g.N) continue;
+                f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
+                if constexpr (MODE == GM_ENC) v += *reinterpret_cast<const f32x4*>(arow + n);
+                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+                *reinterpret_cast<f32x4*>(crow + n) = v;
+                if constexpr (MODE == GM_ENC) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
+            }
+        }
+    }
+}
+
+// scalar epilogue for outputs whose rows are not 16-byte aligned (pose decoder: N = 322)
+template <int MODE>
+__device__ __forceinline__ void epilogue_scalar(const GemmArgs& g, int grp, int row0, int nrows, int tn, int wm, int wn,
+                                                int lane, f32x16 (&acc)[2][2]) {
+    const float* __restrict__ bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
+    float* __restrict__ Cb = g.C + (long)grp * g.c_gstride + g.c_col;
+    const float* __restrict__ Rb = g.R ? g.R + (long)grp * g.c_gstride + g.c_col : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = wm * 64 + mi * 32 + (lane & 31);
+        if (m >= nrows) continue;
+        long drow = row0 + m;
+        if constexpr (MODE == GM_EXP2) drow = g.dst_row[row0 + m];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = tn * BN + wn * 64 + ni * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (n >= g.N) continue;
+                float v = acc[mi][ni][reg];
+                if (bias) v += bias[n];
+                v = apply_act(v, g.act);
+                if (Rb) v += Rb[drow * g.ldr + n];
+                Cb[drow * g.ldc + n] = v;
+            }
+        }
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
@@ -63,66 +212,24 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
     // staging assignment: thread -> rows (tid>>3) + 32*i, k-column (tid&7)*4
     const int sr = tid >> 3;
     const int sk = (tid & 7) * 4;
-    long arow_off[4];
-    bool arow_ok[4];
-    float cw0[4], cw1[4];
+    Stage st;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int r = sr + 32 * i;
-        arow_ok[i] = r < nrows;
+        const int r = sr + 32 * i;
+        st.aok[i] = r < nrows;
         long srow = row0 + r;
-        if constexpr (MODE == GM_EXP1) srow = arow_ok[i] ? g.src_row[row0 + r] : 0;
+        if constexpr (MODE == GM_EXP1) srow = st.aok[i] ? g.src_row[row0 + r] : 0;
         if constexpr (MODE == GM_COMB) {
-            arow_off[i] = 2 * srow * g.lda;
-            cw0[i] = arow_ok[i] ? g.comb_w[2 * srow] : 0.f;
-            cw1[i] = arow_ok[i] ? g.comb_w[2 * srow + 1] : 0.f;
+            st.aoff[i] = 2 * srow * g.lda;
+            st.cw0[i] = st.aok[i] ? g.comb_w[2 * srow] : 0.f;
+            st.cw1[i] = st.aok[i] ? g.comb_w[2 * srow + 1] : 0.f;
         } else {
-            arow_off[i] = srow * g.lda;
+            st.aoff[i] = srow * g.lda;
         }
+        const int n = tn * BN + r;
+        st.wok[i] = n < g.N;
+        st.woff[i] = (long)n * g.ldw;
     }
-    long wrow_off[4];
-    bool wrow_ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int n = tn * BN + sr + 32 * i;
-        wrow_ok[i] = n < g.N;
-        wrow_off[i] = (long)n * g.ldw;
-    }
-
-    f32x4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-        const int k = k0 + sk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (arow_ok[i] && k < g.K) {
-                if constexpr (MODE == GM_COMB) {
-                    f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-                    if (cw0[i] != 0.f) y0 = *reinterpret_cast<const f32x4*>(Ab + arow_off[i] + k);
-                    if (cw1[i] != 0.f) y1 = *reinterpret_cast<const f32x4*>(Ab + arow_off[i] + g.lda + k);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_exact(cw0[i] * y0[j] + cw1[i] * y1[j]);
-                } else if (MODE == GM_PLAIN && g.a_scalar) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k + j < g.K) v[j] = Ab[arow_off[i] + k + j];
-                } else {
-                    v = *reinterpret_cast<const f32x4*>(Ab + arow_off[i] + k);
-                }
-            }
-            ra[i] = v;
-            f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (wrow_ok[i] && k < g.K) w = *reinterpret_cast<const f32x4*>(Wb + wrow_off[i] + k);
-            rb[i] = w;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(As + buf * BM * LD + (sr + 32 * i) * LD + sk) = ra[i];
-            *reinterpret_cast<f32x4*>(Bs + buf * BN * LD + (sr + 32 * i) * LD + sk) = rb[i];
-        }
-    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -132,60 +239,22 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nk = (g.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    const int frow = lane & 31;
-    const int fk = (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
-        const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(Ap + j * 8);
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(Ap + 32 * LD + j * 8);
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(Bp + j * 8);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(Bp + 32 * LD + j * 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
+    const bool full = nrows == BM && (tn + 1) * BN <= g.N && (g.K % BK) == 0 && MODE != GM_ENC;
+    if (full) mainloop<MODE, false>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
+    else mainloop<MODE, true>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
 
-    // epilogue
-    const float* __restrict__ bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
-    float* __restrict__ Cb = g.C + (long)grp * g.c_gstride + g.c_col;
-    const float* __restrict__ Rb = g.R ? g.R + (long)grp * g.c_gstride + g.c_col : nullptr;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            if (r >= nrows) continue;
-            long drow = row0 + r;
-            if constexpr (MODE == GM_EXP2) drow = g.dst_row[row0 + r];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int n = tn * BN + wn * 64 + ni * 32 + (lane & 31);
-                if (n >= g.N) continue;
-                float v = acc[mi][ni][reg];
-                if (bias) v += bias[n];
-                v = apply_act(v, g.act);
-                if (g.add) v += g.add[(long)((row0 + r) % g.add_mod) * g.ld_add + n];
-                if (Rb) v += Rb[drow * g.ldr + n];
-                Cb[drow * g.ldc + n] = v;
-                if (g.dup_rows > 0) Cb[(drow + g.dup_rows) * g.ldc + n] = v;
-            }
-        }
+    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_col % 4 == 0) && (g.c_gstride % 4 == 0) &&
+                     (!g.R || g.ldr % 4 == 0);
+    if (!vec) {
+        epilogue_scalar<MODE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+    } else if (full) {
+        if (g.act == ACT_GELU) epilogue_vec<MODE, false, ACT_GELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else if (g.act == ACT_SILU) epilogue_vec<MODE, false, ACT_SILU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else epilogue_vec<MODE, false, ACT_NONE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+    } else {
+        if (g.act == ACT_GELU) epilogue_vec<MODE, true, ACT_GELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else if (g.act == ACT_SILU) epilogue_vec<MODE, true, ACT_SILU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else epilogue_vec<MODE, true, ACT_NONE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
     }
 }
 
@@ -195,12 +264,14 @@ int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipSt
     const int ntn = cdiv(g.N, BN);
     int ntm = (mode == GM_EXP1 || mode == GM_EXP2) ? max_tiles : cdiv(g.M, BM);
     if (ntm <= 0 || ntn <= 0) return MC_OK;
+    if (mode != GM_ENC) MC_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
     dim3 grid(ntm * ntn, groups > 0 ? groups : 1, 1);
     switch (mode) {
         case GM_PLAIN: hipLaunchKernelGGL(gemm_k<GM_PLAIN>, grid, dim3(256), 0, stream, g); break;
         case GM_EXP1: hipLaunchKernelGGL(gemm_k<GM_EXP1>, grid, dim3(256), 0, stream, g); break;
         case GM_EXP2: hipLaunchKernelGGL(gemm_k<GM_EXP2>, grid, dim3(256), 0, stream, g); break;
         case GM_COMB: hipLaunchKernelGGL(gemm_k<GM_COMB>, grid, dim3(256), 0, stream, g); break;
+        case GM_ENC: hipLaunchKernelGGL(gemm_k<GM_ENC>, grid, dim3(256), 0, stream, g); break;
         default: mc_set_error("bad gemm mode %d", mode); return MC_ERR_ARG;
     }
     MC_LAUNCH_CHECK();

@@ -55,6 +55,8 @@ struct mc_ctx {
     float *te, *e1, *emb, *semb, *ss;   // ss: [NL][2][maxS][2D]
     RouteBufs rb;
     bool have_cond = false;
+    int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
+    float* cap_w = nullptr;      // ... and combine weights (0 = dropped) of every layer
 };
 
 namespace {
@@ -335,6 +337,14 @@ void mc_ctx_destroy(mc_ctx* c) {
 
 int64_t mc_ctx_workspace_bytes(const mc_ctx* c) { return c ? c->bytes : 0; }
 
+int mc_ctx_enable_capture(mc_ctx* c) {
+    MC_REQUIRE(c, "null context");
+    if (c->cap_idx) return MC_OK;
+    int r;
+    if ((r = ws_alloc(c, &c->cap_idx, (size_t)c->m->cfg.num_layers * 2 * c->N)) != MC_OK) return r;
+    return ws_alloc(c, &c->cap_w, (size_t)c->m->cfg.num_layers * 2 * c->N);
+}
+
 // time_embed (diffusion_transformer.py:89-93,206-208) and every StylizationBlock.emb_layers
 // (stylization_block.py:17-20,34-35) depend only on the timestep, which is identical for the whole
 // batch -> evaluated once for all S steps of the schedule as M = S row GEMMs.
@@ -395,12 +405,12 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     // written to both CFG halves (stmogen.py:336-353; diffusion_transformer.py:215-218; stmogen.py:740)
     {
         GemmArgs e;
-        e.A = x_t; e.lda = C; e.a_scalar = 1;
+        e.A = x_t; e.lda = C;
         e.W = c->enc_w; e.ldw = c->m->Cp; e.bias = c->enc_b;
         e.add = c->seq_emb; e.add_mod = c->T; e.ld_add = D;
         e.C = c->h; e.ldc = D; e.dup_rows = BT;
         e.M = (int)BT; e.N = D; e.K = C;
-        if ((r = mc_launch_gemm(GM_PLAIN, e, 1, 0, s))) return r;
+        if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
     for (int i = 0; i < nl; ++i) {
@@ -408,6 +418,10 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
         // ---- STMA ----
         if ((r = mc_launch_ln_rows(c->h, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
         if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, s))) return r;
+        if (c->cap_idx) {
+            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
+            MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
+        }
         if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
         if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
         if ((r = mc_launch_body(c->mf, 4 * L, c->qkv, w.wsm, c->ys, c->rows, H, L, g.dyn_heads, s))) return r;
@@ -482,6 +496,8 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
     else if (n == "gate") { p = c->rb.gate; cnt = 2 * c->N; }
     else if (n == "comb_w") { p = c->rb.comb_w; cnt = 2 * c->N; }
     else if (n == "key") { p = c->rb.key; cnt = c->N; }
+    else if (n == "cap_idx" && c->cap_idx) { p = c->cap_idx + (long)layer * 2 * c->N; cnt = 2 * c->N; }
+    else if (n == "cap_w" && c->cap_w) { p = c->cap_w + (long)layer * 2 * c->N; cnt = 2 * c->N; }
     else { mc_set_error("unknown buffer '%s'", name); return MC_ERR_ARG; }
     *dev_ptr = p;
     *numel = cnt;

@@ -1,0 +1,70 @@
+"""Data-parallel sampling over the GPUs of one node: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+The path shards by samples: rank r owns the contiguous block
+[r*B/W, (r+1)*B/W) and a full weight replica.  There is NO per-step collective: one broadcast of
+the frozen condition embeddings before the loop (reference analogue: every rank reads its own
+batches, tools/test.py:107-113) and one all-gather of the finished [B/W, T, C] fp32 poses after
+it (reference: pickled-bytes all_gather in mogen/apis/test.py:141-150).
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
+
+
+def shard_range(total, rank=None, world_size=None):
+    """Contiguous block of `total` samples owned by `rank`; requires total % world_size == 0."""
+    if rank is None:
+        rank, world_size = world()
+    if total % world_size != 0:
+        raise ValueError(f'batch {total} is not divisible by world size {world_size}')
+    per = total // world_size
+    return rank * per, (rank + 1) * per
+
+
+def broadcast_condition(xf_out, motion_mask, src=0):
+    """Rank `src` holds the condition of the GLOBAL batch; every rank returns its own slice.
+    Tensors on other ranks only need the right shape/dtype/device (contents are overwritten)."""
+    if not is_dist():
+        return xf_out, motion_mask
+    dist.broadcast(xf_out, src=src)
+    dist.broadcast(motion_mask, src=src)
+    lo, hi = shard_range(xf_out.shape[0])
+    return xf_out[lo:hi].contiguous(), motion_mask[lo:hi].contiguous()
+
+
+def gather_results(local):
+    """all-gather of the finished sequences: [B/W, T, C] on every rank -> [B, T, C] on every rank."""
+    if not is_dist():
+        return local
+    rank, ws = world()
+    out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous()) if local.is_cuda else \
+        dist.all_gather(list(out.chunk(ws, dim=0)), local.contiguous())
+    return out
+
+
+def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, **kwargs):
+    """Shard a global batch over the ranks, sample each shard through `arch` (MotionDiffusion
+    mirror) and all-gather the poses.  `noise` / `step_noise` are GLOBAL tensors / callables
+    returning global tensors (parity definition of SURVEY.md section 8e: each rank must match the
+    oracle run on its shard alone)."""
+    lo, hi = shard_range(motion.shape[0])
+    sl = slice(lo, hi)
+    inf = dict(kwargs.pop('inference_kwargs', {}))
+    if noise is not None:
+        inf['noise'] = noise[sl]
+    if step_noise is not None:
+        inf['step_noise'] = (lambda i: step_noise(i)[sl]) if callable(step_noise) else [n[sl] for n in step_noise]
+    res = arch(motion=motion[sl], motion_mask=motion_mask[sl], motion_length=motion_mask[sl].sum(1, keepdim=True).long(),
+               xf_out=xf_out[sl], inference_kwargs=inf, **kwargs)
+    local = torch.stack([r['pred_motion'] for r in res])
+    dev = motion.device
+    return gather_results(local.to(dev))

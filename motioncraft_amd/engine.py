@@ -78,6 +78,16 @@ class NativeContext:
     def workspace_bytes(self):
         return int(self.lib.mc_ctx_workspace_bytes(self.handle))
 
+    def enable_capture(self):
+        """Keep every layer's routing decisions of the last denoise call (tests)."""
+        _lib.check(self.lib.mc_ctx_enable_capture(self.handle), 'mc_ctx_enable_capture')
+
+    def routing(self, layer):
+        """(expert ids [N,2] long, keep [N,2] bool) of `layer` from the last denoise call, on CPU."""
+        idx = self.buffer('cap_idx', layer, dtype=torch.int32).view(-1, 2).cpu().long()
+        keep = (self.buffer('cap_w', layer).view(-1, 2) != 0).cpu()
+        return idx, keep
+
     def set_timesteps(self, t_orig):
         t = np.ascontiguousarray(np.asarray(t_orig, dtype=np.int32))
         _lib.check(self.lib.mc_ctx_set_timesteps(self.handle, t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),

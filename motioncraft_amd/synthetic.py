@@ -1,0 +1,174 @@
+"""Synthetic, deterministic weights: every parameter is a function of (seed, state-dict key).
+
+Data generation only (no arithmetic of the path): used by bench.py / tools for the random-init
+weights of the named architecture, and re-exported by oracle/weights.py so the CPU oracle, the
+reference modules (tests/golden/make_golden.py) and the HIP path all see identical weights.
+``param_shapes`` is checked key-by-key against the reference's own ``state_dict()`` there.
+
+Released checkpoints are not available offline and most output layers of the
+reference are zero-initialised (``zero_module``: reference
+``mogen/models/utils/stylization_block.py:26``, ``mogen/models/transformers/stmogen.py:641``),
+so a freshly constructed model outputs exactly 0 and parity tests would be
+vacuous.  Instead both sides (reference modules, oracle, HIP path) regenerate the
+same non-trivial weights from the key names of SURVEY.md Appendix B; nothing is
+committed.
+"""
+import math
+import zlib
+from collections import OrderedDict
+
+import torch
+
+PART_NAMES = ['head', 'stem', 'larm', 'rarm', 'lleg', 'rleg', 'root', 'trans', 'face', 'lhand', 'rhand']
+
+
+def smplx_part_slices():
+    """Channel lists of the 11 body parts of the 322-d SMPL-X vector, in PoseEncoder
+    concat order (reference stmogen.py:53-68 ``get_smplx_slice``)."""
+    j = lambda *ids: [3 * i + c for i in ids for c in range(3)]
+    d = OrderedDict()
+    d['head'] = j(12, 15) + [156, 157, 158]
+    d['stem'] = j(3, 6, 9)
+    d['larm'] = j(14, 17, 19, 21)
+    d['rarm'] = j(13, 16, 18, 20)
+    d['lleg'] = j(2, 5, 8, 11)
+    d['rleg'] = j(1, 4, 7, 10)
+    d['root'] = [0, 1, 2] + list(range(312, 322))
+    d['trans'] = [309, 310, 311]
+    d['face'] = list(range(159, 309))
+    d['lhand'] = list(range(66, 111))
+    d['rhand'] = list(range(111, 156))
+    return d
+
+
+def default_dims(**over):
+    """0.125b config (reference configs/stmogen/T2M_motionx_align_Finedance_Beats2_face_no_loss_0_125b.py:26-83)."""
+    d = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77,
+             E=16, topk=2, scale=6.5, dyn_heads=8)
+    d.update(over)
+    return d
+
+
+def param_shapes(dims):
+    """name -> shape for the denoiser's state dict."""
+    L, H, NL, F, Te, Dt, Nt, E = (dims[k] for k in ('L', 'H', 'NL', 'F', 'Te', 'Dt', 'Nt', 'E'))
+    D, C, Tm = L * H, dims['input_feats'], dims['max_seq_len']
+    sl = smplx_part_slices()
+    s = OrderedDict()
+    s['sequence_embedding'] = (Tm, D)
+    for p in PART_NAMES:
+        s[f'joint_embed.{p}_embed.weight'] = (L, len(sl[p]))
+        s[f'joint_embed.{p}_embed.bias'] = (L,)
+    s['joint_embed.body_embed.weight'] = (L, C)
+    s['joint_embed.body_embed.bias'] = (L,)
+    s['time_embed.0.weight'] = (Te, D)
+    s['time_embed.0.bias'] = (Te,)
+    s['time_embed.2.weight'] = (Te, Te)
+    s['time_embed.2.bias'] = (Te,)
+
+    def stylization(pre):
+        s[pre + 'emb_layers.1.weight'] = (2 * D, Te)
+        s[pre + 'emb_layers.1.bias'] = (2 * D,)
+        s[pre + 'norm.weight'] = (D,)
+        s[pre + 'norm.bias'] = (D,)
+        s[pre + 'out_layers.2.weight'] = (D, D)
+        s[pre + 'out_layers.2.bias'] = (D,)
+
+    def moe(pre, seq, heads, din, dout):
+        s[pre + 'proj.weight'] = (dout, din)
+        s[pre + 'proj.bias'] = (dout,)
+        s[pre + 'model.gates.0.temperature'] = (1,)
+        s[pre + 'model.gates.0.cosine_projector.weight'] = (256, din)
+        s[pre + 'model.gates.0.cosine_projector.bias'] = (256,)
+        s[pre + 'model.gates.0.sim_matrix'] = (256, E)
+        s[pre + 'model.experts.batched_fc1_w'] = (E, 4 * din, din)
+        s[pre + 'model.experts.batched_fc2_w'] = (E, 4 * din, din)
+        s[pre + 'model.experts.batched_fc1_bias'] = (E, 4 * din)
+        s[pre + 'model.experts.batched_fc2_bias'] = (E, din)
+        s[pre + 'embedding'] = (1, seq, heads, din)
+
+    for i in range(NL):
+        ca = f'temporal_decoder_blocks.{i}.ca_block.'
+        s[ca + 'body_weight'] = (H, H)
+        s[ca + 'norm.weight'] = (L,)
+        s[ca + 'norm.bias'] = (L,)
+        s[ca + 'text_norm.weight'] = (Dt,)
+        s[ca + 'text_norm.bias'] = (Dt,)
+        moe(ca + 'text_moe.', Nt, 1, Dt, 2 * L)
+        moe(ca + 'motion_moe.', Tm, H, L, 4 * L)
+        s[ca + 'body_d_attn.norm.weight'] = (L,)
+        s[ca + 'body_d_attn.norm.bias'] = (L,)
+        for n in ('query', 'key', 'value'):
+            s[ca + f'body_d_attn.{n}.weight'] = (L, L)
+            s[ca + f'body_d_attn.{n}.bias'] = (L,)
+        stylization(ca + 'proj_out.')
+        ff = f'temporal_decoder_blocks.{i}.ffn.'
+        for p in range(H):
+            s[ff + f'linear1_list.{p}.weight'] = (F, L)
+            s[ff + f'linear1_list.{p}.bias'] = (F,)
+            s[ff + f'linear2_list.{p}.weight'] = (L, F)
+            s[ff + f'linear2_list.{p}.bias'] = (L,)
+        stylization(ff + 'proj_out.')
+    for p in PART_NAMES:
+        s[f'out.{p}_out.weight'] = (len(sl[p]), L)
+        s[f'out.{p}_out.bias'] = (len(sl[p]),)
+    s['out.body_out.weight'] = (C, L)
+    s['out.body_out.bias'] = (C,)
+    return s
+
+
+def _randn(seed, name, shape):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(zlib.crc32(f'{seed}:{name}'.encode()) & 0x7FFFFFFF)
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def make_param(seed, name, shape):
+    r = _randn(seed, name, shape)
+    if name.endswith('temperature'):
+        return math.log(2.0) + 0.1 * r                      # tutel init: log(1/init_t), init_t=0.5
+    if name.endswith('sim_matrix'):
+        return 0.01 * r                                      # tutel init: normal(0, 0.01)
+    if name.endswith('embedding') or name.endswith('body_weight'):
+        return r                                             # reference init: torch.randn
+    if name.endswith('batched_fc1_w'):
+        return r / math.sqrt(shape[2])
+    if name.endswith('batched_fc2_w'):
+        return r / math.sqrt(shape[1])
+    if name.endswith('_bias') or name.endswith('.bias'):
+        if '.norm.' in name or 'text_norm' in name:
+            return 0.1 * r
+        return 0.02 * r
+    if name.endswith('.weight'):
+        if '.norm.' in name or 'text_norm' in name:
+            return 1.0 + 0.1 * r
+        scale = 1.0 / math.sqrt(shape[1])
+        if 'out_layers.2' in name:                           # zero_module() in the reference
+            scale *= 0.5
+        return scale * r
+    raise KeyError(name)
+
+
+def make_state_dict(dims, seed=0, shapes=None):
+    shapes = param_shapes(dims) if shapes is None else shapes
+    return OrderedDict((k, make_param(seed, k, tuple(v))) for k, v in shapes.items())
+
+
+def reference_model_cfg(dims):
+    """The ``model=dict(type='STMoGenTransformer', ...)`` dict of the reference configs for these dims."""
+    L, H = dims['L'], dims['H']
+    return dict(
+        type='STMoGenTransformer', input_feats=dims['input_feats'], max_seq_len=dims['max_seq_len'],
+        latent_dim=L * H, time_embed_dim=dims['Te'], num_layers=dims['NL'],
+        ca_block_cfg=dict(type='STMA', latent_dim=L, text_latent_dim=dims['Dt'], num_heads=H,
+                          num_text_heads=1, num_experts=dims['E'], topk=dims['topk'],
+                          gate_type='cosine_top', gate_noise=1.0, ffn_dim=dims['F'],
+                          time_embed_dim=dims['Te'], max_seq_len=dims['max_seq_len'],
+                          max_text_seq_len=dims['Nt'], temporal_comb=False, dropout=0,
+                          dynamic_body=True),
+        ffn_cfg=dict(latent_dim=L, ffn_dim=dims['F'], dropout=0, time_embed_dim=dims['Te'], num_heads=H),
+        text_encoder=None,
+        pose_encoder_cfg=dict(dataset_name='motionx', latent_dim=L, input_dim=dims['input_feats']),
+        pose_decoder_cfg=dict(dataset_name='motionx', latent_dim=L, output_dim=dims['input_feats']),
+        scale_func_cfg=dict(scale=dims['scale']), moe_route_loss_weight=10.0,
+        template_kl_loss_weight=0.0001, use_pos_embedding=True)

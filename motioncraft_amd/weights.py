@@ -12,25 +12,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-PART_NAMES = ['head', 'stem', 'larm', 'rarm', 'lleg', 'rleg', 'root', 'trans', 'face', 'lhand', 'rhand']
-
-
-def smplx_part_slices():
-    """11 body-part channel lists of the 322-d motionx vector (reference stmogen.py:53-68)."""
-    j = lambda *ids: [3 * i + c for i in ids for c in range(3)]
-    d = OrderedDict()
-    d['head'] = j(12, 15) + [156, 157, 158]
-    d['stem'] = j(3, 6, 9)
-    d['larm'] = j(14, 17, 19, 21)
-    d['rarm'] = j(13, 16, 18, 20)
-    d['lleg'] = j(2, 5, 8, 11)
-    d['rleg'] = j(1, 4, 7, 10)
-    d['root'] = [0, 1, 2] + list(range(312, 322))
-    d['trans'] = [309, 310, 311]
-    d['face'] = list(range(159, 309))
-    d['lhand'] = list(range(66, 111))
-    d['rhand'] = list(range(111, 156))
-    return d
+from .synthetic import PART_NAMES, smplx_part_slices  # 322-d motionx part layout (reference stmogen.py:53-68)
 
 
 def strip_prefix(state_dict):

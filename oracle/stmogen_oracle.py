@@ -82,7 +82,7 @@ def pose_decoder(p, h, L, out_dim=322):
 # ------------------------------------------------------------------------------------
 # a16 + MOE wrapper
 # ------------------------------------------------------------------------------------
-def moe_wrapper(p, pre, z, return_routing=False):
+def moe_wrapper(p, pre, z, return_routing=False, forced=None):
     """mogen/models/attentions/st_attention.py:49-56 (class MOE.forward); tutel boundary a16."""
     B, S, G, Din = z.shape
     x = (z + p[pre + 'embedding'][:, :S]).reshape(-1, Din)
@@ -92,7 +92,7 @@ def moe_wrapper(p, pre, z, return_routing=False):
         p[m + 'gates.0.sim_matrix'], p[m + 'gates.0.temperature'],
         p[m + 'experts.batched_fc1_w'], p[m + 'experts.batched_fc1_bias'],
         p[m + 'experts.batched_fc2_w'], p[m + 'experts.batched_fc2_bias'],
-        top_k=2, capacity_factor=1.5, batch_prioritized_routing=True, return_routing=return_routing)
+        top_k=2, capacity_factor=1.5, batch_prioritized_routing=True, return_routing=return_routing, forced=forced)
     y, routing = r if return_routing else (r, None)
     y = F.linear(F.gelu(y), p[pre + 'proj.weight'], p[pre + 'proj.bias']).reshape(B, S, G, -1)
     return (y, routing) if return_routing else y
@@ -137,7 +137,7 @@ def text_kv(p, pre, xf, dims):
     return moe_wrapper(p, pre + 'text_moe.', tf)
 
 
-def stma(p, pre, x, xf, emb, src_mask, cond_type, dims, text_feat=None, cap=None):
+def stma(p, pre, x, xf, emb, src_mask, cond_type, dims, text_feat=None, cap=None, forced=None):
     """mogen/models/attentions/st_attention.py:105-179.
     x [B,T,D], xf [B,Nt,Dt], emb [B,Te], src_mask [B,T] or [B,T,1], cond_type [B,1,1]."""
     B, T, D = x.shape
@@ -146,7 +146,11 @@ def stma(p, pre, x, xf, emb, src_mask, cond_type, dims, text_feat=None, cap=None
     if text_feat is None:
         text_feat = text_kv(p, pre, xf, dims)
     mn = F.layer_norm(x4, (L,), p[pre + 'norm.weight'], p[pre + 'norm.bias'])
-    motion_feat = moe_wrapper(p, pre + 'motion_moe.', mn)
+    if cap is not None:
+        motion_feat, routing = moe_wrapper(p, pre + 'motion_moe.', mn, return_routing=True, forced=forced)
+        cap['routing'] = routing
+    else:
+        motion_feat = moe_wrapper(p, pre + 'motion_moe.', mn, forced=forced)
     if cap is not None:
         cap['motion_feat'] = motion_feat
         cap['text_feat'] = text_feat
@@ -203,7 +207,7 @@ def precompute_text(p, xf_out, dims):
     return [text_kv(p, f'temporal_decoder_blocks.{i}.ca_block.', xf2, dims) for i in range(dims['NL'])]
 
 
-def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None):
+def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None, forced_routing=None):
     """mogen/models/transformers/diffusion_transformer.py:186-238 + stmogen.py:725-761.
     x_t [B,T,C]; t_orig: int original (un-spaced) timestep, identical for the batch;
     returns the CFG-combined x0 prediction [B,T,C]."""
@@ -225,7 +229,8 @@ def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None
         lcap = {} if cap is not None else None
         pre = f'temporal_decoder_blocks.{i}.'
         h = stma(p, pre + 'ca_block.', h, xf2, emb2, mask2, cond, dims,
-                 text_feat=None if text_feats is None else text_feats[i], cap=lcap)
+                 text_feat=None if text_feats is None else text_feats[i], cap=lcap,
+                 forced=None if forced_routing is None else forced_routing[i])
         if lcap is not None:
             lcap['after_stma'] = h
         h = sffn(p, pre + 'ffn.', h, emb2, dims, cap=lcap)

@@ -93,13 +93,37 @@ def extract_critical(scores, top_k, capacity_factor, batch_prioritized_routing=T
 
 def moe_forward(x, proj_w, proj_b, sim_matrix, temperature, fc1_w, fc1_b, fc2_w, fc2_b,
                 top_k=2, capacity_factor=1.5, batch_prioritized_routing=True,
-                return_routing=False):
-    """Whole layer, x: [N, D] -> [N, D]."""
+                return_routing=False, forced=None):
+    """Whole layer, x: [N, D] -> [N, D].
+
+    ``forced = (indices [N, k] long, keep [N, k] bool)`` replaces the DISCRETE routing decisions
+    (top-k expert ids and the capacity drop set) by externally supplied ones while every
+    continuous quantity (scores, gates, expert FFNs) is still computed here.  Tests use it to
+    separate arithmetic parity from the inherently discontinuous capacity-boundary decision
+    (a 1-ulp change of a max score can swap which of two near-tied tokens is dropped)."""
     N, D = x.shape
     E = fc1_w.shape[0]
     scores = gate_scores(x, proj_w, proj_b, sim_matrix, temperature)
     indices_s, locations_s, gates_s, capacity = extract_critical(
         scores, top_k, capacity_factor, batch_prioritized_routing)
+    free = dict(indices=indices_s, keeps=[l < capacity for l in locations_s])
+    if forced is not None:
+        f_idx, f_keep = forced
+        indices_s = [f_idx[:, k].long().contiguous() for k in range(top_k)]
+        g = [scores.gather(1, i.unsqueeze(1)).squeeze(1) for i in indices_s]
+        denom = torch.clamp(sum(g), min=torch.finfo(scores.dtype).eps)
+        gates_s = [v / denom for v in g]
+        # give every kept pair its own slot (slot identity does not influence the result):
+        # first choices of expert e occupy 0..c0[e]-1, kept second choices follow
+        keep_s = [f_keep[:, k].bool() for k in range(top_k)]
+        base = torch.zeros(E, dtype=torch.long)
+        locations_s, big = [], 10 ** 9
+        for k in range(top_k):
+            oh = F.one_hot(indices_s[k], num_classes=E) * keep_s[k].unsqueeze(1).long()
+            pos = (torch.cumsum(oh, dim=0) - 1).gather(1, indices_s[k].unsqueeze(1)).squeeze(1)
+            locations_s.append(torch.where(keep_s[k], pos + base[indices_s[k]], torch.full_like(pos, big)))
+            base = base + oh.sum(0)
+        capacity = int(base.max()) + 1
     xg = x.to(scores.dtype)
     # fast_encode, is_postscore=True: slot buffer accumulates x (weight 1)
     disp = torch.zeros(E * capacity, D, dtype=xg.dtype)
@@ -122,7 +146,7 @@ def moe_forward(x, proj_w, proj_b, sim_matrix, temperature, fc1_w, fc1_b, fc2_w,
     y = y.to(x.dtype)
     if return_routing:
         return y, dict(scores=scores, indices=indices_s, locations=locations_s,
-                       gates=gates_s, capacity=capacity, keeps=keeps)
+                       gates=gates_s, capacity=capacity, keeps=keeps, free=free)
     return y
 
 

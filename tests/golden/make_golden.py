@@ -255,7 +255,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-full', action='store_true')
     a = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     schedules()
     small_modules()
     small_loops()

@@ -1,0 +1,284 @@
+"""GPU (MI355X): HIP path vs the CPU oracle and the committed golden vectors, through the C-ABI.
+
+Tolerances: the north star asks <= 1e-3 abs fp32 on the final pose tensor; single denoiser calls
+and short trajectories are held to 2e-4 (observed ~1e-5)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FULL, SMALL, SMALL_SEED, load, step_noise_from_seed, synth_inputs
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL_STEP = 2e-4
+TOL_FINAL = 1e-3
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxabs(a, b):
+    return float((a.detach().cpu().double().reshape(-1) - b.detach().cpu().double().reshape(-1)).abs().max())
+
+
+@pytest.fixture(scope='module')
+def small_model():
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    sd = W.make_state_dict(SMALL, SMALL_SEED)
+    nm = NativeModel(SMALL, sd, cfg_scale=SMALL['scale'])
+    yield sd, nm
+    nm.close()
+
+
+@pytest.fixture(scope='module')
+def full_model():
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    sd = W.make_state_dict(FULL, 0)
+    nm = NativeModel(FULL, sd, cfg_scale=FULL['scale'])
+    yield sd, nm
+    nm.close()
+
+
+def test_native_library_is_what_runs():
+    from motioncraft_amd import lib
+    l = lib.load(require_gpu=True)
+    maps = open('/proc/self/maps').read()
+    assert 'libmotioncraft_amd.so' in maps
+
+
+def test_gemm_family_vs_fp64():
+    from motioncraft_amd import lib as L_
+    from motioncraft_amd.engine import _ptr, _stream
+    lib = L_.load(require_gpu=True)
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K, act, res) in [(128, 128, 32, 0, False), (300, 200, 64, 1, True), (77, 322, 1536, 0, False),
+                                (1000, 64, 192, 2, False), (5, 3072, 2048, 0, False), (257, 129, 20, 0, True),
+                                (1, 1, 4, 0, False)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = a.double() @ w.double().t() + b.double()
+        ref = torch.nn.functional.gelu(ref) if act == 1 else torch.nn.functional.silu(ref) if act == 2 else ref
+        if res:
+            ref = ref + r.double()
+        ad, wd, bd, rd = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+        c = torch.empty(M, N, device='cuda')
+        L_.check(lib.mc_op_gemm(_ptr(ad), _ptr(wd), _ptr(bd), _ptr(rd if res else None), _ptr(c), M, N, K, K, act,
+                                _stream()))
+        torch.cuda.synchronize()
+        assert maxabs(c, ref) <= 2e-5, (M, N, K)
+    with pytest.raises(RuntimeError):
+        L_.check(lib.mc_op_gemm(_ptr(ad), _ptr(wd), None, None, _ptr(c), 4, 4, 3, 3, 0, _stream()))  # K % 4 != 0
+
+
+def test_ln_rows_and_sampler_update_ops():
+    from motioncraft_amd import lib as L_
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import _ptr, _stream
+    from oracle import stmogen_oracle as O
+    lib = L_.load(require_gpu=True)
+    g = torch.Generator().manual_seed(1)
+    for Lw in (32, 64, 128, 256):
+        x = torch.randn(1000, Lw, generator=g) * 2 + 0.5
+        ga, be, add = torch.randn(Lw, generator=g), torch.randn(Lw, generator=g), torch.randn(24, Lw, generator=g)
+        ref = torch.nn.functional.layer_norm(x, (Lw,), ga, be) + add.repeat(42, 1)[:1000]
+        xd, gd, bd, addd = x.cuda(), ga.cuda(), be.cuda(), add.cuda()
+        y = torch.empty(1000, Lw, device='cuda')
+        L_.check(lib.mc_op_ln_rows(_ptr(xd), Lw, _ptr(gd), _ptr(bd), _ptr(addd), 24, _ptr(y), 1000, Lw, _stream()))
+        torch.cuda.synchronize()
+        assert maxabs(y, ref) <= 1e-5
+    base = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large')
+    n = 2 * 24 * 322
+    xt, ot, on, nz = (torch.randn(n, generator=g) for _ in range(4))
+    for mode, respace in (('ddpm', None), ('ddim', '15,15,8,6,6')):
+        d = build_diffusion(dict(base, respace=respace))
+        s = O.Schedule(1000, respace)
+        for i in (d.num_timesteps - 1, 7, 0):
+            c = d.step_coefs(i, mode, 6.5)
+            x0_ref = ot * c.text_coef + on * c.none_coef
+            ref = (O.ddpm_step if mode == 'ddpm' else O.ddim_step)(s, i, xt, x0_ref, nz)
+            xtd, otd, ond, nzd = xt.cuda(), ot.cuda(), on.cuda(), nz.cuda()
+            xp, x0 = torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+            L_.check(lib.mc_op_sampler_update(_ptr(xtd), _ptr(otd), _ptr(ond), _ptr(nzd), _ptr(xp), _ptr(x0), n,
+                                              ctypes.byref(c), _stream()))
+            torch.cuda.synchronize()
+            assert maxabs(x0, x0_ref) <= 2e-5 and maxabs(xp, ref) <= 5e-5, (mode, i)
+
+
+def test_small_denoiser_stage_by_stage_vs_reference_golden(small_model):
+    from oracle import stmogen_oracle as O
+    sd, nm = small_model
+    g = load('small_modules.npz')
+    x_t, xf, mask = T_(g['x_t']), T_(g['xf_out']), T_(g['motion_mask'])
+    B, T = 2, 24
+    ctx = nm.context(B, T, max_steps=1)
+    ctx.set_timesteps([int(g['t'])])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    assert maxabs(ctx.buffer('emb')[:SMALL['Te']], T_(g['emb'])[0]) <= 1e-5
+    for i in range(SMALL['NL']):
+        assert maxabs(ctx.buffer('tf', i), T_(g[f'layer{i}.text_feat'])) <= 1e-5
+    xd = x_t.cuda()
+    for i in range(SMALL['NL']):
+        ctx.denoise(xd, 0, stop_after_layers=i + 1)
+        assert maxabs(ctx.buffer('mf'), T_(g[f'layer{i}.motion_feat'])) <= TOL_STEP
+        assert maxabs(ctx.buffer('h'), T_(g[f'layer{i}.after_ffn'])) <= TOL_STEP
+        dropped = int((ctx.buffer('comb_w') == 0).sum())
+        assert dropped == int(g[f'layer{i}.dropped'].sum())        # capacity overflow handled like the oracle
+    out2 = ctx.denoise(xd, 0)
+    assert maxabs(out2, T_(g['out2'])) <= TOL_STEP
+    w = (1 - (1000 - int(g['t'])) / 1000) * SMALL['scale'] + 1
+    assert maxabs(out2[:B] * w + out2[B:] * (1 - w), T_(g['x0'])) <= TOL_STEP
+    # determinism: slot order inside an expert is atomics-dependent, the values must not be
+    again = ctx.denoise(xd, 0)
+    assert torch.equal(out2, again)
+    ctx.close()
+
+
+def _arch_small(sd):
+    import motioncraft_amd as mc
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    arch = mc.build_architecture(cfg.model)
+    arch.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    return cfg, arch
+
+
+def test_small_ddim_50_steps_through_the_reference_api(small_model):
+    """configs -> build_architecture -> MotionDiffusion.forward(**kwargs) -> list of per-sample dicts."""
+    sd, _ = small_model
+    g = load('small_ddim.npz')
+    cfg, arch = _arch_small(sd)
+    B, T = 2, 24
+    noises = step_noise_from_seed(int(g['noise_seed']), (B, T, 322), 50)
+    mask = T_(g['motion_mask'])
+    res = arch(motion=torch.zeros(B, T, 322), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+               motion_metas=[{'text': 'a'}, {'text': 'b'}], xf_out=T_(g['xf_out']),
+               inference_kwargs=dict(noise=T_(g['x_T']), step_noise=lambda i: noises[49 - i]))
+    assert isinstance(res, list) and len(res) == B
+    assert set(res[0]) == {'motion', 'pred_motion', 'motion_length', 'motion_mask', 'pred_motion_length',
+                           'pred_motion_mask', 'text'}
+    assert res[1]['text'] == 'b' and not res[0]['pred_motion'].is_cuda
+    assert torch.equal(res[0]['pred_motion_mask'], mask[0]) and int(res[0]['pred_motion_length']) == int(mask[0].sum())
+    final = torch.stack([r['pred_motion'] for r in res])
+    assert maxabs(final, T_(g['final'])) <= TOL_FINAL
+    arch.model.release()
+
+
+def test_small_ddim_and_ddpm_trajectories(small_model):
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = small_model
+    base = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large')
+
+    class M:        # minimal `model` object of the sampler API
+        cfg_scale = SMALL['scale']
+
+        def sampling_context(self, B, T, tmap, kw, device=None):
+            ctx = nm.context(B, T, max_steps=len(tmap))
+            ctx.set_timesteps(tmap)
+            ctx.set_condition(kw['xf_out'].cuda(), kw['motion_mask'].cuda())
+            self.ctx = ctx
+            return ctx
+    for name, mode, respace, nsteps, every in (('small_ddim.npz', 'ddim', '15,15,8,6,6', 50, 10),
+                                               ('small_ddpm.npz', 'ddpm', None, 20, 5)):
+        g = load(name)
+        d = build_diffusion(dict(base, respace=respace))
+        S = d.num_timesteps
+        noises = step_noise_from_seed(int(g['noise_seed']), (2, 24, 322), nsteps)
+        traj = []
+        m = M()
+        loop = d.ddim_sample_loop if mode == 'ddim' else d.p_sample_loop
+        loop(m, (2, 24, 322), noise=T_(g['x_T']), clip_denoised=False,
+             model_kwargs=dict(xf_out=T_(g['xf_out']), motion_mask=T_(g['motion_mask']), y={}),
+             step_noise=lambda i: noises[S - 1 - i], num_steps=nsteps, trajectory=traj)
+        for n, ref in zip(range(every - 1, nsteps, every), g['traj']):
+            assert maxabs(traj[n][1], T_(ref)) <= TOL_FINAL, (name, n)
+        m.ctx.close()
+
+
+def test_full_size_denoise_vs_reference_golden(full_model):
+    sd, nm = full_model
+    g = load('full_denoise.npz')
+    x_T, xf, mask = synth_inputs(FULL, 1, 196, int(g['input_seed']))
+    ctx = nm.context(1, 196, max_steps=3)
+    ctx.set_timesteps([999, 57, 500])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    for s, t in ((0, 999), (1, 57)):
+        out2 = ctx.denoise(x_T.cuda(), s)
+        w = (1 - (1000 - t) / 1000) * FULL['scale'] + 1
+        assert maxabs(out2[:1] * w + out2[1:] * (1 - w), T_(g[f'x0_t{t}'])) <= TOL_STEP, t
+    _, _, mask2 = synth_inputs(FULL, 1, 196, int(g['input_seed']), lengths=[150])
+    ctx.set_condition(xf.cuda(), mask2.cuda())
+    out2 = ctx.denoise(x_T.cuda(), 2)
+    w = (1 - (1000 - 500) / 1000) * FULL['scale'] + 1
+    assert maxabs(out2[:1] * w + out2[1:] * (1 - w), T_(g['x0_t500_len150'])) <= TOL_STEP
+    ctx.close()
+
+
+def test_full_size_50_step_ddim_vs_reference_golden(full_model):
+    """North-star bar: <= 1e-3 abs on the final 322-d pose tensor, identical noise seeds."""
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = full_model
+    g = load('full_ddim.npz')
+    x_T, xf, mask = synth_inputs(FULL, 1, 196, int(g['input_seed']))
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    ctx = nm.context(1, 196, max_steps=50)
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    noises = step_noise_from_seed(int(g['noise_seed']), (1, 196, 322), 50)
+    x = x_T.cuda()
+    for n, i in enumerate(range(49, -1, -1)):
+        x = ctx.sample_step(x, i, d.step_coefs(i, 'ddim', FULL['scale']), noises[n].cuda())
+    torch.cuda.synchronize()
+    assert maxabs(x, T_(g['final'])) <= TOL_FINAL
+    ctx.close()
+
+
+def test_baseline_batch_64_single_step_vs_oracle(full_model):
+    """BASELINE.json configs[1] size (B=64, T=196, mixed lengths): one denoiser call vs the CPU oracle.
+
+    At N = 301 056 tokens neighbouring importance scores at an expert's capacity boundary are ~1e-6
+    apart -- the size of fp32 rounding differences between ANY two implementations of the gate
+    (including torch-CPU at two thread counts) -- so a handful of (token, choice) pairs can land on
+    the other side of the drop threshold, each changing its token by O(1) (tutel's batch-prioritised
+    dropping is discontinuous by construction).  Parity is therefore asserted in two parts:
+      (a) the DISCRETE decisions differ from the free-running oracle in at most a tiny fraction of
+          pairs, all of them capacity drops (never a different expert id for a confident token);
+      (b) with the oracle teacher-forced to the HIP path's decisions, every CONTINUOUS quantity
+          matches within the north-star tolerance of 1e-3."""
+    from oracle import stmogen_oracle as O
+    sd, nm = full_model
+    B, T = 64, 196
+    g = torch.Generator().manual_seed(5)
+    lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(FULL, B, T, seed=33, lengths=lengths)
+    ctx = nm.context(B, T, max_steps=1)
+    ctx.enable_capture()
+    ctx.set_timesteps([640])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    out2 = ctx.denoise(x_T.cuda(), 0)
+    again = ctx.denoise(x_T.cuda(), 0)
+    assert torch.equal(out2, again)                     # race-free / deterministic
+    forced = [ctx.routing(i) for i in range(FULL['NL'])]
+    torch.set_num_threads(min(32, os.cpu_count()))
+    cap = {}
+    ref = O.denoise(sd, FULL, x_T, 640, xf, mask, forced_routing=forced, cap=cap)
+    w = (1 - (1000 - 640) / 1000) * FULL['scale'] + 1
+    assert maxabs(out2[:B] * w + out2[B:] * (1 - w), ref) <= TOL_FINAL          # (b)
+    npairs = 2 * 2 * B * T * FULL['H']
+    for i in range(FULL['NL']):                                                 # (a)
+        free = cap[f'layer{i}']['routing']['free']
+        fidx, fkeep = torch.stack(free['indices'], 1), torch.stack(free['keeps'], 1)
+        idx_diff = int((fidx != forced[i][0]).sum())
+        keep_diff = int(((fkeep != forced[i][1]) & (fidx == forced[i][0])).sum())
+        dropped = int((~fkeep).sum())
+        print(f'layer {i}: dropped {dropped}, expert-id flips {idx_diff}, keep flips {keep_diff} of {npairs} pairs')
+        assert idx_diff <= 1e-4 * npairs and keep_diff <= max(8, 0.02 * dropped)
+    ctx.close()

@@ -1,0 +1,175 @@
+"""CPU: host logic of the drop-in boundary -- config loader, registry, schedule tables, weight
+packing, and that the C-ABI library loads and exports every declared symbol (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import motioncraft_amd as mc
+from motioncraft_amd import diffusion as D, lib, synthetic, weights
+from helpers import FULL, SMALL, load
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF_CFG = '/root/reference/configs/stmogen'
+
+
+def test_config_base_inheritance_and_access():
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    assert cfg.model.type == 'MotionDiffusion' and cfg.model['model']['type'] == 'STMoGenTransformer'
+    assert cfg.data.samples_per_gpu == 4 and cfg.data.workers_per_gpu == 0          # recursive merge
+    assert cfg.data.test.dataset_name == 'motionx' and cfg.dist_params.backend == 'nccl'
+    assert cfg.get('copy_blocks_num', 7) == 7 and cfg.latent_dim == 32
+    cfg.model['opt'] = {'same_overlap_noisy': False}
+    assert cfg.model.opt.same_overlap_noisy is False
+    cfg.merge_from_dict({'model.inference_type': 'ddpm', 'data.samples_per_gpu': 9})
+    assert cfg.model.inference_type == 'ddpm' and cfg.data.samples_per_gpu == 9
+    assert cfg.model.model.num_layers == 2
+    with pytest.raises(AttributeError):
+        cfg.no_such_key
+    with pytest.raises(FileNotFoundError):
+        mc.Config.fromfile(os.path.join(HERE, 'configs', 'missing.py'))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference tree only exists in the build container')
+def test_reference_configs_load_and_build_unchanged():
+    names = sorted(f for f in os.listdir(REF_CFG) if f.endswith('.py'))
+    assert len(names) == 11
+    for n in names:
+        cfg = mc.Config.fromfile(os.path.join(REF_CFG, n))
+        assert cfg.model.type == 'MotionDiffusion'
+        if n == 'T2M_humanml3d.py':
+            with pytest.raises(NotImplementedError):   # 263-d / 8-part variant is "next" 
+                mc.build_architecture(cfg.model)
+            continue
+        arch = mc.build_architecture(cfg.model)
+        assert arch.model.dims['H'] == 12 and arch.model.dims['L'] in (64, 128)
+        assert arch.diffusion_test.num_timesteps == 50 and arch.inference_type == 'ddim'
+
+
+def test_registry_semantics():
+    reg = mc.Registry('things')
+
+    @reg.register_module()
+    class A:
+        def __init__(self, x, y=2):
+            self.x, self.y = x, y
+    assert reg.get('A') is A and 'A' in reg
+    a = reg.build(dict(type='A', x=1))
+    assert (a.x, a.y) == (1, 2)
+    assert reg.build(None) is None
+    with pytest.raises(KeyError):
+        reg.build(dict(type='B'))
+    with pytest.raises(KeyError):
+        reg.build(dict(x=1))
+    with pytest.raises(TypeError):
+        reg.build([1, 2])
+    with pytest.raises(KeyError):
+        reg.register_module()(A)
+    assert mc.MODELS is mc.ARCHITECTURES is mc.SUBMODULES is mc.ATTENTIONS is mc.LOSSES
+    for n in ('MotionDiffusion', 'STMoGenTransformer', 'STMA', 'MSELoss'):
+        assert mc.MODELS.get(n) is not None
+
+
+def test_build_architecture_small_and_unsupported_options():
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    arch = mc.build_architecture(cfg.model)
+    assert arch.model.dims == dict(input_feats=322, max_seq_len=24, L=32, H=12, NL=2, F=64, Te=64, Dt=32, Nt=8,
+                                   E=16, topk=2)
+    assert arch.model.cfg_scale == 6.5
+    with pytest.raises(NotImplementedError):
+        arch.train()
+    with pytest.raises(NotImplementedError):        # text encoder is off-path: xf_out must be given
+        arch.model.get_precompute_condition(text=['a person walks'])
+    with pytest.raises(RuntimeError):               # no weights loaded -> loud failure, no fallback
+        arch.model.native
+    bad = cfg.model.model.ca_block_cfg
+    bad['gate_type'] = 'top'
+    with pytest.raises(NotImplementedError):
+        mc.build_attention(bad)
+
+
+def test_schedule_tables_against_reference_golden():
+    g = load('schedules.npz')
+    base = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large')
+    for tag, respace in (('ddim50', '15,15,8,6,6'), ('ddpm1000', None)):
+        d = D.build_diffusion(dict(base, respace=respace))
+        assert list(g[f'{tag}.timestep_map']) == list(d.timestep_map)
+        for name in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_recip_alphas_cumprod',
+                     'sqrt_recipm1_alphas_cumprod', 'posterior_mean_coef1', 'posterior_mean_coef2'):
+            assert np.array_equal(g[f'{tag}.{name}'], getattr(d, name)), (tag, name)
+        lv = g[f'{tag}.model_log_variance']
+        for i in (0, 1, d.num_timesteps - 1):
+            c = d.step_coefs(i, 'ddpm', 6.5)
+            assert abs(c.log_var - np.float32(lv[i])) <= 1e-6 * abs(lv[i])
+            assert c.c1 == np.float32(d.posterior_mean_coef1[i]) and c.nonzero == (0.0 if i == 0 else 1.0)
+            t = d.timestep_map[i]
+            assert c.text_coef == np.float32(1 + 6.5 * t / 1000) or abs(c.text_coef - (1 + 6.5 * t / 1000)) < 1e-6
+    assert D.space_timesteps(1000, 'ddim50') == set(range(0, 1000, 20))
+    with pytest.raises(ValueError):
+        D.space_timesteps(10, '20')
+
+
+def test_sampler_rejects_options_outside_the_path():
+    d = D.build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                               model_var_type='fixed_large'))
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop(None, (1, 24, 322), clip_denoised=True, model_kwargs={})
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(None, (1, 24, 322), clip_denoised=False,
+                           model_kwargs={'y': {'outpainting_mask': torch.ones(1, dtype=torch.bool)}})
+    with pytest.raises(NotImplementedError):
+        D.build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='epsilon',
+                               model_var_type='fixed_large')).p_sample_loop(None, (1, 2, 3), clip_denoised=False)
+
+
+def test_weight_packing_layouts():
+    sd = synthetic.make_state_dict(SMALL, 0)
+    p = weights.pack_state_dict({'model.' + k: v for k, v in sd.items()}, SMALL)   # checkpoint prefix stripped
+    L, H, C = SMALL['L'], SMALL['H'], 322
+    assert p['enc.w'].shape == (L * H, 324) and p['dec.w'].shape == (C, L * H)
+    sl = synthetic.smplx_part_slices()
+    x = torch.randn(3, C)
+    # dense encoder == per-part linears (reference stmogen.py:336-353)
+    dense = x @ torch.from_numpy(p['enc.w'][:, :C]).t() + torch.from_numpy(p['enc.b'])
+    for i, n in enumerate(synthetic.PART_NAMES):
+        ref = torch.nn.functional.linear(x[:, sl[n]], sd[f'joint_embed.{n}_embed.weight'], sd[f'joint_embed.{n}_embed.bias'])
+        assert torch.allclose(dense[:, i * L:(i + 1) * L], ref, atol=1e-5)
+    body = [c for n in synthetic.PART_NAMES for c in sl[n]]
+    ref = torch.nn.functional.linear(x[:, body], sd['joint_embed.body_embed.weight'], sd['joint_embed.body_embed.bias'])
+    assert torch.allclose(dense[:, (H - 1) * L:], ref, atol=1e-5)
+    assert np.all(p['enc.w'][:, C:] == 0)
+    # every 322 channel is owned by exactly one part
+    assert sorted(body) == list(range(C))
+    assert p['l0.mm.fc2_wt'].shape == (16, L, 4 * L) and p['l0.tm.fc1_w'].shape == (16, 4 * SMALL['Dt'], SMALL['Dt'])
+    assert np.allclose(np.linalg.norm(p['l1.mm.sim_n'], axis=0), 1.0, atol=1e-6)
+    assert np.allclose(p['l0.body_wsm'].sum(1), 1.0, atol=1e-6)
+    assert p['l0.ffn.w1'].shape == (H, SMALL['F'], L) and p['l0.dyn.qkv_w'].shape == (3 * L, L)
+    # full-size parameter budget of SURVEY.md: 127.9 M
+    n = sum(int(np.prod(s)) for s in synthetic.param_shapes(FULL).values())
+    assert abs(n / 1e6 - 127.9) < 0.1
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'motioncraft_amd.h')).read()
+    declared = set(re.findall(r'\b(mc_[a-z_0-9]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert declared == set(lib.EXPORTED_SYMBOLS), declared ^ set(lib.EXPORTED_SYMBOLS)
+    l = lib.load(require_gpu=False)           # dlopen only, no compute
+    for name in declared:
+        assert hasattr(l, name), name
+    assert ctypes.sizeof(lib.ModelConfig) == 14 * 4 and ctypes.sizeof(lib.StepCoefs) == 12 * 4
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):     # product path fails loudly without an MI355X
+            lib.load(require_gpu=True)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'motioncraft_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f

@@ -170,7 +170,7 @@ if __name__ == '__main__':
     ap.add_argument('--what', default='ops,small,full')
     ap.add_argument('--bench-b', default='1,8,64')
     a = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     print('device:', torch.cuda.get_device_name(0), flush=True)
     what = a.what.split(',')
     if 'ops' in what:
