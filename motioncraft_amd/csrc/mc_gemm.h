@@ -37,6 +37,7 @@ struct GemmArgs {
     const int* src_row = nullptr;
     const int* dst_row = nullptr;
     const float* comb_w = nullptr;  // [M][2]
+    int tune = 0;                   // bit0: 2-deep prefetch + mid-loop staging writes (set by the launcher; MC_GEMM_TUNE=0 disables)
 };
 
 int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream);

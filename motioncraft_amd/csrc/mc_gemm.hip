@@ -26,6 +26,7 @@
 //             (positional embedding) and duplicate-row write (the two CFG halves share h0)
 #include "mc_common.h"
 #include "mc_gemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, const float* __rest
     }
 }
 
-template <int MODE, bool GUARD>
+template <int MODE, bool GUARD, bool EARLY>
 __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restrict__ Ab, const float* __restrict__ Wb,
                                          const Stage& st, float* As, float* Bs, int sr, int sk, int wm, int wn, int lane,
                                          f32x16 (&acc)[2][2]) {
@@ -79,33 +80,76 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
         }
     };
     const int nk = (g.K + BK - 1) / BK;
-    load_tile<MODE, GUARD>(g, Ab, Wb, st, sk, ra, rb);
-    store_tile(0);
-    __syncthreads();
     const int frow = lane & 31;
     const int fk = (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 1) * BK + sk, ra, rb);
-        const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
-        const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
+    // fragments of k-group j+1 are read while the 16 MFMAs of group j execute (explicit software pipeline)
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto ld_frag = [&](const float* Ap, const float* Bp, int j) {
+        Frag f;
+        f.a0 = *reinterpret_cast<const f32x4*>(Ap + j * 8);
+        f.a1 = *reinterpret_cast<const f32x4*>(Ap + 32 * LD + j * 8);
+        f.b0 = *reinterpret_cast<const f32x4*>(Bp + j * 8);
+        f.b1 = *reinterpret_cast<const f32x4*>(Bp + 32 * LD + j * 8);
+        return f;
+    };
+    auto mma = [&](const Frag& f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ap + j * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ap + 32 * LD + j * 8);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bp + j * 8);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bp + 32 * LD + j * 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // D[n][m] += W[n][k] * A[m][k]   (W is the MFMA "A" operand)
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[i], a0[i], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[i], a0[i], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[i], a1[i], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[i], a1[i], acc[1][1], 0, 0, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            // D[n][m] += W[n][k] * A[m][k]   (W is the MFMA "A" operand)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a0[i], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a0[i], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a1[i], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a1[i], acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+    if constexpr (!EARLY) {
+        load_tile<MODE, GUARD>(g, Ab, Wb, st, sk, ra, rb);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 1) * BK + sk, ra, rb);
+            const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
+            const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
+            Frag f0 = ld_frag(Ap, Bp, 0);
+            Frag f1 = ld_frag(Ap, Bp, 1);
+            mma(f0);
+            f0 = ld_frag(Ap, Bp, 2);
+            mma(f1);
+            f1 = ld_frag(Ap, Bp, 3);
+            mma(f0);
+            mma(f1);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // 2-deep register prefetch: tile kt+2 is requested at the top of iteration kt, tile kt+1
+        // (requested one iteration earlier, long landed) is written to the other LDS buffer in the
+        // MIDDLE of iteration kt's MFMAs, so neither the global latency nor the staging writes sit
+        // between the last MFMA and the barrier.
+        f32x4 na[4], nb[4];
+        load_tile<MODE, GUARD>(g, Ab, Wb, st, sk, ra, rb);
+        store_tile(0);
+        if (nk > 1) load_tile<MODE, GUARD>(g, Ab, Wb, st, BK + sk, ra, rb);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 2 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 2) * BK + sk, na, nb);
+            const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
+            const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
+            Frag f0 = ld_frag(Ap, Bp, 0);
+            Frag f1 = ld_frag(Ap, Bp, 1);
+            mma(f0);
+            f0 = ld_frag(Ap, Bp, 2);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            mma(f1);
+            f1 = ld_frag(Ap, Bp, 3);
+            mma(f0);
+            mma(f1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[i] = na[i]; rb[i] = nb[i]; }
+            __syncthreads();
+        }
     }
 }
 
@@ -240,8 +284,12 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const bool full = nrows == BM && (tn + 1) * BN <= g.N && (g.K % BK) == 0 && MODE != GM_ENC;
-    if (full) mainloop<MODE, false>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
-    else mainloop<MODE, true>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
+    if (full) {
+        if (g.tune & 1) mainloop<MODE, false, true>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
+        else mainloop<MODE, false, false>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
+    } else {
+        mainloop<MODE, true, false>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
+    }
 
     const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_col % 4 == 0) && (g.c_gstride % 4 == 0) &&
                      (!g.R || g.ldr % 4 == 0);
@@ -260,7 +308,18 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
 
 }  // namespace
 
-int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream) {
+static int tune_bits() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MC_GEMM_TUNE");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipStream_t stream) {
+    GemmArgs g = g0;
+    g.tune = tune_bits();
     const int ntn = cdiv(g.N, BN);
     int ntm = (mode == GM_EXP1 || mode == GM_EXP2) ? max_tiles : cdiv(g.M, BM);
     if (ntm <= 0 || ntn <= 0) return MC_OK;

@@ -17,6 +17,7 @@
 #include "mc_common.h"
 #include "mc_gemm.h"
 #include "mc_kernels.h"
+#include "mc_mlp.h"
 
 struct mc_model {
     mc_model_config cfg;
@@ -181,20 +182,30 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
     if ((r = mc_launch_route(Ntok, E, capacity, c->rb, s))) return r;
     const int max_tiles = cdiv(2 * Ntok, 128) + E;
-    GemmArgs a;
-    a.A = z; a.lda = din; a.src_row = c->rb.src_row;
-    a.W = w.fc1_w; a.ldw = din; a.w_gstride = (long)hid * din;
-    a.bias = w.fc1_b; a.b_gstride = hid; a.act = ACT_GELU;
-    a.C = c->hbuf; a.ldc = hid; a.N = hid; a.K = din;
-    a.tile_group = c->rb.tile_group; a.tile_row0 = c->rb.tile_row0; a.tile_nrows = c->rb.tile_nrows;
-    a.num_tiles = mc_route_num_tiles_ptr(c->rb);
-    if ((r = mc_launch_gemm(GM_EXP1, a, 1, max_tiles, s))) return r;
-    GemmArgs b;
-    b.A = c->hbuf; b.lda = hid; b.W = w.fc2_wt; b.ldw = hid; b.w_gstride = (long)din * hid;
-    b.bias = w.fc2_b; b.b_gstride = din; b.dst_row = c->rb.dst_row;
-    b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
-    b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
-    if ((r = mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s))) return r;
+    if (mc_mlp_supported(din, hid)) {
+        // fused expert FFN: hidden activations stay on chip (mc_mlp.hip)
+        MlpArgs m;
+        m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
+        m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
+        m.tile_group = c->rb.tile_group; m.tile_row0 = c->rb.tile_row0; m.tile_nrows = c->rb.tile_nrows;
+        m.num_tiles = mc_route_num_tiles_ptr(c->rb); m.src_row = c->rb.src_row; m.dst_row = c->rb.dst_row;
+        if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
+    } else {
+        GemmArgs a;
+        a.A = z; a.lda = din; a.src_row = c->rb.src_row;
+        a.W = w.fc1_w; a.ldw = din; a.w_gstride = (long)hid * din;
+        a.bias = w.fc1_b; a.b_gstride = hid; a.act = ACT_GELU;
+        a.C = c->hbuf; a.ldc = hid; a.N = hid; a.K = din;
+        a.tile_group = c->rb.tile_group; a.tile_row0 = c->rb.tile_row0; a.tile_nrows = c->rb.tile_nrows;
+        a.num_tiles = mc_route_num_tiles_ptr(c->rb);
+        if ((r = mc_launch_gemm(GM_EXP1, a, 1, max_tiles, s))) return r;
+        GemmArgs b;
+        b.A = c->hbuf; b.lda = hid; b.W = w.fc2_wt; b.ldw = hid; b.w_gstride = (long)din * hid;
+        b.bias = w.fc2_b; b.b_gstride = din; b.dst_row = c->rb.dst_row;
+        b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
+        b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
+        if ((r = mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s))) return r;
+    }
     GemmArgs p;
     p.A = c->y2; p.lda = din; p.comb_w = c->rb.comb_w;
     p.W = w.proj_w; p.ldw = din; p.bias = w.proj_b;
@@ -430,7 +441,13 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
         const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
         if ((r = film_block(c, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, s))) return r;
         // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
-        {
+        if (mc_mlp_supported(L, F)) {
+            MlpArgs m;
+            m.X = c->h; m.ldx = D; m.x_gstride = L;
+            m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
+            m.Y = c->z2; m.ldy = D; m.y_gstride = L; m.M = (int)c->rows; m.L = L; m.hidden = F;
+            if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
+        } else {
             GemmArgs f1;
             f1.A = c->h; f1.lda = D; f1.a_gstride = L;
             f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
