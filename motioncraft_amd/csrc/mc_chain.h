@@ -1,0 +1,65 @@
+// Register-chained row-panel kernels (mc_chain.hip): fused MLP, gate, combine+proj+LN+qkv.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { MLP_EXPERT = 0, MLP_PARTS = 1 };
+
+struct MlpArgs {
+    const float* X = nullptr;   // row r of group g at X[g*x_gstride + row(r)*ldx + 0..L)
+    long ldx = 0, x_gstride = 0;
+    const float* W1 = nullptr;  // [groups][hidden][L]
+    const float* b1 = nullptr;  // [groups][hidden]
+    const float* W2t = nullptr; // [groups][L][hidden]   (output-major, hidden contiguous)
+    const float* b2 = nullptr;  // [groups][L]
+    float* Y = nullptr;         // row r at Y[g*y_gstride + drow(r)*ldy + 0..L)
+    long ldy = 0, y_gstride = 0;
+    int M = 0, L = 0, hidden = 0;
+    // MLP_EXPERT: device tile map + gather/scatter lists (mc_route.hip)
+    const int* tile_group = nullptr;
+    const int* tile_row0 = nullptr;
+    const int* tile_nrows = nullptr;
+    const int* num_tiles = nullptr;
+    const int* src_row = nullptr;
+    const int* dst_row = nullptr;
+};
+
+struct GateArgs {
+    const float* X = nullptr;      // token rows [N][ldx] (the residual stream viewed per part)
+    long ldx = 0;
+    const float* gamma = nullptr;  // STMA.norm
+    const float* beta = nullptr;
+    const float* emb = nullptr;    // MOE.embedding rows [(t,h)][L]
+    int emb_mod = 1;
+    float* Z = nullptr;            // [N][L]  LN(x)+embedding (expert input)
+    const float* Wp = nullptr;     // cosine projector [256][L]
+    const float* bp = nullptr;
+    const float* sim_n = nullptr;  // [256][E] unit columns
+    const float* logit_scale = nullptr;
+    long N = 0;
+    int E = 0, L = 0;
+    int* idx = nullptr;            // [N][2]
+    float* gate = nullptr;         // [N][2]
+    uint32_t* key = nullptr;       // [N]
+    int* cnt = nullptr;            // [2][16] per (choice, expert) counts (zeroed by the launcher)
+};
+
+struct RowChainArgs {
+    const float* X = nullptr;      // kind 0: Y2 [N][2][L] expert outputs per choice; kind 1: rows [N][ldx]
+    long ldx = 0;
+    const float* comb_w = nullptr; // kind 0: [N][2] gate if kept else 0
+    const float* gamma = nullptr;  // kind 1: LayerNorm affine
+    const float* beta = nullptr;
+    const float* W = nullptr;      // [Nout][L]
+    const float* bias = nullptr;
+    float* Y = nullptr;            // [N][ldy]
+    long ldy = 0;
+    long N = 0;
+    int L = 0, Nout = 0;
+};
+
+bool mc_chain_enabled(int which);   // 0: fused mlp, 1: gate, 2: rowchain (proj, qkv)   (env MC_CHAIN bitmask, default all)
+bool mc_mlp_supported(int L, int hidden);
+int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStream_t s);
+int mc_launch_gate(const GateArgs& g, hipStream_t s);
+int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s);   // 0: combine+GELU+proj, 1: LN+linear

@@ -1,0 +1,475 @@
+// Register-chained row-panel kernels (gfx950, fp32 MFMA 32x32x2).
+//
+// Key property used here: with the weights as the MFMA "A" operand a wave computes C^T fragments,
+// lane l owning output row (l & 31) and, per accumulator quad q, the 4 consecutive columns
+// 8q + 4(l >> 5) + {0..3} of a 32-column chunk.  That is EXACTLY the B-operand fragment layout of
+// the next GEMM over the same rows (k-group j = 4*chunk + q, k = 8j + 4(l >> 5) + i): chained
+// per-row GEMMs (and the elementwise / per-row-LayerNorm work between them) need no data movement
+// at all -- accumulators become operands.  Each wave owns 32 rows, a 128-row workgroup shares only
+// the weight chunks, which stream through a double-buffered LDS slab with register prefetch
+// (one barrier per 32-column chunk = per 64 MFMAs).
+//
+//   mlp2_k        Y = GELU(X W1^T + b1) W2 + b2       experts (gathered rows) and SFFN parts
+//   gate_k        z = LN(x) + emb;  p = z Wp^T + bp;  cosine logits, softmax, top-2, counts
+//   rowchain_k<0> a = GELU(w0 y0 + w1 y1);  mf = a Wproj^T + b
+//   rowchain_k<1> qkv = LN(mf[:, :L]) Wqkv^T + b
+#include "mc_common.h"
+#include "mc_chain.h"
+#include <stdlib.h>
+
+namespace {
+
+// ---- weight chunk streaming -------------------------------------------------------------------
+// A "chunk" is ROWS x KW floats of a row-major matrix with leading dimension ld, staged in LDS
+// with row stride KW + 4 (conflict-free b128 fragment reads).
+template <int ROWS, int KW>
+struct ChunkStage {
+    static constexpr int LDS_LD = KW + 4;
+    static constexpr int F4 = ROWS * KW / 4;            // float4 per chunk
+    static constexpr int PT = (F4 + 255) / 256;         // float4 per thread
+    f32x4 r[PT];
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, long ld, int row0, int col0, int tid) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int idx = tid + 256 * i;
+            if (F4 % 256 == 0 || idx < F4) {
+                const int rr = idx / (KW / 4), cc = (idx % (KW / 4)) * 4;
+                r[i] = *reinterpret_cast<const f32x4*>(W + (long)(row0 + rr) * ld + col0 + cc);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(float* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int idx = tid + 256 * i;
+            if (F4 % 256 == 0 || idx < F4) {
+                const int rr = idx / (KW / 4), cc = (idx % (KW / 4)) * 4;
+                *reinterpret_cast<f32x4*>(lds + rr * LDS_LD + cc) = r[i];
+            }
+        }
+    }
+};
+
+// acc[32 out][32 rows] = Wc[32 out][8*NJ] * X[32 rows][8*NJ].  One accumulator chain: for
+// v_mfma_f32_32x32x2_f32 the dependent-accumulator latency equals the 64-cycle issue interval.
+template <int NJ>
+__device__ __forceinline__ f32x16 chunk_mma(const float* Wc, const f32x4 (&xf)[NJ], int lane) {
+    constexpr int LDW = 8 * NJ + 4;
+    f32x16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* wp = Wc + (lane & 31) * LDW + (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + 8 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], xf[j][i], a, 0, 0, 0);
+    }
+    // schedule: weight fragments are read two k-groups ahead of their MFMAs instead of all NJ at
+    // once (the default hoists every ds_read_b128 to the top: +4*NJ live VGPRs)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int j = 0; j < NJ - 2; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    return a;
+}
+
+// per-row LayerNorm of a fragment-distributed row: lane l and lane l^32 hold the two halves
+template <int NJ>
+__device__ __forceinline__ void frag_layernorm(f32x4 (&x)[NJ], const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, int kq) {
+    constexpr int L = 8 * NJ;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += x[j][0] + x[j][1] + x[j][2] + x[j][3];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)L;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[j][i] -= mean;
+            q += x[j][i] * x[j][i];
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q / (float)L + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 8 * j + kq);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 8 * j + kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[j][i] = x[j][i] * rstd * g[i] + b[i];
+    }
+}
+
+// =================================================================================================
+// Fused 2-layer MLP (reference: tutel FusedExpertsNetwork; SFFN stmogen.py:596-607)
+// =================================================================================================
+template <int L, int MODE>
+__global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
+    constexpr int NJ = L / 8, NT = L / 32, HC = 32;
+    using S1 = ChunkStage<HC, L>;      // W1 chunk  [32 hidden][L]
+    using S2 = ChunkStage<L, HC>;      // W2^T chunk [L out][32 hidden]
+    __shared__ __attribute__((aligned(16))) float smem[2 * (HC * S1::LDS_LD + L * S2::LDS_LD)];
+    constexpr int BUFSZ = HC * S1::LDS_LD + L * S2::LDS_LD;
+    auto W1s = [&](int b) { return smem + b * BUFSZ; };
+    auto W2s = [&](int b) { return smem + b * BUFSZ + HC * S1::LDS_LD; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int grp, row0, nrows;
+    if constexpr (MODE == MLP_EXPERT) {
+        const int real = *g.num_tiles;
+        if ((int)blockIdx.x >= real) return;
+        const int t = xcd_remap(blockIdx.x, real);
+        grp = g.tile_group[t];
+        row0 = g.tile_row0[t];
+        nrows = g.tile_nrows[t];
+    } else {
+        grp = blockIdx.y;
+        row0 = blockIdx.x * 128;
+        nrows = min(128, g.M - row0);
+    }
+    const float* __restrict__ W1 = g.W1 + (long)grp * g.hidden * L;
+    const float* __restrict__ W2t = g.W2t + (long)grp * L * g.hidden;
+    const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
+    const float* __restrict__ b2 = g.b2 + (long)grp * L;
+
+    const int r = wave * 32 + (lane & 31);
+    const bool rok = r < nrows;
+    const int kq = (lane >> 5) * 4;
+    f32x4 xf[NJ];
+    {
+        long srow = row0 + r;
+        if constexpr (MODE == MLP_EXPERT) srow = rok ? g.src_row[row0 + r] : 0;
+        const float* xp = g.X + (long)grp * g.x_gstride + srow * g.ldx + kq;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rok) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+        }
+    }
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[t][q] = 0.f;
+
+    const int nch = g.hidden / HC;
+    S1 s1;
+    S2 s2;
+    s1.fetch(W1, L, 0, 0, tid);
+    s2.fetch(W2t, g.hidden, 0, 0, tid);
+    s1.commit(W1s(0), tid);
+    s2.commit(W2s(0), tid);
+    if (nch > 1) {
+        s1.fetch(W1, L, HC, 0, tid);
+        s2.fetch(W2t, g.hidden, 0, HC, tid);
+    }
+    __syncthreads();
+    for (int hc = 0; hc < nch; ++hc) {
+        const int buf = hc & 1;
+        if (hc + 1 < nch) {
+            s1.commit(W1s(buf ^ 1), tid);
+            s2.commit(W2s(buf ^ 1), tid);
+        }
+        if (hc + 2 < nch) {
+            s1.fetch(W1, L, (hc + 2) * HC, 0, tid);
+            s2.fetch(W2t, g.hidden, 0, (hc + 2) * HC, tid);
+        }
+        // FC1 chunk: 32 hidden units of this wave's 32 rows
+        const f32x16 a1 = chunk_mma<NJ>(W1s(buf), xf, lane);
+        // bias + exact GELU; the C^T fragment IS the B-operand fragment of FC2 (k-group q)
+        f32x4 hf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + hc * HC + 8 * q + kq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hf[q][i] = gelu_exact(a1[4 * q + i] + bb[i]);
+        }
+        // FC2 partial: out[L] += W2t[:, chunk] h
+        const float* w2p = W2s(buf) + (lane & 31) * S2::LDS_LD + kq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(w2p + t * 32 * S2::LDS_LD + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[i], hf[q][i], acc2[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!rok) return;
+    long drow = row0 + r;
+    if constexpr (MODE == MLP_EXPERT) drow = g.dst_row[row0 + r];
+    float* yrow = g.Y + (long)grp * g.y_gstride + drow * g.ldy;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = t * 32 + 8 * q + kq;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + n);
+            f32x4 v = {acc2[t][4 * q] + bb[0], acc2[t][4 * q + 1] + bb[1], acc2[t][4 * q + 2] + bb[2], acc2[t][4 * q + 3] + bb[3]};
+            *reinterpret_cast<f32x4*>(yrow + n) = v;
+        }
+}
+
+// =================================================================================================
+// Gate: LayerNorm + embedding + cosine projector + logits + softmax + top-2
+// (st_attention.py:116-120 LN; MOE.forward :49-51; tutel cosine_top gate + moe_layer routing())
+// =================================================================================================
+template <int L>
+__global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
+    constexpr int NJ = L / 8, PC = 256 / 32, MAXE = 16, LDS_SIM = 256 + 4;
+    using SP = ChunkStage<32, L>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 32 * LDS_SIM];
+    __shared__ int s_cnt[2 * MAXE];
+    auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
+    float* s_simT = smem + 2 * 32 * SP::LDS_LD;    // [32 expert rows (>= E zero)][256 + 4]: sim_n^T as an MFMA "A" operand
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 32 * 256; i += 256) {
+        const int e = i >> 8, j = i & 255;
+        s_simT[e * LDS_SIM + j] = e < g.E ? g.sim_n[j * g.E + e] : 0.f;
+    }
+    if (tid < 2 * MAXE) s_cnt[tid] = 0;
+    const long tok = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool rok = tok < g.N;
+    const int hf = lane >> 5, kq = hf * 4;
+    // z = LN(x) * gamma + beta + embedding[(t,h)]
+    f32x4 zf[NJ];
+    {
+        const float* xp = g.X + tok * g.ldx + kq;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            zf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rok) zf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+        }
+        frag_layernorm<NJ>(zf, g.gamma, g.beta, kq);
+        if (rok) {
+            const float* ep = g.emb + (tok % g.emb_mod) * L + kq;
+            float* zp = g.Z + tok * L + kq;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 e = *reinterpret_cast<const f32x4*>(ep + 8 * j);
+                zf[j] += e;
+                *reinterpret_cast<f32x4*>(zp + 8 * j) = zf[j];
+            }
+        }
+    }
+    // p = z Wp^T + bp in 8 chunks of 32 columns; |p|^2 on the VALU, p . sim_n chained on the MFMA
+    // (the C^T fragment of a chunk is the B operand of the [32 -> experts] product)
+    float ss = 0.f;
+    f32x16 lacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    SP sp;
+    sp.fetch(g.Wp, L, 0, 0, tid);
+    sp.commit(Ws(0), tid);
+    sp.fetch(g.Wp, L, 32, 0, tid);
+    __syncthreads();
+    const float* simp = s_simT + (lane & 31) * LDS_SIM + kq;
+    for (int c = 0; c < PC; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < PC) sp.commit(Ws(buf ^ 1), tid);
+        if (c + 2 < PC) sp.fetch(g.Wp, L, (c + 2) * 32, 0, tid);
+        const f32x16 p = chunk_mma<NJ>(Ws(buf), zf, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bp + c * 32 + 8 * q + kq);
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(simp + c * 32 + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = p[4 * q + i] + bb[i];
+                ss += v * v;
+                lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], v, lacc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);                    // F.normalize(dim=1)
+    const float scale = g.logit_scale[0];
+    // this lane holds the logits of experts e(r) = (r & 3) + 8 (r >> 2) + 4 hf, r = 0..7; its partner the other 8
+    float lg[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        lg[r] = e < g.E ? (lacc[r] / denom) * scale : -INFINITY;
+        mx = fmaxf(mx, lg[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        lg[r] = expf(lg[r] - mx);          // exp(-inf) = 0 for e >= E
+        sum += lg[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    auto merge = [&](float& v, int& e) {   // combine with the partner half: larger score, lowest index on ties
+        const float pv = __shfl_xor(v, 32, 64);
+        const int pe = __shfl_xor(e, 32, 64);
+        if (pv > v || (pv == v && pe < e)) { v = pv; e = pe; }
+    };
+    float m1 = -1.f, m2 = -1.f;
+    int c1 = 99, c2 = 99;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        lg[r] = lg[r] / sum;
+        if (e < g.E && lg[r] > m1) { m1 = lg[r]; c1 = e; }
+    }
+    merge(m1, c1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (e < g.E && e != c1 && lg[r] > m2) { m2 = lg[r]; c2 = e; }
+    }
+    merge(m2, c2);
+    if (rok && lane < 32) {
+        const float den = fmaxf(m1 + m2, 1.1920928955078125e-07f);   // normalize_gate, finfo(float32).eps
+        g.idx[tok * 2] = c1;
+        g.idx[tok * 2 + 1] = c2;
+        g.gate[tok * 2] = m1 / den;
+        g.gate[tok * 2 + 1] = m2 / den;
+        g.key[tok] = __float_as_uint(m1);
+        atomicAdd(&s_cnt[c1], 1);
+        atomicAdd(&s_cnt[MAXE + c2], 1);
+    }
+    __syncthreads();
+    if (tid < 2 * MAXE && s_cnt[tid]) atomicAdd(&g.cnt[tid], s_cnt[tid]);
+}
+
+// =================================================================================================
+// combproj_k: a = GELU(w0 y0 + w1 y1) (post-score combine, st_attention.py:52) ; mf = a Wproj^T + b
+// lnqkv_k   : q|k|v = LN(body_value) Wqkv^T + b   (efficient_attention.py:32-38, one shared LayerNorm)
+// Both: one B-operand fragment per wave (32 rows x L in L/2 VGPRs), N streamed in 32-column chunks.
+// =================================================================================================
+template <int L, int KIND>   // KIND 0: combproj, 1: lnqkv
+__global__ __launch_bounds__(256, 3) void rowchain_k(RowChainArgs g) {
+    constexpr int NJ = L / 8;
+    using SP = ChunkStage<32, L>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD];
+    auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tok = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool rok = tok < g.N;
+    const int kq = (lane >> 5) * 4;
+    f32x4 xf[NJ];
+    if constexpr (KIND == 0) {
+        const float w0 = rok ? g.comb_w[2 * tok] : 0.f, w1 = rok ? g.comb_w[2 * tok + 1] : 0.f;
+        const float* y0 = g.X + 2 * tok * L + kq;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (w0 != 0.f) a = *reinterpret_cast<const f32x4*>(y0 + 8 * j);        // dropped choices were never written
+            if (w1 != 0.f) b = *reinterpret_cast<const f32x4*>(y0 + L + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[j][i] = gelu_exact(w0 * a[i] + w1 * b[i]);
+        }
+    } else {
+        const float* xp = g.X + tok * g.ldx + kq;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rok) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+        }
+        frag_layernorm<NJ>(xf, g.gamma, g.beta, kq);
+    }
+    const int nc = g.Nout / 32;
+    SP sp;
+    sp.fetch(g.W, L, 0, 0, tid);
+    sp.commit(Ws(0), tid);
+    if (nc > 1) sp.fetch(g.W, L, 32, 0, tid);
+    __syncthreads();
+    float* orow = g.Y + tok * g.ldy + kq;
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) sp.commit(Ws((c & 1) ^ 1), tid);
+        if (c + 2 < nc) sp.fetch(g.W, L, (c + 2) * 32, 0, tid);
+        const f32x16 a = chunk_mma<NJ>(Ws(c & 1), xf, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + c * 32 + 8 * q + kq);
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]};
+            if (rok) *reinterpret_cast<f32x4*>(orow + c * 32 + 8 * q) = v;
+        }
+        __syncthreads();
+    }
+}
+
+int tune_bits() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MC_CHAIN");
+        v = e ? atoi(e) : 7;
+    }
+    return v;
+}
+
+}  // namespace
+
+bool mc_chain_enabled(int which) { return (tune_bits() >> which) & 1; }
+
+bool mc_mlp_supported(int L, int hidden) { return (L == 32 || L == 64 || L == 128) && hidden % 32 == 0 && hidden >= 32; }
+
+int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStream_t s) {
+    MC_REQUIRE(mc_mlp_supported(g.L, g.hidden), "fused mlp: L=%d hidden=%d unsupported", g.L, g.hidden);
+    MC_REQUIRE(g.ldx % 4 == 0 && g.ldy % 4 == 0 && g.x_gstride % 4 == 0 && g.y_gstride % 4 == 0, "fused mlp: unaligned strides");
+    dim3 grid;
+    if (mode == MLP_EXPERT) {
+        if (max_tiles <= 0) return MC_OK;
+        grid = dim3(max_tiles);
+    } else {
+        if (g.M <= 0) return MC_OK;
+        grid = dim3(cdiv(g.M, 128), groups);
+    }
+#define MC_MLP_CASE(LL)                                                                              \
+    case LL:                                                                                         \
+        if (mode == MLP_EXPERT) hipLaunchKernelGGL((mlp2_k<LL, MLP_EXPERT>), grid, dim3(256), 0, s, g); \
+        else hipLaunchKernelGGL((mlp2_k<LL, MLP_PARTS>), grid, dim3(256), 0, s, g);                  \
+        break;
+    switch (g.L) {
+        MC_MLP_CASE(128)
+        MC_MLP_CASE(64)
+        MC_MLP_CASE(32)
+        default: mc_set_error("fused mlp: L=%d unsupported", g.L); return MC_ERR_ARG;
+    }
+#undef MC_MLP_CASE
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_gate(const GateArgs& g, hipStream_t s) {
+    MC_REQUIRE(g.E >= 2 && g.E <= 16, "gate: num_experts=%d unsupported (2..16)", g.E);
+    if (g.N <= 0) return MC_OK;
+    MC_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * 32, s));
+    dim3 grid(cdiv(g.N, 128));
+    switch (g.L) {
+        case 128: hipLaunchKernelGGL(gate_k<128>, grid, dim3(256), 0, s, g); break;
+        case 64: hipLaunchKernelGGL(gate_k<64>, grid, dim3(256), 0, s, g); break;
+        case 32: hipLaunchKernelGGL(gate_k<32>, grid, dim3(256), 0, s, g); break;
+        default: mc_set_error("gate: L=%d unsupported", g.L); return MC_ERR_ARG;
+    }
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s) {
+    MC_REQUIRE(g.Nout % 32 == 0 && g.ldy % 4 == 0, "rowchain: Nout=%d / ldy unsupported", g.Nout);
+    if (g.N <= 0) return MC_OK;
+    dim3 grid(cdiv(g.N, 128));
+#define MC_RC_CASE(LL)                                                                    \
+    case LL:                                                                              \
+        if (kind == 0) hipLaunchKernelGGL((rowchain_k<LL, 0>), grid, dim3(256), 0, s, g);  \
+        else hipLaunchKernelGGL((rowchain_k<LL, 1>), grid, dim3(256), 0, s, g);            \
+        break;
+    switch (g.L) {
+        MC_RC_CASE(128)
+        MC_RC_CASE(64)
+        MC_RC_CASE(32)
+        default: mc_set_error("rowchain: L=%d unsupported", g.L); return MC_ERR_ARG;
+    }
+#undef MC_RC_CASE
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

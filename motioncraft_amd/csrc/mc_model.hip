@@ -17,7 +17,7 @@
 #include "mc_common.h"
 #include "mc_gemm.h"
 #include "mc_kernels.h"
-#include "mc_mlp.h"
+#include "mc_chain.h"
 
 struct mc_model {
     mc_model_config cfg;
@@ -172,17 +172,20 @@ int dense(const float* A, long lda, const float* W, long ldw, const float* bias,
 
 // One tutel MoE layer + GELU + proj (class MOE, st_attention.py:49-56) over Ntok tokens whose
 // gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
-int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, hipStream_t s) {
+// `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
+int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, bool gated, hipStream_t s) {
     const mc_model_config& g = c->m->cfg;
     const int E = g.num_experts, din = w.din, hid = 4 * w.din;
     int r;
-    // cosine projector (tutel/gates/cosine_top.py): proj = z Wp^T + bp
-    if ((r = dense(z, din, w.gate_w, din, w.gate_b, nullptr, 0, c->proj, 256, Ntok, 256, din, ACT_NONE, s))) return r;
-    if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
+    if (!gated) {
+        // cosine projector (tutel/gates/cosine_top.py): proj = z Wp^T + bp
+        if ((r = dense(z, din, w.gate_w, din, w.gate_b, nullptr, 0, c->proj, 256, Ntok, 256, din, ACT_NONE, s))) return r;
+        if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
+    }
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
     if ((r = mc_launch_route(Ntok, E, capacity, c->rb, s))) return r;
     const int max_tiles = cdiv(2 * Ntok, 128) + E;
-    if (mc_mlp_supported(din, hid)) {
+    if (mc_chain_enabled(0) && mc_mlp_supported(din, hid)) {
         // fused expert FFN: hidden activations stay on chip (mc_mlp.hip)
         MlpArgs m;
         m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
@@ -205,6 +208,12 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
         b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
         b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
         if ((r = mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s))) return r;
+    }
+    if (mc_chain_enabled(2) && mc_mlp_supported(din, 32) && w.dout % 32 == 0) {
+        RowChainArgs p;
+        p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.proj_w; p.bias = w.proj_b;
+        p.Y = out; p.ldy = ldout; p.N = Ntok; p.L = din; p.Nout = w.dout;
+        return mc_launch_rowchain(0, p, s);
     }
     GemmArgs p;
     p.A = c->y2; p.lda = din; p.comb_w = c->rb.comb_w;
@@ -397,7 +406,7 @@ int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_d
         const LayerW& w = c->lw[i];
         if ((r = mc_launch_ln_rows(xf_out_dev, Dt, 0, w.tnorm_g, w.tnorm_b, w.tm.emb, Nt, c->xfn, Dt, half, Dt, s))) return r;
         MC_HIP(hipMemcpyAsync(c->xfn + half * Dt, c->xfn, sizeof(float) * half * Dt, hipMemcpyDeviceToDevice, s));
-        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, s))) return r;
+        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, false, s))) return r;
     }
     c->have_cond = true;
     return MC_OK;
@@ -427,21 +436,38 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     for (int i = 0; i < nl; ++i) {
         const LayerW& w = c->lw[i];
         // ---- STMA ----
-        if ((r = mc_launch_ln_rows(c->h, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
-        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, s))) return r;
+        const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
+        if (fused_gate) {
+            GateArgs ga;
+            ga.X = c->h; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
+            ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
+            ga.N = c->N; ga.E = g.num_experts; ga.L = L;
+            ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
+            if ((r = mc_launch_gate(ga, s))) return r;
+        } else {
+            if ((r = mc_launch_ln_rows(c->h, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
+        }
+        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, fused_gate, s))) return r;
         if (c->cap_idx) {
             MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
             MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
         }
-        if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
-        if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
+        if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
+            RowChainArgs q;
+            q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
+            q.Y = c->qkv; q.ldy = 3 * L; q.N = c->N; q.L = L; q.Nout = 3 * L;
+            if ((r = mc_launch_rowchain(1, q, s))) return r;
+        } else {
+            if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
+            if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
+        }
         if ((r = mc_launch_body(c->mf, 4 * L, c->qkv, w.wsm, c->ys, c->rows, H, L, g.dyn_heads, s))) return r;
         if ((r = mc_launch_temporal(c->mf, c->tf + (long)i * c->Ntxt * 2 * L, c->mask, c->yt, 2 * c->B, c->B, c->T,
                                     g.max_text_len, H, L, s))) return r;
         const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
         if ((r = film_block(c, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, s))) return r;
         // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
-        if (mc_mlp_supported(L, F)) {
+        if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
             MlpArgs m;
             m.X = c->h; m.ldx = D; m.x_gstride = L;
             m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
