@@ -10,92 +10,105 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------
-// One workgroup per frame (b,t).  bv = motion_feat[..., 0:L] of the frame's H tokens,
-// qkv = [query | key | value] of LN(bv) (GEMM done before).  Writes
-//   ys[h][c] = sum_l softmax(body_weight)[h][l] bv[l][c]  +  bv[h][c] + (q A)[h][c]
+// Body topology, register-resident: HD = L/8 lanes per (frame, head g); lane l of a group owns
+// channel c = g*HD + l of all H parts: bv[h][c], q[h][c], k[h][c], v[h][c] (4H registers).
+//   static : ys[h][c]  = sum_j softmax(body_weight)[h][j] * bv[j][c]              (in-lane, st_attention.py:123-128)
+//   dynamic: k softmax over the H parts (in-lane), q softmax over the HD channels of the head
+//            (group shuffles), A[d][l] = sum_h k[h][d] v[h][l] and y[h][l] = sum_d q[h][d] A[d][l]
+//            with k/q broadcast inside the HD-lane group   (efficient_attention.py:25-46, mask == 1)
+// No LDS, no barriers; every load/store instruction of a wave covers 256 contiguous bytes.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void body_k(const float* __restrict__ mf, long ldmf, const float* __restrict__ qkv,
-                                              const float* __restrict__ wsm, float* __restrict__ ys, int H, int L, int G) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int HL = H * L;
-    const int hd = L / G;
-    float* s_bv = sm;
-    float* s_q = s_bv + HL;
-    float* s_k = s_q + HL;
-    float* s_v = s_k + HL;
-    float* s_A = s_v + HL;          // [G][hd][hd]
-    float* s_w = s_A + L * hd;      // [H][H]
-    const long frame = blockIdx.x;
+template <int HD, int H>
+__global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, long ldmf, const float* __restrict__ qkv,
+                                                   const float* __restrict__ wsm, float* __restrict__ ys, long frames) {
+    constexpr int G = 8, L = G * HD;
+    constexpr int GPW = 64 / HD;                 // (frame, head) groups per wave
+    __shared__ float s_w[H * H];
+    for (int i = threadIdx.x; i < H * H; i += 256) s_w[i] = wsm[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long grp = wave * GPW + lane / HD;     // global (frame, head) index
+    const long frame = grp / G;
+    const int gh = (int)(grp % G), l = lane % HD;
+    if (frame >= frames) return;                 // whole HD-lane groups leave together
+    const int c = gh * HD + l;
     const long tok0 = frame * H;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < HL / 4; i += 256) {
-        const int h = (i * 4) / L, c = (i * 4) % L;
-        *reinterpret_cast<f32x4*>(s_bv + h * L + c) = *reinterpret_cast<const f32x4*>(mf + (tok0 + h) * ldmf + c);
-        const float* qr = qkv + (tok0 + h) * 3 * L + c;
-        *reinterpret_cast<f32x4*>(s_q + h * L + c) = *reinterpret_cast<const f32x4*>(qr);
-        *reinterpret_cast<f32x4*>(s_k + h * L + c) = *reinterpret_cast<const f32x4*>(qr + L);
-        *reinterpret_cast<f32x4*>(s_v + h * L + c) = *reinterpret_cast<const f32x4*>(qr + 2 * L);
+    float bv[H], q[H], k[H], v[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        bv[h] = mf[(tok0 + h) * ldmf + c];
+        const float* r = qkv + (tok0 + h) * 3 * L + c;
+        q[h] = r[0];
+        k[h] = r[L];
+        v[h] = r[2 * L];
     }
-    for (int i = tid; i < H * H; i += 256) s_w[i] = wsm[i];
-    __syncthreads();
-    // query: softmax over the hd channels of a head   (efficient_attention.py:35)
-    for (int i = tid; i < H * G; i += 256) {
-        float* p = s_q + (i / G) * L + (i % G) * hd;
-        float m = p[0];
-        for (int d = 1; d < hd; ++d) m = fmaxf(m, p[d]);
+    // key: softmax over the H body parts (dim=1)
+    {
+        float m = k[0];
+#pragma unroll
+        for (int h = 1; h < H; ++h) m = fmaxf(m, k[h]);
         float s = 0.f;
-        for (int d = 0; d < hd; ++d) { p[d] = expf(p[d] - m); s += p[d]; }
-        for (int d = 0; d < hd; ++d) p[d] /= s;
+#pragma unroll
+        for (int h = 0; h < H; ++h) { k[h] = expf(k[h] - m); s += k[h]; }
+#pragma unroll
+        for (int h = 0; h < H; ++h) k[h] /= s;
     }
-    // key: softmax over the H body parts (dim=1)      (efficient_attention.py:36), mask == 1
-    for (int c = tid; c < L; c += 256) {
-        float m = s_k[c];
-        for (int h = 1; h < H; ++h) m = fmaxf(m, s_k[h * L + c]);
-        float s = 0.f;
-        for (int h = 0; h < H; ++h) { const float e = expf(s_k[h * L + c] - m); s_k[h * L + c] = e; s += e; }
-        for (int h = 0; h < H; ++h) s_k[h * L + c] /= s;
+    // query: softmax over the HD channels of the head
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const float m = group_max(q[h], HD);
+        const float e = expf(q[h] - m);
+        q[h] = e / group_sum(e, HD);
     }
-    __syncthreads();
-    // A[g][d][l] = sum_h k[h][g,d] v[h][g,l]
-    for (int o = tid; o < L * hd; o += 256) {
-        const int g = o / (hd * hd), d = (o / hd) % hd, l = o % hd;
+    // A[d][l] = sum_h k[h][d] v[h][l]  (this lane: column l, all d)
+    float A[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
         float a = 0.f;
-        for (int h = 0; h < H; ++h) a += s_k[h * L + g * hd + d] * s_v[h * L + g * hd + l];
-        s_A[o] = a;
+#pragma unroll
+        for (int h = 0; h < H; ++h) a += __shfl(k[h], d, HD) * v[h];
+        A[d] = a;
     }
-    __syncthreads();
-    float* out = ys + frame * HL;
-    for (int o = tid; o < HL; o += 256) {
-        const int h = o / L, c = o % L, g = c / hd, l = c % hd;
+    float* out = ys + frame * (H * L) + c;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
         float st = 0.f;
-        for (int j = 0; j < H; ++j) st += s_w[h * H + j] * s_bv[j * L + c];
+#pragma unroll
+        for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
         float dy = 0.f;
-        for (int d = 0; d < hd; ++d) dy += s_q[h * L + g * hd + d] * s_A[(g * hd + d) * hd + l];
-        out[o] = st + (s_bv[o] + dy);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dy += __shfl(q[h], d, HD) * A[d];
+        out[h * L] = st + (bv[h] + dy);
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// Temporal linear attention, one workgroup per (sample b of the CFG-doubled batch, part h).
+// Temporal linear attention, one workgroup per (sample b of the CFG-doubled batch, part h)
+// (st_attention.py:137-170):
+//   K = concat(key_text + (1-c)(-1e6), key_motion + (1-mask)(-1e6)) -> softmax over the 77+T tokens
+//   V = concat(value_text * c, value_motion * mask);  A2 = K^T V  [L x L];  y_t = softmax_L(Q) A2
+// Wave w owns output columns l in [32w, 32w+32) for ALL d: A2 lives in 16*L/32 accumulator
+// registers per lane and -- C^T fragment == next B operand -- feeds the second contraction
+// directly from registers (no A2 round trip through LDS).  K/V rows stream through one 32-row LDS
+// chunk, softmax_L(Q) rows through a [32][L+4] slab read as b128 A fragments.
 // ---------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
-                                                  const float* __restrict__ mask, float* __restrict__ yt,
-                                                  int B, int T, int Nt, int H) {
-    constexpr int MT = (L == 128) ? 2 : 1;
+__global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
+                                                     const float* __restrict__ mask, float* __restrict__ yt,
+                                                     int B, int T, int Nt, int H) {
+    constexpr int NT = L / 32;           // 32-wide d tiles (= active waves)
     constexpr int LP = L + 4;
-    constexpr int LQ = L + 1;
     constexpr int C4 = L / 4;            // float4 columns per row
     constexpr int NSL = 256 / C4;        // row slices in the stats pass
-    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP + L * LP];
+    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP + 32 * LP];
     float* s_m = sm;
     float* s_s = s_m + L;
     float* s_pm = s_s + L;               // [NSL][L]
     float* s_ps = s_pm + NSL * L;        // [NSL][L]
     float* Ks = s_ps + NSL * L;          // [32][LP]
     float* Vs = Ks + 32 * LP;            // [32][LP]
-    float* A2s = Vs + 32 * LP;           // [L][LP]
-    float* Qs = Ks;                      // [32][LQ]  (aliases Ks/Vs after phase 2)
+    float* Qs = Vs + 32 * LP;            // [32][LP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -104,6 +117,7 @@ __global__ __launch_bounds__(256) void temporal_k(const float* __restrict__ mf, 
     const int Nseq = Nt + T;
     const float NEG = -1000000.f;
     const long D4 = 4 * L;
+    const int hf = lane >> 5;
 
     auto load_kv = [&](int n, int c4, f32x4& kk, f32x4& vv) {
         if (n < Nt) {
@@ -154,15 +168,12 @@ __global__ __launch_bounds__(256) void temporal_k(const float* __restrict__ mf, 
     __syncthreads();
 
     // ---- phase 2: A2[d][l] = sum_n softmaxK[n][d] V[n][l]  (st_attention.py:167) ----
-    const bool mm_active = (L >= 64) || wave == 0;
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[MT][MT];
+    const bool mm_active = wave < NT;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int dt = 0; dt < NT; ++dt)
 #pragma unroll
-        for (int ni = 0; ni < MT; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const int nch = (Nseq + 31) / 32;
     for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
@@ -184,36 +195,21 @@ __global__ __launch_bounds__(256) void temporal_k(const float* __restrict__ mf, 
         if (mm_active) {
 #pragma unroll 4
             for (int ks = 0; ks < 16; ++ks) {
-                const int n = 2 * ks + (lane >> 5);
-                float a[MT], bb[MT];
+                const int n = 2 * ks + hf;
+                const float bb = Vs[n * LP + wave * 32 + (lane & 31)];
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) a[mi] = Ks[n * LP + (wm * MT + mi) * 32 + (lane & 31)];
-#pragma unroll
-                for (int ni = 0; ni < MT; ++ni) bb[ni] = Vs[n * LP + (wn * MT + ni) * 32 + (lane & 31)];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < MT; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bb[ni], acc[mi][ni], 0, 0, 0);
+                for (int dt = 0; dt < NT; ++dt) {
+                    const float a = Ks[n * LP + dt * 32 + (lane & 31)];
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[dt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
     }
-    if (mm_active) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < MT; ++ni)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int d = (wm * MT + mi) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    const int l = (wn * MT + ni) * 32 + (lane & 31);
-                    A2s[d * LP + l] = acc[mi][ni][reg];
-                }
-    }
-    __syncthreads();
 
-    // ---- phase 3: y_t[t] = softmax_L(q[t]) A2   (st_attention.py:164-169) ----
+    // ---- phase 3: y_t[t][l] = sum_d softmax_L(q[t])[d] A2[d][l]  (st_attention.py:164-169) ----
+    // lane (l = 32*wave + (lane&31), half hf) holds A2[d][l] for d = 32 dt + 8 q + 4 hf + i in acc[dt][4q+i]:
+    // exactly the B operand of k-group (dt, q); the A operand Q[t][same d] is one b128 read.
     const int ntc = (T + 31) / 32;
     for (int tc = 0; tc < ntc; ++tc) {
         {
@@ -240,23 +236,29 @@ __global__ __launch_bounds__(256) void temporal_k(const float* __restrict__ mf, 
             }
             s = group_sum(s, 8);
 #pragma unroll
-            for (int j = 0; j < SEG; ++j) Qs[row * LQ + sub * SEG + j] = (t < T) ? v[j] / s : 0.f;
+            for (int j = 0; j < SEG; j += 4) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (t < T) o = f32x4{v[j] / s, v[j + 1] / s, v[j + 2] / s, v[j + 3] / s};
+                *reinterpret_cast<f32x4*>(Qs + row * LP + sub * SEG + j) = o;
+            }
         }
         __syncthreads();
-        if (wave < L / 32) {
+        if (mm_active) {
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll 4
-            for (int ks = 0; ks < L / 2; ++ks) {
-                const int d = 2 * ks + (lane >> 5);
-                const float a = Qs[(lane & 31) * LQ + d];
-                const float bb = A2s[d * LP + wave * 32 + (lane & 31)];
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, o, 0, 0, 0);
-            }
+            const float* qp = Qs + (lane & 31) * LP + 4 * hf;
+#pragma unroll
+            for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(qp + dt * 32 + 8 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], acc[dt][4 * q + i], o, 0, 0, 0);
+                }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int t = tc * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int t = tc * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
                 if (t < T) yt[((long)b * T + t) * (H * L) + h * L + wave * 32 + (lane & 31)] = o[reg];
             }
         }
@@ -268,11 +270,15 @@ __global__ __launch_bounds__(256) void temporal_k(const float* __restrict__ mf, 
 
 int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* wsm, float* ys,
                    long frames, int H, int L, int G, hipStream_t s) {
-    MC_REQUIRE(L % 4 == 0 && L % G == 0, "body: L=%d G=%d unsupported", L, G);
-    const size_t lds = sizeof(float) * ((size_t)4 * H * L + (size_t)L * (L / G) + (size_t)H * H);
-    MC_REQUIRE(lds <= 160 * 1024, "body: tile does not fit LDS");
+    MC_REQUIRE(G == 8 && H == 12 && (L == 32 || L == 64 || L == 128), "body: H=%d L=%d G=%d unsupported", H, L, G);
     if (frames <= 0) return MC_OK;
-    hipLaunchKernelGGL(body_k, dim3((unsigned)frames), dim3(256), lds, s, mf, ldmf, qkv, wsm, ys, H, L, G);
+    const int hd = L / G;
+    const long groups = frames * G;               // (frame, head) groups of hd lanes
+    const long waves = (groups * hd + 63) / 64;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (hd == 16) hipLaunchKernelGGL((body_reg_k<16, 12>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
+    else if (hd == 8) hipLaunchKernelGGL((body_reg_k<8, 12>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
+    else hipLaunchKernelGGL((body_reg_k<4, 12>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

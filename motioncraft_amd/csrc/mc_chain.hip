@@ -50,29 +50,32 @@ struct ChunkStage {
     }
 };
 
-// acc[32 out][32 rows] = Wc[32 out][8*NJ] * X[32 rows][8*NJ].  One accumulator chain: for
-// v_mfma_f32_32x32x2_f32 the dependent-accumulator latency equals the 64-cycle issue interval.
-template <int NJ>
+// acc[32 out][32 rows] = Wc[32 out][8*NJ] * X[32 rows][8*NJ] with CH independent accumulator chains
+// (k-groups dealt round-robin, summed at the end).
+template <int NJ, int CH = 2>
 __device__ __forceinline__ f32x16 chunk_mma(const float* Wc, const f32x4 (&xf)[NJ], int lane) {
     constexpr int LDW = 8 * NJ + 4;
-    f32x16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
     const float* wp = Wc + (lane & 31) * LDW + (lane >> 5) * 4;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + 8 * j);
+    for (int j = 0; j < NJ; j += CH) {
+        f32x4 w[CH];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], xf[j][i], a, 0, 0, 0);
-    }
-    // schedule: weight fragments are read two k-groups ahead of their MFMAs instead of all NJ at
-    // once (the default hoists every ds_read_b128 to the top: +4*NJ live VGPRs)
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        for (int c = 0; c < CH; ++c) w[c] = *reinterpret_cast<const f32x4*>(wp + 8 * (j + c));
 #pragma unroll
-    for (int j = 0; j < NJ - 2; ++j) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][i], xf[j + c][i], acc[c], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    return a;
+#pragma unroll
+    for (int c = 1; c < CH; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] += acc[c][q];
+    return acc[0];
 }
 
 // per-row LayerNorm of a fragment-distributed row: lane l and lane l^32 hold the two halves
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
             s2.fetch(W2t, g.hidden, 0, (hc + 2) * HC, tid);
         }
         // FC1 chunk: 32 hidden units of this wave's 32 rows
-        const f32x16 a1 = chunk_mma<NJ>(W1s(buf), xf, lane);
+        const f32x16 a1 = chunk_mma<NJ, 1>(W1s(buf), xf, lane);
         // bias + exact GELU; the C^T fragment IS the B-operand fragment of FC2 (k-group q)
         f32x4 hf[4];
 #pragma unroll
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
 // Both: one B-operand fragment per wave (32 rows x L in L/2 VGPRs), N streamed in 32-column chunks.
 // =================================================================================================
 template <int L, int KIND>   // KIND 0: combproj, 1: lnqkv
-__global__ __launch_bounds__(256, 3) void rowchain_k(RowChainArgs g) {
+__global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     constexpr int NJ = L / 8;
     using SP = ChunkStage<32, L>;
     __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD];
