@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_rows_k(const float* __restrict__ X, lo
 // precomputed per (step, layer, block): ss[0:D] = scale, ss[D:2D] = shift.
 // ---------------------------------------------------------------------------------------
 constexpr int FILM_MAXC = 8;  // 8 float4 chunks x 64 lanes = 2048 channels
-__global__ __launch_bounds__(256) void film_rows_k(const float* __restrict__ Y1, const float* __restrict__ Y2,
+__global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ Y1, const float* __restrict__ Y2,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ ss, float* __restrict__ A,
                                                    long rows, int D) {
