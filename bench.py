@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 TOTAL_DDPM_STEPS = 1000
+# HBM bytes of one B=64 step from rocprofv3 PMC passes (cannot be collected from inside this process);
+# re-measured when the kernel schedule changes: profiles/r01_pmc_hbm_traffic.txt
+MEASURED_HBM_GB_PER_STEP_B64 = 33.07
 
 DIMS = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77, E=16, topk=2,
             scale=6.5)
@@ -217,7 +220,8 @@ def main():
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': MEASURED_HBM_GB_PER_STEP_B64 if (B, T) == (64, 196) else None,
+                         'traffic_unit': 'GB per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate PMC passes; profiles/r01_pmc_hbm_traffic.txt)',
                          'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_k fp32 MFMA GEMMs)',
                          'algorithmic_gflop_per_sample_step': round(algorithmic_flops_per_sample_step(DIMS, T) / 1e9, 3),
                          'event_ms_per_step': round(ev_ms, 4)},
