@@ -11,6 +11,7 @@
  *                         + time_embed / emb_layers hoists             diffusion_transformer.py:89-93,206-208; stylization_block.py:17-20
  *   mc_ctx_set_condition  model_kwargs {xf_out, motion_mask}           mogen/models/architectures/diffusion_architecture.py:166-174
  *                         + per-layer text_moe K/V hoist               mogen/models/attentions/st_attention.py:116-118
+ *   mc_ctx_set_control    ControlT2MHalf.forward_c + before_proj           mogen/models/transformers/controlnet.py:66,186-199
  *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
  *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
  *
@@ -53,6 +54,10 @@ typedef struct mc_model_config {
     int32_t dyn_heads;        /* 8 (st_attention.py:95)                            */
     float capacity_factor;    /* 1.5 (st_attention.py:33)                          */
     float cfg_scale;          /* scale_func_cfg.scale = 6.5                        */
+    /* plug-and-play control branch ControlT2MHalf (mogen/models/transformers/controlnet.py:107-183); 0 = none */
+    int32_t num_ctrl_layers;  /* copy_blocks_num                                   */
+    int32_t ctrl_cond_feats;  /* width of the condition fed to control_cond_input  */
+    int32_t ctrl_condition_cfg; /* condition_encode_cfg.condition_cfg: zero c in the uncond half */
 } mc_model_config;
 
 /* per-step scalars of the sampler, fp64 schedule tables cast to fp32 like _extract_into_tensor
@@ -87,6 +92,10 @@ int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
 int mc_ctx_enable_capture(mc_ctx* c);
 int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t num_steps, void* stream);
 int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_dev, void* stream);
+/* control condition (ControlT2MHalf.forward_c + controlnet[0].before_proj, controlnet.py:186-199, 66):
+ * c_feat_dev [B, Tc, ctrl_cond_feats] = output of the (step-invariant) condition_pre_encoder, Tc <= frames;
+ * NULL disables the branch for this context (forward_test with c=None, controlnet.py:405-413). */
+int mc_ctx_set_control(mc_ctx* c, const float* c_feat_dev, int32_t Tc, void* stream);
 
 /* x_t_dev [B,T,C] at schedule index step_index -> out2_dev [2B,T,C] (text half, then uncond half);
  * out2_dev may be NULL (result stays in the context, buffer "out2").

@@ -5,6 +5,7 @@ from .builder import (ARCHITECTURES, ATTENTIONS, LOSSES, MODELS, SUBMODULES, bui
 from .config import Config, ConfigDict
 from .registry import Registry, build_from_cfg
 from . import models as _models  # registers MotionDiffusion / STMoGenTransformer / STMA / MSELoss
+from .models import ControlT2MHalf
 
 __all__ = ['ARCHITECTURES', 'ATTENTIONS', 'LOSSES', 'MODELS', 'SUBMODULES', 'build_architecture',
-           'build_attention', 'build_loss', 'build_submodule', 'Config', 'ConfigDict', 'Registry', 'build_from_cfg']
+           'build_attention', 'build_loss', 'build_submodule', 'Config', 'ConfigDict', 'Registry', 'build_from_cfg', 'ControlT2MHalf']

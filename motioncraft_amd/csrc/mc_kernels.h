@@ -13,6 +13,8 @@ int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, co
 // te[s][0:D] = cat(cos(t_s f), sin(t_s f))
 int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s);
 int mc_launch_silu(const float* X, float* Y, long n, hipStream_t s);
+// out = a + b + bias (each optional), rows x D
+int mc_launch_add_rows(float* out, const float* a, const float* b, const float* bias, long rows, int D, hipStream_t s);
 // out = softmax(W[H][H], dim=1)
 int mc_launch_softmax_rows_small(const float* W, float* out, int rows, int cols, hipStream_t s);
 

@@ -117,6 +117,20 @@ __global__ void timestep_embedding_k(const int* __restrict__ t_orig, float* __re
     te[i] = v;
 }
 
+// out[r][c] = a[r][c] (or 0) + b[r][c] (or 0) + bias[c] (or 0), D % 4 == 0
+__global__ __launch_bounds__(256) void add_rows_k(float* __restrict__ out, const float* __restrict__ a,
+                                                  const float* __restrict__ b, const float* __restrict__ bias,
+                                                  long rows, int D) {
+    const long n4 = rows * (D / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a) v += *reinterpret_cast<const f32x4*>(a + i * 4);
+        if (b) v += *reinterpret_cast<const f32x4*>(b + i * 4);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + (i % (D / 4)) * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
 __global__ void silu_k(const float* __restrict__ X, float* __restrict__ Y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) Y[i] = silu_f(X[i]);
@@ -187,6 +201,16 @@ int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, co
 
 int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s) {
     hipLaunchKernelGGL(timestep_embedding_k, dim3(cdiv((long)S * D, 256)), dim3(256), 0, s, t_orig, te, S, D);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_add_rows(float* out, const float* a, const float* b, const float* bias, long rows, int D, hipStream_t s) {
+    MC_REQUIRE(D % 4 == 0, "add_rows: D %% 4 != 0");
+    if (rows <= 0) return MC_OK;
+    long blocks = (rows * (D / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_rows_k, dim3((unsigned)blocks), dim3(256), 0, s, out, a, b, bias, rows, D);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

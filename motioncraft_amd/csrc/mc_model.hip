@@ -38,6 +38,8 @@ struct LayerW {
     const float *ca_film_w, *ca_film_b, *ca_ln_g, *ca_ln_b, *ca_out_w, *ca_out_b;
     const float *ffn_w1, *ffn_b1, *ffn_w2, *ffn_b2;
     const float *ffn_film_w, *ffn_film_b, *ffn_ln_g, *ffn_ln_b, *ffn_out_w, *ffn_out_b;
+    // control-branch copies only (ControlT2MBlock): zero-init projections around the copied DecoderLayer
+    const float *before_w = nullptr, *before_b = nullptr, *after_w = nullptr, *after_b = nullptr;
 };
 
 struct mc_ctx {
@@ -46,6 +48,10 @@ struct mc_ctx {
     long N = 0, rows = 0, Ntxt = 0;
     std::vector<LayerW> lw;
     const float *enc_w, *enc_b, *seq_emb, *time_w0, *time_b0, *time_w2, *time_b2, *dec_w, *dec_b;
+    const float *ctrl_in_w = nullptr, *ctrl_in_b = nullptr;
+    int NLA = 0;                 // base + control layers (weights, text K/V and FiLM tables are per layer slot)
+    float *hc = nullptr, *cb = nullptr, *cenc = nullptr;   // control stream, before_proj(c) [rows,D], forward_c(c) [B*T,D]
+    bool have_ctrl = false;
     // workspace
     std::vector<void*> allocs;
     int64_t bytes = 0;
@@ -125,10 +131,24 @@ int bind_weights(mc_ctx* c) {
     GP(c->time_b2, "time.b2", Te);
     GP(c->dec_w, "dec.w", (int64_t)g.input_feats * D);
     GP(c->dec_b, "dec.b", g.input_feats);
-    c->lw.resize(g.num_layers);
-    for (int i = 0; i < g.num_layers; ++i) {
+    c->NLA = g.num_layers + g.num_ctrl_layers;
+    c->lw.resize(c->NLA);
+    if (g.num_ctrl_layers > 0) {
+        GP(c->ctrl_in_w, "ctrl_in.w", (int64_t)D * ((g.ctrl_cond_feats + 3) / 4 * 4));
+        GP(c->ctrl_in_b, "ctrl_in.b", D);
+    }
+    for (int i = 0; i < c->NLA; ++i) {
         LayerW& w = c->lw[i];
-        const std::string p = "l" + std::to_string(i) + ".";
+        const bool is_ctrl = i >= g.num_layers;
+        const std::string p = (is_ctrl ? "c" + std::to_string(i - g.num_layers) : "l" + std::to_string(i)) + ".";
+        if (is_ctrl) {
+            if (i == g.num_layers) {
+                GP(w.before_w, p + "before_w", (int64_t)D * D);
+                GP(w.before_b, p + "before_b", D);
+            }
+            GP(w.after_w, p + "after_w", (int64_t)D * D);
+            GP(w.after_b, p + "after_b", D);
+        }
         GP(w.norm_g, p + "norm.g", L);
         GP(w.norm_b, p + "norm.b", L);
         GP(w.tnorm_g, p + "text_norm.g", g.text_latent_dim);
@@ -222,13 +242,79 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     return mc_launch_gemm(GM_COMB, p, 1, 0, s);
 }
 
-int film_block(mc_ctx* c, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
+int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, hipStream_t s) {
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     int r;
     if ((r = mc_launch_film_rows(y1, y2, ln_g, ln_b, ss, c->a, c->rows, D, s))) return r;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
-    return dense(c->a, D, out_w, D, out_b, c->h, D, c->h, D, c->rows, D, D, ACT_NONE, s);
+    return dense(c->a, D, out_w, D, out_b, hs, D, hs, D, c->rows, D, D, ACT_NONE, s);
+}
+
+// One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
+// `i` selects the layer slot (weights, text K/V, FiLM tables): base layers first, control copies after.
+int run_layer(mc_ctx* c, int i, float* hs, int step, hipStream_t s) {
+    const mc_model_config& g = c->m->cfg;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
+    const LayerW& w = c->lw[i];
+    int r;
+        // ---- STMA ----
+        const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
+        if (fused_gate) {
+            GateArgs ga;
+            ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
+            ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
+            ga.N = c->N; ga.E = g.num_experts; ga.L = L;
+            ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
+            if ((r = mc_launch_gate(ga, s))) return r;
+        } else {
+            if ((r = mc_launch_ln_rows(hs, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
+        }
+        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, fused_gate, s))) return r;
+        if (c->cap_idx) {
+            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
+            MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
+        }
+        if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
+            RowChainArgs q;
+            q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
+            q.Y = c->qkv; q.ldy = 3 * L; q.N = c->N; q.L = L; q.Nout = 3 * L;
+            if ((r = mc_launch_rowchain(1, q, s))) return r;
+        } else {
+            if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
+            if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
+        }
+        if ((r = mc_launch_body(c->mf, 4 * L, c->qkv, w.wsm, c->ys, c->rows, H, L, g.dyn_heads, s))) return r;
+        if ((r = mc_launch_temporal(c->mf, c->tf + (long)i * c->Ntxt * 2 * L, c->mask, c->yt, 2 * c->B, c->B, c->T,
+                                    g.max_text_len, H, L, s))) return r;
+        const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
+        if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, s))) return r;
+        // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
+        if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
+            MlpArgs m;
+            m.X = hs; m.ldx = D; m.x_gstride = L;
+            m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
+            m.Y = c->z2; m.ldy = D; m.y_gstride = L; m.M = (int)c->rows; m.L = L; m.hidden = F;
+            if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
+        } else {
+            GemmArgs f1;
+            f1.A = hs; f1.lda = D; f1.a_gstride = L;
+            f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
+            f1.bias = w.ffn_b1; f1.b_gstride = F; f1.act = ACT_GELU;
+            f1.C = c->fh; f1.ldc = (long)H * F; f1.c_gstride = F;
+            f1.M = (int)c->rows; f1.N = F; f1.K = L;
+            if ((r = mc_launch_gemm(GM_PLAIN, f1, H, 0, s))) return r;
+            GemmArgs f2;
+            f2.A = c->fh; f2.lda = (long)H * F; f2.a_gstride = F;
+            f2.W = w.ffn_w2; f2.ldw = F; f2.w_gstride = (long)L * F;
+            f2.bias = w.ffn_b2; f2.b_gstride = L;
+            f2.C = c->z2; f2.ldc = D; f2.c_gstride = L;
+            f2.M = (int)c->rows; f2.N = L; f2.K = F;
+            if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
+        }
+        const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
+        if ((r = film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, s))) return r;
+    return MC_OK;
 }
 
 }  // namespace
@@ -251,6 +337,8 @@ int mc_model_create(const mc_model_config* cfg, mc_model** out) {
     MC_REQUIRE(cfg->topk == 2, "topk=%d unsupported (reference configs use 2)", cfg->topk);
     MC_REQUIRE(cfg->num_experts >= 2 && cfg->num_experts <= 16, "num_experts=%d unsupported", cfg->num_experts);
     MC_REQUIRE(cfg->latent_dim % cfg->dyn_heads == 0, "latent_dim %% dyn_heads != 0");
+    MC_REQUIRE(cfg->num_ctrl_layers >= 0 && cfg->num_ctrl_layers < cfg->num_layers, "copy_blocks_num=%d must be in [0, num_layers)", cfg->num_ctrl_layers);
+    MC_REQUIRE(cfg->num_ctrl_layers == 0 || cfg->ctrl_cond_feats >= 1, "ctrl_cond_feats must be >= 1");
     MC_REQUIRE(cfg->ffn_dim % 4 == 0 && cfg->time_embed_dim % 4 == 0 && cfg->text_latent_dim % 4 == 0, "dims must be multiples of 4");
     {
         const int q = cfg->text_latent_dim / 4;
@@ -326,13 +414,18 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->fh, c->rows * H * F);
     WS(c->out2, c->rows * g.input_feats);
     WS(c->xfn, c->Ntxt * Dt);
-    WS(c->tf, (long)g.num_layers * c->Ntxt * 2 * L);
+    WS(c->tf, (long)c->NLA * c->Ntxt * 2 * L);
     WS(c->t_orig, max_steps);
     WS(c->te, (long)max_steps * D);
     WS(c->e1, (long)max_steps * Te);
     WS(c->emb, (long)max_steps * Te);
     WS(c->semb, (long)max_steps * Te);
-    WS(c->ss, (long)g.num_layers * 2 * max_steps * 2 * D);
+    WS(c->ss, (long)c->NLA * 2 * max_steps * 2 * D);
+    if (g.num_ctrl_layers > 0) {
+        WS(c->hc, c->rows * D);
+        WS(c->cb, c->rows * D);
+        WS(c->cenc, (long)batch * frames * D);
+    }
     WS(c->rb.idx, 2 * Nmax);
     WS(c->rb.gate, 2 * Nmax);
     WS(c->rb.key, Nmax);
@@ -361,8 +454,8 @@ int mc_ctx_enable_capture(mc_ctx* c) {
     MC_REQUIRE(c, "null context");
     if (c->cap_idx) return MC_OK;
     int r;
-    if ((r = ws_alloc(c, &c->cap_idx, (size_t)c->m->cfg.num_layers * 2 * c->N)) != MC_OK) return r;
-    return ws_alloc(c, &c->cap_w, (size_t)c->m->cfg.num_layers * 2 * c->N);
+    if ((r = ws_alloc(c, &c->cap_idx, (size_t)c->NLA * 2 * c->N)) != MC_OK) return r;
+    return ws_alloc(c, &c->cap_w, (size_t)c->NLA * 2 * c->N);
 }
 
 // time_embed (diffusion_transformer.py:89-93,206-208) and every StylizationBlock.emb_layers
@@ -381,7 +474,7 @@ int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t S, void*
     if ((r = dense(c->te, D, c->time_w0, D, c->time_b0, nullptr, 0, c->e1, Te, S, Te, D, ACT_SILU, s))) return r;
     if ((r = dense(c->e1, Te, c->time_w2, Te, c->time_b2, nullptr, 0, c->emb, Te, S, Te, Te, ACT_NONE, s))) return r;
     if ((r = mc_launch_silu(c->emb, c->semb, (long)S * Te, s))) return r;
-    for (int i = 0; i < g.num_layers; ++i) {
+    for (int i = 0; i < c->NLA; ++i) {
         const LayerW& w = c->lw[i];
         float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS) * 2 * D;
         float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS) * 2 * D;
@@ -402,13 +495,48 @@ int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_d
     const long half = (long)c->B * Nt;
     c->mask = mask_dev;
     int r;
-    for (int i = 0; i < g.num_layers; ++i) {
+    for (int i = 0; i < c->NLA; ++i) {
         const LayerW& w = c->lw[i];
         if ((r = mc_launch_ln_rows(xf_out_dev, Dt, 0, w.tnorm_g, w.tnorm_b, w.tm.emb, Nt, c->xfn, Dt, half, Dt, s))) return r;
         MC_HIP(hipMemcpyAsync(c->xfn + half * Dt, c->xfn, sizeof(float) * half * Dt, hipMemcpyDeviceToDevice, s));
         if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, false, s))) return r;
     }
     c->have_cond = true;
+    return MC_OK;
+}
+
+// ControlT2MHalf.forward_c (controlnet.py:186-199) with condition_pre_encoder = identity, followed by
+// `c * all_cond_type` (controlnet.py:377-379) and controlnet[0].before_proj (controlnet.py:66): all
+// step-invariant, evaluated once per condition batch.
+int mc_ctx_set_control(mc_ctx* c, const float* c_feat_dev, int32_t Tc, void* stream) {
+    MC_REQUIRE(c, "null context");
+    const mc_model_config& g = c->m->cfg;
+    if (!c_feat_dev) { c->have_ctrl = false; return MC_OK; }
+    MC_REQUIRE(g.num_ctrl_layers > 0, "the model has no control branch");
+    MC_REQUIRE(Tc >= 1 && Tc <= c->T, "control length %d outside [1, %d]", Tc, c->T);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = g.latent_dim * g.num_parts, Fc = g.ctrl_cond_feats;
+    const long BT = (long)c->B * c->T;
+    int r;
+    MC_HIP(hipMemsetAsync(c->cenc, 0, sizeof(float) * BT * D, s));           // zero padding for t >= Tc
+    {
+        GemmArgs e;   // per sample: [Tc, Fc] x [D, Fc]^T + bias + sequence_embedding[:Tc]
+        e.A = c_feat_dev; e.lda = Fc; e.a_gstride = (long)Tc * Fc;
+        e.W = c->ctrl_in_w; e.ldw = (Fc + 3) / 4 * 4; e.bias = c->ctrl_in_b;
+        e.add = c->seq_emb; e.add_mod = Tc; e.ld_add = D;
+        e.C = c->cenc; e.ldc = D; e.c_gstride = (long)c->T * D; e.dup_rows = 0;
+        e.M = Tc; e.N = D; e.K = Fc;
+        if ((r = mc_launch_gemm(GM_ENC, e, c->B, 0, s))) return r;
+    }
+    const LayerW& w0 = c->lw[g.num_layers];
+    // text-conditioned half: before_proj(c); unconditional half: before_proj(c * 0) = bias when condition_cfg
+    if ((r = dense(c->cenc, D, w0.before_w, D, w0.before_b, nullptr, 0, c->cb, D, BT, D, D, ACT_NONE, s))) return r;
+    if (g.ctrl_condition_cfg) {
+        if ((r = mc_launch_add_rows(c->cb + BT * D, nullptr, nullptr, w0.before_b, BT, D, s))) return r;
+    } else {
+        MC_HIP(hipMemcpyAsync(c->cb + BT * D, c->cb, sizeof(float) * BT * D, hipMemcpyDeviceToDevice, s));
+    }
+    c->have_ctrl = true;
     return MC_OK;
 }
 
@@ -433,64 +561,20 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
         if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
+    const int NC = c->have_ctrl ? g.num_ctrl_layers : 0;
     for (int i = 0; i < nl; ++i) {
-        const LayerW& w = c->lw[i];
-        // ---- STMA ----
-        const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
-        if (fused_gate) {
-            GateArgs ga;
-            ga.X = c->h; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
-            ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
-            ga.N = c->N; ga.E = g.num_experts; ga.L = L;
-            ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
-            if ((r = mc_launch_gate(ga, s))) return r;
-        } else {
-            if ((r = mc_launch_ln_rows(c->h, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
+        // ControlT2MHalf.forward_test (controlnet.py:372-413): base block 0, then for index 1..copy:
+        //   c, c_skip = controlnet[index-1](x=h, c=c);  h = base[index](h + c_skip)
+        if (i >= 1 && i <= NC) {
+            const int j = i - 1, slot = g.num_layers + j;
+            if (j == 0) {
+                if ((r = mc_launch_add_rows(c->hc, c->h, c->cb, nullptr, c->rows, D, s))) return r;   // x + before_proj(c)
+            }
+            if ((r = run_layer(c, slot, c->hc, step, s))) return r;                                     // copied_block
+            const LayerW& cw = c->lw[slot];
+            if ((r = dense(c->hc, D, cw.after_w, D, cw.after_b, c->h, D, c->h, D, c->rows, D, D, ACT_NONE, s))) return r;  // h += after_proj(c)
         }
-        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, fused_gate, s))) return r;
-        if (c->cap_idx) {
-            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
-            MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
-        }
-        if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
-            RowChainArgs q;
-            q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
-            q.Y = c->qkv; q.ldy = 3 * L; q.N = c->N; q.L = L; q.Nout = 3 * L;
-            if ((r = mc_launch_rowchain(1, q, s))) return r;
-        } else {
-            if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
-            if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
-        }
-        if ((r = mc_launch_body(c->mf, 4 * L, c->qkv, w.wsm, c->ys, c->rows, H, L, g.dyn_heads, s))) return r;
-        if ((r = mc_launch_temporal(c->mf, c->tf + (long)i * c->Ntxt * 2 * L, c->mask, c->yt, 2 * c->B, c->B, c->T,
-                                    g.max_text_len, H, L, s))) return r;
-        const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
-        if ((r = film_block(c, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, s))) return r;
-        // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
-        if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
-            MlpArgs m;
-            m.X = c->h; m.ldx = D; m.x_gstride = L;
-            m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
-            m.Y = c->z2; m.ldy = D; m.y_gstride = L; m.M = (int)c->rows; m.L = L; m.hidden = F;
-            if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
-        } else {
-            GemmArgs f1;
-            f1.A = c->h; f1.lda = D; f1.a_gstride = L;
-            f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
-            f1.bias = w.ffn_b1; f1.b_gstride = F; f1.act = ACT_GELU;
-            f1.C = c->fh; f1.ldc = (long)H * F; f1.c_gstride = F;
-            f1.M = (int)c->rows; f1.N = F; f1.K = L;
-            if ((r = mc_launch_gemm(GM_PLAIN, f1, H, 0, s))) return r;
-            GemmArgs f2;
-            f2.A = c->fh; f2.lda = (long)H * F; f2.a_gstride = F;
-            f2.W = w.ffn_w2; f2.ldw = F; f2.w_gstride = (long)L * F;
-            f2.bias = w.ffn_b2; f2.b_gstride = L;
-            f2.C = c->z2; f2.ldc = D; f2.c_gstride = L;
-            f2.M = (int)c->rows; f2.N = L; f2.K = F;
-            if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
-        }
-        const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
-        if ((r = film_block(c, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, s))) return r;
+        if ((r = run_layer(c, i, c->h, step, s))) return r;
     }
     if (stop_after >= 0) return MC_OK;
     // PoseDecoder as one dense [D -> C] GEMM (stmogen.py:505-544), /2 folded into the packed weight
@@ -539,6 +623,8 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
     else if (n == "gate") { p = c->rb.gate; cnt = 2 * c->N; }
     else if (n == "comb_w") { p = c->rb.comb_w; cnt = 2 * c->N; }
     else if (n == "key") { p = c->rb.key; cnt = c->N; }
+    else if (n == "hc" && c->hc) { p = c->hc; cnt = c->rows * D; }
+    else if (n == "cb" && c->cb) { p = c->cb; cnt = c->rows * D; }
     else if (n == "cap_idx" && c->cap_idx) { p = c->cap_idx + (long)layer * 2 * c->N; cnt = 2 * c->N; }
     else if (n == "cap_w" && c->cap_w) { p = c->cap_w + (long)layer * 2 * c->N; cnt = 2 * c->N; }
     else { mc_set_error("unknown buffer '%s'", name); return MC_ERR_ARG; }

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .weights import pack_state_dict
+from .weights import control_info, pack_state_dict
 
 
 def _ptr(t):
@@ -28,17 +28,21 @@ def _dev_f32(t, name):
 
 
 class NativeModel:
-    def __init__(self, dims, state_dict, cfg_scale=6.5, capacity_factor=1.5, dyn_heads=8, device=None):
+    def __init__(self, dims, state_dict, cfg_scale=6.5, capacity_factor=1.5, dyn_heads=8, device=None,
+                 condition_cfg=True):
         self.lib = _lib.load(require_gpu=True)
         if device is not None:
             torch.cuda.set_device(device)
             _lib.check(self.lib.mc_set_device(torch.cuda.current_device()), 'mc_set_device')
         self.dims = dict(dims)
+        self.copy_blocks_num, self.control_cond_feats = control_info(state_dict)
         cfg = _lib.ModelConfig(
             input_feats=dims['input_feats'], max_seq_len=dims['max_seq_len'], latent_dim=dims['L'],
             num_parts=dims['H'], num_layers=dims['NL'], ffn_dim=dims['F'], time_embed_dim=dims['Te'],
             text_latent_dim=dims['Dt'], max_text_len=dims['Nt'], num_experts=dims['E'], topk=dims.get('topk', 2),
-            dyn_heads=dyn_heads, capacity_factor=capacity_factor, cfg_scale=cfg_scale)
+            dyn_heads=dyn_heads, capacity_factor=capacity_factor, cfg_scale=cfg_scale,
+            num_ctrl_layers=self.copy_blocks_num, ctrl_cond_feats=self.control_cond_feats,
+            ctrl_condition_cfg=int(bool(condition_cfg)))
         self.cfg_scale = float(cfg_scale)
         h = ctypes.c_void_p()
         _lib.check(self.lib.mc_model_create(ctypes.byref(cfg), ctypes.byref(h)), 'mc_model_create')
@@ -104,6 +108,17 @@ class NativeContext:
             raise ValueError(f'motion_mask has {mask.numel()} elements, expected {self.B * self.T}')
         self._keep = [xf, mask]        # the library reads the mask every step: keep it alive
         _lib.check(self.lib.mc_ctx_set_condition(self.handle, _ptr(xf), _ptr(mask), _stream()), 'mc_ctx_set_condition')
+
+    def set_control(self, c_feat):
+        """c_feat [B, Tc, control_cond_feats] (output of the step-invariant condition pre-encoder) or None."""
+        if c_feat is None:
+            _lib.check(self.lib.mc_ctx_set_control(self.handle, None, 0, _stream()), 'mc_ctx_set_control')
+            return
+        c = _dev_f32(c_feat, 'c')
+        if c.dim() != 3 or c.shape[0] != self.B or c.shape[2] != self.model.control_cond_feats:
+            raise ValueError(f'c shape {tuple(c.shape)} != (B={self.B}, Tc, {self.model.control_cond_feats})')
+        self._keep_c = c
+        _lib.check(self.lib.mc_ctx_set_control(self.handle, _ptr(c), int(c.shape[1]), _stream()), 'mc_ctx_set_control')
 
     def denoise(self, x_t, step_index, out2=None, stop_after_layers=-1):
         x = _dev_f32(x_t, 'x_t')

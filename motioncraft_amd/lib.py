@@ -18,7 +18,8 @@ class ModelConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'input_feats', 'max_seq_len', 'latent_dim', 'num_parts', 'num_layers', 'ffn_dim',
         'time_embed_dim', 'text_latent_dim', 'max_text_len', 'num_experts', 'topk', 'dyn_heads')] + [
-        ('capacity_factor', ctypes.c_float), ('cfg_scale', ctypes.c_float)]
+        ('capacity_factor', ctypes.c_float), ('cfg_scale', ctypes.c_float),
+        ('num_ctrl_layers', ctypes.c_int32), ('ctrl_cond_feats', ctypes.c_int32), ('ctrl_condition_cfg', ctypes.c_int32)]
 
 
 class StepCoefs(ctypes.Structure):
@@ -42,6 +43,7 @@ _SIGNATURES = {
     'mc_ctx_enable_capture': (ctypes.c_int, [_P]),
     'mc_ctx_set_timesteps': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, _P]),
     'mc_ctx_set_condition': (ctypes.c_int, [_P, _P, _P, _P]),
+    'mc_ctx_set_control': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'mc_denoise': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
     'mc_sample_step': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, _P, _P, _P]),
     'mc_ctx_get_buffer': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P),

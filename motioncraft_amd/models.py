@@ -78,6 +78,7 @@ class STMoGenTransformer:
         self._native = None
         self._ctx = {}
         self._state = None
+        self._control = None            # set by ControlT2MHalf: dict(copy_blocks_num, cond_feats, condition_cfg, pre_encode)
 
     # ---- nn.Module-ish surface used by the tools ---------------------------------------------
     def eval(self):
@@ -119,8 +120,23 @@ class STMoGenTransformer:
         if self._native is None:
             if self._state is None:
                 raise RuntimeError('load_state_dict() has not been called: no weights to run')
-            self._native = NativeModel(self.dims, self._state, cfg_scale=self.cfg_scale)
+            ccfg = True if not self._control else self._control['condition_cfg']
+            self._native = NativeModel(self.dims, self._state, cfg_scale=self.cfg_scale, condition_cfg=ccfg)
+            if self._control and self._native.copy_blocks_num != self._control['copy_blocks_num']:
+                raise RuntimeError(f"checkpoint has {self._native.copy_blocks_num} control blocks, the wrapper expects "
+                                   f"{self._control['copy_blocks_num']}")
         return self._native
+
+    def _encode_control(self, c, dev):
+        """The step-invariant condition pre-encoder sits before the path (WavEncoder for BEAT2 audio,
+        identity for FineDance music features): the library consumes its OUTPUT."""
+        c = c.to(device=dev, dtype=torch.float32).contiguous()
+        want = self.native.control_cond_feats
+        if c.dim() != 3 or c.shape[-1] != want:
+            raise NotImplementedError(
+                f'control condition of shape {tuple(c.shape)}: expected [B, Tc, {want}] = the output of the condition '
+                'pre-encoder (raw audio needs the reference WavEncoder first; SURVEY.md section 8f.2)')
+        return c
 
     def sampling_context(self, B, T, timestep_map, model_kwargs, device=None):
         """Context with FiLM tables for ``timestep_map`` and text K/V for ``model_kwargs['xf_out']``."""
@@ -134,8 +150,10 @@ class STMoGenTransformer:
             self._ctx[key] = ctx
         if ctx.timesteps != [int(t) for t in timestep_map]:
             ctx.set_timesteps(timestep_map)
-        if model_kwargs.get('c', None) is not None:
-            raise NotImplementedError('control-branch condition `c` needs ControlT2MHalf (SURVEY.md a15)')
+        c = model_kwargs.get('c', None)
+        if c is not None and not self._control:
+            raise ValueError('a control condition `c` was given but the model has no control branch: wrap it with '
+                             'ControlT2MHalf and load a checkpoint that has controlnet.* weights')
         xf = model_kwargs.get('xf_out', None)
         if xf is None:
             raise ValueError("model_kwargs['xf_out'] is required (see get_precompute_condition)")
@@ -146,6 +164,8 @@ class STMoGenTransformer:
         xf = xf.to(device=dev, dtype=torch.float32).contiguous()
         mask = mask.to(device=dev, dtype=torch.float32).reshape(B, T).contiguous()
         ctx.set_condition(xf, mask)
+        if self._control:
+            ctx.set_control(None if c is None else self._encode_control(c, dev))
         return ctx
 
     # ---- reference API ----------------------------------------------------------------------------
@@ -183,6 +203,73 @@ class STMoGenTransformer:
         out2 = ctx.denoise(motion.to(device=dev, dtype=torch.float32).contiguous(), 0)
         c = self.scale_func(t)
         return out2[:B] * c['text_coef'] + out2[B:] * c['none_coef']
+
+    __call__ = forward
+
+
+class ControlT2MHalf:
+    """Mirror of the reference's plug-and-play control wrapper (controlnet.py:107-439):
+    ``model.model = ControlT2MHalf(model.model, copy_blocks_num, control_cond_feats, cfg)`` as in
+    tools/s2g_test.py:592-601 and tools/m2d_test.py:372-381.  The copied DecoderLayers, the zero-init
+    before/after projections and ``control_cond_input`` run inside the library; the condition
+    pre-encoder (WavEncoder) is step-invariant and stays outside the per-step path."""
+
+    def __init__(self, base_model, copy_blocks_num=2, control_cond_feats=438, cfg=None, joint_embed_unfreeze=True,
+                 unfreeze_mode='all'):
+        if not isinstance(base_model, STMoGenTransformer):
+            raise TypeError('base_model must be the STMoGenTransformer built from the config')
+        cfg = cfg if cfg is not None else {}
+        ce = cfg['condition_encode_cfg'] if 'condition_encode_cfg' in cfg else {}
+        if cfg.get('patch_size', 1) != 1:
+            raise NotImplementedError('patch_size > 1 is not used by the shipped configs')
+        if not (1 <= copy_blocks_num < base_model.num_layers):
+            raise ValueError('copy_blocks_num must be in [1, num_layers)')
+        self.base_model = base_model
+        self.copy_blocks_num = copy_blocks_num
+        pre = bool(ce.get('condition_pre_encode', False))
+        feats = ce.get('condition_latent_dim', base_model.latent_dim) if pre else control_cond_feats
+        base_model._control = dict(copy_blocks_num=copy_blocks_num, cond_feats=feats,
+                                   condition_cfg=bool(ce.get('condition_cfg', False)), pre_encode=pre)
+        self.cfg = cfg
+        self.training = False
+
+    # delegate the sampler-facing surface
+    cfg_scale = property(lambda self: self.base_model.cfg_scale)
+    dims = property(lambda self: self.base_model.dims)
+
+    def sampling_context(self, *a, **k):
+        return self.base_model.sampling_context(*a, **k)
+
+    def get_precompute_condition(self, **kwargs):
+        return self.base_model.get_precompute_condition(**kwargs)
+
+    def post_process(self, output):
+        return self.base_model.post_process(output)
+
+    def load_state_dict(self, state_dict, strict=True):
+        self.base_model.load_state_dict(state_dict, strict=strict)
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('training is outside the MI355X sampling path')
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def release(self):
+        self.base_model.release()
+
+    def forward(self, motion, timesteps, motion_mask=None, motion_length=None, num_intervals=1, c=None, **kwargs):
+        return self.base_model.forward(motion, timesteps, motion_mask=motion_mask, motion_length=motion_length,
+                                       num_intervals=num_intervals, c=c, **kwargs)
 
     __call__ = forward
 

@@ -117,6 +117,28 @@ def param_shapes(dims):
     return s
 
 
+def control_param_shapes(dims, copy_blocks_num, cond_feats):
+    """Extra state-dict entries of ``ControlT2MHalf`` (reference controlnet.py:107-183) for the
+    ``condition_pre_encode=False`` form (pre-encoded / raw feature condition of width ``cond_feats``).
+    Key names are relative to the wrapper: base keys move under ``base_model.``."""
+    base = param_shapes(dims)
+    D = dims['L'] * dims['H']
+    s = OrderedDict(('base_model.' + k, v) for k, v in base.items())
+    for j in range(copy_blocks_num):
+        for k, v in base.items():
+            pre = 'temporal_decoder_blocks.0.'
+            if k.startswith(pre):
+                s[f'controlnet.{j}.copied_block.' + k[len(pre):]] = v
+        if j == 0:
+            s['controlnet.0.before_proj.weight'] = (D, D)
+            s['controlnet.0.before_proj.bias'] = (D,)
+        s[f'controlnet.{j}.after_proj.weight'] = (D, D)
+        s[f'controlnet.{j}.after_proj.bias'] = (D,)
+    s['control_cond_input.weight'] = (D, cond_feats)
+    s['control_cond_input.bias'] = (D,)
+    return s
+
+
 def _randn(seed, name, shape):
     g = torch.Generator(device='cpu')
     g.manual_seed(zlib.crc32(f'{seed}:{name}'.encode()) & 0x7FFFFFFF)
@@ -143,7 +165,7 @@ def make_param(seed, name, shape):
         if '.norm.' in name or 'text_norm' in name:
             return 1.0 + 0.1 * r
         scale = 1.0 / math.sqrt(shape[1])
-        if 'out_layers.2' in name:                           # zero_module() in the reference
+        if 'out_layers.2' in name or 'after_proj' in name or 'before_proj' in name:   # zero-init in the reference
             scale *= 0.5
         return scale * r
     raise KeyError(name)

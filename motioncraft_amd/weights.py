@@ -16,12 +16,15 @@ from .synthetic import PART_NAMES, smplx_part_slices  # 322-d motionx part layou
 
 
 def strip_prefix(state_dict):
+    """Normalise checkpoint key names: drop the ``model.`` attribute prefix of ``MotionDiffusion``
+    (diffusion_architecture.py:83) and the ``base_model.`` prefix a ``ControlT2MHalf`` wrapper adds
+    (controlnet.py:427-439); ``controlnet.*`` / ``control_cond_input.*`` keys are kept as they are."""
     out = {}
     for k, v in state_dict.items():
-        for pre in ('model.base_model.', 'model.'):
-            if k.startswith(pre):
-                k = k[len(pre):]
-                break
+        if k.startswith('model.'):
+            k = k[len('model.'):]
+        if k.startswith('base_model.'):
+            k = k[len('base_model.'):]
         out[k] = v
     return out
 
@@ -47,6 +50,39 @@ def pack_moe(sd, pre, out, key):
     out[key + 'fc2_b'] = _f(sd[m + 'experts.batched_fc2_bias'])
     out[key + 'proj_w'] = _f(sd[pre + 'proj.weight'])
     out[key + 'proj_b'] = _f(sd[pre + 'proj.bias'])
+
+
+def pack_layer(sd, src, out, k, H):
+    """One DecoderLayer (STMA ca_block + SFFN ffn) -> packed entries with prefix `k`."""
+    ca, ff = src + 'ca_block.', src + 'ffn.'
+    out[k + 'norm.g'], out[k + 'norm.b'] = _f(sd[ca + 'norm.weight']), _f(sd[ca + 'norm.bias'])
+    out[k + 'text_norm.g'], out[k + 'text_norm.b'] = _f(sd[ca + 'text_norm.weight']), _f(sd[ca + 'text_norm.bias'])
+    out[k + 'body_wsm'] = _f(torch.softmax(sd[ca + 'body_weight'].float(), dim=1))
+    pack_moe(sd, ca + 'motion_moe.', out, k + 'mm.')
+    pack_moe(sd, ca + 'text_moe.', out, k + 'tm.')
+    out[k + 'dyn.norm.g'] = _f(sd[ca + 'body_d_attn.norm.weight'])
+    out[k + 'dyn.norm.b'] = _f(sd[ca + 'body_d_attn.norm.bias'])
+    out[k + 'dyn.qkv_w'] = _f(torch.cat([sd[ca + f'body_d_attn.{n}.weight'] for n in ('query', 'key', 'value')], 0))
+    out[k + 'dyn.qkv_b'] = _f(torch.cat([sd[ca + f'body_d_attn.{n}.bias'] for n in ('query', 'key', 'value')], 0))
+    for blk, s_ in (('ca.', ca + 'proj_out.'), ('ffn.', ff + 'proj_out.')):
+        out[k + blk + 'film_w'] = _f(sd[s_ + 'emb_layers.1.weight'])
+        out[k + blk + 'film_b'] = _f(sd[s_ + 'emb_layers.1.bias'])
+        out[k + blk + 'ln_g'], out[k + blk + 'ln_b'] = _f(sd[s_ + 'norm.weight']), _f(sd[s_ + 'norm.bias'])
+        out[k + blk + 'out_w'] = _f(sd[s_ + 'out_layers.2.weight'])
+        out[k + blk + 'out_b'] = _f(sd[s_ + 'out_layers.2.bias'])
+    out[k + 'ffn.w1'] = _f(torch.stack([sd[ff + f'linear1_list.{p}.weight'] for p in range(H)]))   # [H, F, L]
+    out[k + 'ffn.b1'] = _f(torch.stack([sd[ff + f'linear1_list.{p}.bias'] for p in range(H)]))
+    out[k + 'ffn.w2'] = _f(torch.stack([sd[ff + f'linear2_list.{p}.weight'] for p in range(H)]))   # [H, L, F]
+    out[k + 'ffn.b2'] = _f(torch.stack([sd[ff + f'linear2_list.{p}.bias'] for p in range(H)]))
+
+
+def control_info(state_dict):
+    """(copy_blocks_num, control_cond_feats) found in a (possibly prefixed) state dict; (0, 0) if none."""
+    sd = strip_prefix(state_dict)
+    n = 0
+    while f'controlnet.{n}.after_proj.weight' in sd:
+        n += 1
+    return (n, int(sd['control_cond_input.weight'].shape[1])) if n else (0, 0)
 
 
 def pack_state_dict(state_dict, dims):
@@ -84,26 +120,22 @@ def pack_state_dict(state_dict, dims):
     out['dec.w'], out['dec.b'] = _f(dec_w), _f(dec_b)
 
     for i in range(NL):
-        ca = f'temporal_decoder_blocks.{i}.ca_block.'
-        ff = f'temporal_decoder_blocks.{i}.ffn.'
-        k = f'l{i}.'
-        out[k + 'norm.g'], out[k + 'norm.b'] = _f(sd[ca + 'norm.weight']), _f(sd[ca + 'norm.bias'])
-        out[k + 'text_norm.g'], out[k + 'text_norm.b'] = _f(sd[ca + 'text_norm.weight']), _f(sd[ca + 'text_norm.bias'])
-        out[k + 'body_wsm'] = _f(torch.softmax(sd[ca + 'body_weight'].float(), dim=1))
-        pack_moe(sd, ca + 'motion_moe.', out, k + 'mm.')
-        pack_moe(sd, ca + 'text_moe.', out, k + 'tm.')
-        out[k + 'dyn.norm.g'] = _f(sd[ca + 'body_d_attn.norm.weight'])
-        out[k + 'dyn.norm.b'] = _f(sd[ca + 'body_d_attn.norm.bias'])
-        out[k + 'dyn.qkv_w'] = _f(torch.cat([sd[ca + f'body_d_attn.{n}.weight'] for n in ('query', 'key', 'value')], 0))
-        out[k + 'dyn.qkv_b'] = _f(torch.cat([sd[ca + f'body_d_attn.{n}.bias'] for n in ('query', 'key', 'value')], 0))
-        for blk, src in (('ca.', ca + 'proj_out.'), ('ffn.', ff + 'proj_out.')):
-            out[k + blk + 'film_w'] = _f(sd[src + 'emb_layers.1.weight'])
-            out[k + blk + 'film_b'] = _f(sd[src + 'emb_layers.1.bias'])
-            out[k + blk + 'ln_g'], out[k + blk + 'ln_b'] = _f(sd[src + 'norm.weight']), _f(sd[src + 'norm.bias'])
-            out[k + blk + 'out_w'] = _f(sd[src + 'out_layers.2.weight'])
-            out[k + blk + 'out_b'] = _f(sd[src + 'out_layers.2.bias'])
-        out[k + 'ffn.w1'] = _f(torch.stack([sd[ff + f'linear1_list.{p}.weight'] for p in range(H)]))   # [H, F, L]
-        out[k + 'ffn.b1'] = _f(torch.stack([sd[ff + f'linear1_list.{p}.bias'] for p in range(H)]))
-        out[k + 'ffn.w2'] = _f(torch.stack([sd[ff + f'linear2_list.{p}.weight'] for p in range(H)]))   # [H, L, F]
-        out[k + 'ffn.b2'] = _f(torch.stack([sd[ff + f'linear2_list.{p}.bias'] for p in range(H)]))
+        pack_layer(sd, f'temporal_decoder_blocks.{i}.', out, f'l{i}.', H)
+    # plug-and-play control branch (ControlT2MHalf, controlnet.py:107-183)
+    ncopy = 0
+    while f'controlnet.{ncopy}.after_proj.weight' in sd:
+        ncopy += 1
+    for j in range(ncopy):
+        pack_layer(sd, f'controlnet.{j}.copied_block.', out, f'c{j}.', H)
+        if j == 0:
+            out['c0.before_w'] = _f(sd['controlnet.0.before_proj.weight'])
+            out['c0.before_b'] = _f(sd['controlnet.0.before_proj.bias'])
+        out[f'c{j}.after_w'] = _f(sd[f'controlnet.{j}.after_proj.weight'])
+        out[f'c{j}.after_b'] = _f(sd[f'controlnet.{j}.after_proj.bias'])
+    if ncopy:
+        w = sd['control_cond_input.weight'].float()                      # [D, Fc] -> rows padded to a multiple of 4
+        fc = w.shape[1]
+        wp = torch.zeros(w.shape[0], (fc + 3) // 4 * 4)
+        wp[:, :fc] = w
+        out['ctrl_in.w'], out['ctrl_in.b'] = _f(wp), _f(sd['control_cond_input.bias'])
     return out

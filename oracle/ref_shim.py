@@ -138,6 +138,26 @@ def build_reference_denoiser(model_cfg):
     return m
 
 
+def build_reference_control(model_cfg, copy_blocks_num, control_cond_feats, condition_cfg=True):
+    """ControlT2MHalf around a reference base model, condition_pre_encode=False."""
+    import torch.nn as _nn
+    install()
+    ctl = importlib.import_module('mogen.models.transformers.controlnet')
+    base = build_reference_denoiser(model_cfg)
+    for n in ('clip', 'text_pre_proj', 'textTransEncoder', 'text_ln'):
+        setattr(base, n, _nn.Identity())
+
+    class _Cfg(dict):
+        __getattr__ = dict.__getitem__
+    mcfg = _Cfg(model=_Cfg(model=_Cfg({k: v for k, v in dict(model_cfg).items()})),
+                condition_encode_cfg=_Cfg(dataset_name='nothing', condition_pre_encode=False,
+                                          condition_pre_encode_type='nothing', control_cond_feats=control_cond_feats,
+                                          condition_latent_dim=model_cfg['latent_dim'], condition_cfg=condition_cfg))
+    m = ctl.ControlT2MHalf(base, copy_blocks_num=copy_blocks_num, control_cond_feats=control_cond_feats, cfg=mcfg)
+    m.eval()
+    return m
+
+
 def build_reference_diffusion(diffusion_cfg, opt=None):
     """build_diffusion (diffusion_architecture.py:25-54) without importing that module
     (its import chain needs pytorch3d/librosa through utils/vis.py)."""

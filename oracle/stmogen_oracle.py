@@ -207,6 +207,62 @@ def precompute_text(p, xf_out, dims):
     return [text_kv(p, f'temporal_decoder_blocks.{i}.ca_block.', xf2, dims) for i in range(dims['NL'])]
 
 
+def control_forward_c(p, c, T):
+    """ControlT2MHalf.forward_c (controlnet.py:186-199), condition_pre_encoder == identity:
+    control_cond_input -> zero-pad to T frames -> + sequence_embedding on the first Tc frames."""
+    c = F.linear(c, p['control_cond_input.weight'], p['control_cond_input.bias'])
+    B, Tc, D = c.shape
+    c_new = torch.cat([c, torch.zeros(B, T - Tc, D, dtype=c.dtype)], dim=-2)
+    c_new[:, :Tc] = c_new[:, :Tc] + p['base_model.sequence_embedding'].unsqueeze(0)[:, :Tc]
+    return c_new
+
+
+def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_num, condition_cfg=True, cap=None):
+    """ControlT2MHalf.forward + forward_test (controlnet.py:201-266, 340-424) with a condition `c`
+    [B, Tc, cond_feats]; `p` uses the wrapper's key names (base_model.* / controlnet.* / control_cond_input.*)."""
+    B, T, C = x_t.shape
+    L, H, NL = dims['L'], dims['H'], dims['NL']
+    D = L * H
+    pb = {k[len('base_model.'):]: v for k, v in p.items() if k.startswith('base_model.')}
+    ts = torch.full((B,), int(t_orig), dtype=torch.long)
+    emb = time_embed(pb, ts, D)
+    h = pose_encoder(pb, x_t)
+    cc = control_forward_c(p, c, T)
+    h = h + pb['sequence_embedding'].unsqueeze(0)[:, :T, :]
+    cond = torch.cat((torch.ones(B, 1, 1), torch.zeros(B, 1, 1)), dim=0)
+    h = h.repeat(2, 1, 1)
+    xf2, emb2 = xf_out.repeat(2, 1, 1), emb.repeat(2, 1)
+    mask2 = motion_mask.reshape(B, T).repeat(2, 1)
+
+    def layer(pp, pre, x):
+        x = stma(pp, pre + 'ca_block.', x, xf2, emb2, mask2, cond, dims)
+        return sffn(pp, pre + 'ffn.', x, emb2, dims)
+
+    h = layer(pb, 'temporal_decoder_blocks.0.', h)
+    cc = cc.repeat(2, 1, 1)
+    if condition_cfg:
+        cc = cc * cond
+    for index in range(1, copy_blocks_num + 1):
+        j = index - 1
+        pre = f'controlnet.{j}.'
+        if j == 0:                                                      # ControlT2MBlock.forward (controlnet.py:53-88)
+            cc = F.linear(cc, p[pre + 'before_proj.weight'], p[pre + 'before_proj.bias'])
+            cc = layer(p, pre + 'copied_block.', h + cc)
+        else:
+            cc = layer(p, pre + 'copied_block.', cc)
+        c_skip = F.linear(cc, p[pre + 'after_proj.weight'], p[pre + 'after_proj.bias'])
+        if cap is not None:
+            cap[f'c_skip{j}'] = c_skip
+        h = layer(pb, f'temporal_decoder_blocks.{index}.', h + c_skip)
+    for index in range(copy_blocks_num + 1, NL):
+        h = layer(pb, f'temporal_decoder_blocks.{index}.', h)
+    out = pose_decoder(pb, h, L, C).view(2 * B, T, -1)
+    if cap is not None:
+        cap['out2'] = out
+    w = (1 - (1000 - int(t_orig)) / 1000) * dims['scale'] + 1
+    return out[:B] * w + out[B:] * (1 - w)
+
+
 def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None, forced_routing=None):
     """mogen/models/transformers/diffusion_transformer.py:186-238 + stmogen.py:725-761.
     x_t [B,T,C]; t_orig: int original (un-spaced) timestep, identical for the batch;

@@ -20,6 +20,7 @@ Fixtures
                         call at t=777 with per-layer intermediates captured by hooks
   small_ddim.npz        reduced config: 50-step DDIM trajectory (every 10th x_t) + final
   small_ddpm.npz        reduced config: 1000-step schedule, first 20 DDPM steps
+  control_small.npz     ControlT2MHalf (copy_blocks_num=2, 35-d condition of 20 frames, NL=3): x0 at t=640, 3
   full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
   full_ddim.npz         0.125b config, B=1: final sample of the 50-step DDIM loop
 """
@@ -40,6 +41,8 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 SMALL = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
 FULL = W.default_dims()
+CTRL = W.default_dims(max_seq_len=24, L=32, NL=3, F=64, Te=64, Dt=32, Nt=8)   # control-branch fixture: copy_blocks_num=2
+CTRL_COPY, CTRL_FEATS, CTRL_TC = 2, 35, 20
 SMALL_SEED = 2   # weight seed whose routing overflows the expert capacity in both layers (drops are exercised)
 DIFF_DDIM = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
                  model_var_type='fixed_large', respace='15,15,8,6,6')
@@ -211,6 +214,38 @@ def small_loops():
                         traj=np.stack([t.numpy() for t in tr[4::5]]))
 
 
+def control():
+    """Plug-and-play control branch (a15): reference ControlT2MHalf, condition_pre_encode=False (M2D form:
+    raw 35-d music features), condition shorter than the motion (zero padding), condition_cfg=True."""
+    dims, B, T = CTRL, 2, 24
+    m = ref_shim.build_reference_control(W.reference_model_cfg(dims), CTRL_COPY, CTRL_FEATS)
+    shapes = W.control_param_shapes(dims, CTRL_COPY, CTRL_FEATS)
+    assert set(m.state_dict().keys()) == set(shapes.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sd = W.make_state_dict(dims, SMALL_SEED, shapes=shapes)
+    torch.nn.Module.load_state_dict(m, sd)        # (the wrapper's own load_state_dict override re-keys base-only checkpoints)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=13, lengths=[24, 18])
+    g = torch.Generator().manual_seed(14)
+    c = torch.randn(B, CTRL_TC, CTRL_FEATS, generator=g)
+    save = dict(x_t=x_T.numpy(), xf_out=xf.numpy(), motion_mask=mask.numpy(), c=c.numpy())
+    for t in (640, 3):
+        with torch.no_grad():
+            ref = m(x_T, torch.full((B,), t), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+                    num_intervals=1, c=c, xf_out=xf, y={}, patch_size=1, sample_idx=None)
+            ref_noc = m(x_T, torch.full((B,), t), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+                        num_intervals=1, c=None, xf_out=xf, y={}, patch_size=1, sample_idx=None)
+        out = O.denoise_control(sd, dims, x_T, t, xf, mask, c, CTRL_COPY)
+        pb = {k[len('base_model.'):]: v for k, v in sd.items() if k.startswith('base_model.')}
+        out_noc = O.denoise(pb, dims, x_T, t, xf, mask)
+        print(f'control t={t}: oracle vs reference {maxabs(ref, out):.2e} (c=None: {maxabs(ref_noc, out_noc):.2e}); '
+              f'|with c - without c| max {maxabs(ref, ref_noc):.2f}')
+        assert maxabs(ref, out) <= 1e-5 and maxabs(ref_noc, out_noc) <= 1e-5
+        save[f'x0_t{t}'] = ref.numpy()
+        save[f'x0_noc_t{t}'] = ref_noc.numpy()
+    np.savez_compressed(os.path.join(OUT, 'control_small.npz'), **save)
+
+
 def full():
     dims, B, T = FULL, 1, 196
     t0 = time.time()
@@ -259,6 +294,7 @@ if __name__ == '__main__':
     schedules()
     small_modules()
     small_loops()
+    control()
     if not a.skip_full:
         full()
     print('golden fixtures written to', OUT)

@@ -10,6 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 SMALL = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
 FULL = W.default_dims()
 SMALL_SEED = 2
+CTRL = W.default_dims(max_seq_len=24, L=32, NL=3, F=64, Te=64, Dt=32, Nt=8)
+CTRL_COPY, CTRL_FEATS, CTRL_TC = 2, 35, 20
 
 
 def synth_inputs(dims, B, T, seed, lengths=None):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FULL, SMALL, SMALL_SEED, load, step_noise_from_seed, synth_inputs
+from helpers import CTRL, CTRL_COPY, CTRL_FEATS, FULL, SMALL, SMALL_SEED, load, step_noise_from_seed, synth_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -313,3 +313,30 @@ def test_baseline_batch_64_single_step_vs_oracle(full_model):
         print(f'layer {i}: dropped {dropped}, expert-id flips {idx_diff}, keep flips {keep_diff} of {npairs} pairs')
         assert idx_diff <= 1e-4 * npairs and keep_diff <= max(8, 0.02 * dropped)
     ctx.close()
+
+
+def test_control_branch_vs_reference_golden():
+    """ControlT2MHalf (a15; BASELINE configs 3-5 form): copied DecoderLayers + zero-init projections + condition
+    padding/CFG masking, through the reference-style wrapper API and through the raw context."""
+    import motioncraft_amd as mc
+    from oracle import weights as W
+    g = load('control_small.npz')
+    sd = W.make_state_dict(CTRL, SMALL_SEED, shapes=W.control_param_shapes(CTRL, CTRL_COPY, CTRL_FEATS))
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    cfg.model.model.num_layers = 3
+    cfg.merge_from_dict({'condition_encode_cfg': dict(dataset_name='nothing', condition_pre_encode=False,
+                                                      condition_pre_encode_type='nothing', control_cond_feats=CTRL_FEATS,
+                                                      condition_latent_dim=CTRL['L'] * CTRL['H'], condition_cfg=True)})
+    arch = mc.build_architecture(cfg.model)
+    arch.model = mc.ControlT2MHalf(arch.model, copy_blocks_num=CTRL_COPY, control_cond_feats=CTRL_FEATS, cfg=cfg)
+    arch.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    x_t, xf, mask, c = (T_(g[k]) for k in ('x_t', 'xf_out', 'motion_mask', 'c'))
+    for t in (640, 3):
+        ts = torch.full((2,), t)
+        x0 = arch.model(x_t, ts, motion_mask=mask, xf_out=xf, c=c)
+        assert maxabs(x0, T_(g[f'x0_t{t}'])) <= TOL_STEP, t
+        x0n = arch.model(x_t, ts, motion_mask=mask, xf_out=xf, c=None)        # forward_test with c=None
+        assert maxabs(x0n, T_(g[f'x0_noc_t{t}'])) <= TOL_STEP, t
+    with pytest.raises(NotImplementedError):                                  # raw audio needs the WavEncoder first
+        arch.model(x_t, ts, motion_mask=mask, xf_out=xf, c=torch.zeros(2, 100, 2))
+    arch.model.release()

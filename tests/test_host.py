@@ -161,7 +161,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     l = lib.load(require_gpu=False)           # dlopen only, no compute
     for name in declared:
         assert hasattr(l, name), name
-    assert ctypes.sizeof(lib.ModelConfig) == 14 * 4 and ctypes.sizeof(lib.StepCoefs) == 12 * 4
+    assert ctypes.sizeof(lib.ModelConfig) == 17 * 4 and ctypes.sizeof(lib.StepCoefs) == 12 * 4
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):     # product path fails loudly without an MI355X
             lib.load(require_gpu=True)

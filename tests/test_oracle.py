@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from oracle import stmogen_oracle as O, tutel_restated as TR, weights as W
-from helpers import SMALL, SMALL_SEED, FULL, load, synth_inputs
+from helpers import CTRL, CTRL_COPY, CTRL_FEATS, SMALL, SMALL_SEED, FULL, load, synth_inputs
 
 
 def T_(a):
@@ -121,3 +121,13 @@ def test_moe_capacity_and_ties():
                 h = torch.nn.functional.gelu(w1[e] @ x[i] + b1[e])
                 yy[i] += r['gates'][k][i] * (h @ w2[e] + b2[e])
     assert float((y - yy).abs().max()) < 1e-4
+
+
+def test_control_branch_against_reference_golden():
+    g = load('control_small.npz')
+    sd = W.make_state_dict(CTRL, SMALL_SEED, shapes=W.control_param_shapes(CTRL, CTRL_COPY, CTRL_FEATS))
+    for t in (640, 3):
+        out = O.denoise_control(sd, CTRL, T_(g['x_t']), t, T_(g['xf_out']), T_(g['motion_mask']), T_(g['c']), CTRL_COPY)
+        assert float((out - T_(g[f'x0_t{t}'])).abs().max()) <= 1e-5
+    # the condition must matter (otherwise the zero-init projections would make the test vacuous)
+    assert float((T_(g['x0_t640']) - T_(g['x0_noc_t640'])).abs().max()) > 0.1
