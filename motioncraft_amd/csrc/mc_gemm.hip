@@ -124,18 +124,17 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
             if (!abl_nobar) __syncthreads();
         }
     } else {
-        // 2-deep register prefetch: tile kt+2 is requested at the top of iteration kt, tile kt+1
-        // (requested one iteration earlier, long landed) is written to the other LDS buffer in the
-        // MIDDLE of iteration kt's MFMAs, so neither the global latency nor the staging writes sit
-        // between the last MFMA and the barrier.
-        f32x4 na[4], nb[4];
+        // Staging in the MIDDLE of the MFMA stream with ONE register set: after the first 16 MFMAs of
+        // k-tile kt the registers holding tile kt+1 (requested during iteration kt-1, ~48 MFMAs = 1.4 us
+        // earlier, so the vmcnt wait in front of the LDS writes is already satisfied) are written to the
+        // other LDS buffer, then tile kt+2 is requested into the same registers.  Neither the global
+        // latency nor the staging writes sit between the last MFMA and the barrier.
         load_tile<MODE, GUARD>(g, Ab, Wb, st, sk, ra, rb);
         store_tile(0);
         if (nk > 1) load_tile<MODE, GUARD>(g, Ab, Wb, st, BK + sk, ra, rb);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
-            if (kt + 2 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 2) * BK + sk, na, nb);
             const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
             const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
             Frag f0 = ld_frag(Ap, Bp, 0);
@@ -143,12 +142,11 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
             mma(f0);
             f0 = ld_frag(Ap, Bp, 2);
             if (kt + 1 < nk) store_tile(buf ^ 1);
+            if (kt + 2 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 2) * BK + sk, ra, rb);
             mma(f1);
             f1 = ld_frag(Ap, Bp, 3);
             mma(f0);
             mma(f1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { ra[i] = na[i]; rb[i] = nb[i]; }
             __syncthreads();
         }
     }
