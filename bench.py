@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='samples per GPU (BASELINE configs[1]: 64)')
     ap.add_argument('--frames', type=int, default=196)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for plumbing smoke tests")
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -123,13 +124,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    if os.environ.get('MC_BENCH_ALL_ON_DEVICE0'):      # plumbing smoke test of the N>1 path on a 1-GPU box (gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from motioncraft_amd import dist as mcd
     from motioncraft_amd.diffusion import build_diffusion
@@ -146,8 +152,9 @@ def main():
                                 model_var_type='fixed_large'))
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if a.backend == 'nccl' else dist.barrier()
         torch.cuda.synchronize()
 
     # ---- once-per-batch setup: condition broadcast (RCCL), FiLM tables, text K/V ----
@@ -198,7 +205,7 @@ def main():
     t_gather = time.perf_counter() - t0
     assert out.shape[0] == GB and bool(torch.isfinite(out).all())
 
-    t = torch.tensor([t_loop, t_setup, t_gather, ev_ms], device=dev, dtype=torch.float64)
+    t = torch.tensor([t_loop, t_setup, t_gather, ev_ms], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_loop, t_setup, t_gather, ev_ms = (float(v) for v in t)

@@ -29,13 +29,28 @@ def shard_range(total, rank=None, world_size=None):
     return rank * per, (rank + 1) * per
 
 
+def _device_collectives():
+    """RCCL ("nccl") moves HBM tensors over xGMI directly; with gloo (CPU tests, single-GPU smoke runs)
+    device tensors are staged through host memory."""
+    return dist.get_backend() == 'nccl'
+
+
+def _bcast(t, src):
+    if t.is_cuda and not _device_collectives():
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def broadcast_condition(xf_out, motion_mask, src=0):
     """Rank `src` holds the condition of the GLOBAL batch; every rank returns its own slice.
     Tensors on other ranks only need the right shape/dtype/device (contents are overwritten)."""
     if not is_dist():
         return xf_out, motion_mask
-    dist.broadcast(xf_out, src=src)
-    dist.broadcast(motion_mask, src=src)
+    _bcast(xf_out, src)
+    _bcast(motion_mask, src)
     lo, hi = shard_range(xf_out.shape[0])
     return xf_out[lo:hi].contiguous(), motion_mask[lo:hi].contiguous()
 
@@ -45,10 +60,14 @@ def gather_results(local):
     if not is_dist():
         return local
     rank, ws = world()
-    out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous()) if local.is_cuda else \
-        dist.all_gather(list(out.chunk(ws, dim=0)), local.contiguous())
-    return out
+    if local.is_cuda and _device_collectives():
+        out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    h = local.detach().cpu().contiguous()
+    out = torch.empty((ws * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+    dist.all_gather(list(out.chunk(ws, dim=0)), h)
+    return out.to(local.device)
 
 
 def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, **kwargs):
