@@ -140,16 +140,32 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
     };
 
     // ---- phase 1: column max / sum over the sequence (softmax dim=1, st_attention.py:155) ----
+    // rows are taken in batches of 8 independent loads (a row-by-row online update serialises one
+    // global-load latency per row); one rescale per batch instead of per row
     {
         const int c4 = (tid % C4) * 4, sl = tid / C4;
         f32x4 m = {-3e38f, -3e38f, -3e38f, -3e38f}, s = {0.f, 0.f, 0.f, 0.f};
-        for (int n = sl; n < Nseq; n += NSL) {
-            f32x4 kk, vv;
-            load_kv(n, c4, kk, vv);
+        constexpr int BATCH = 8;
+        for (int n0 = sl; n0 < Nseq; n0 += NSL * BATCH) {
+            f32x4 kk[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int n = n0 + u * NSL;
+                kk[u] = f32x4{-3e38f, -3e38f, -3e38f, -3e38f};
+                if (n < Nseq) {
+                    f32x4 vv;
+                    load_kv(n, c4, kk[u], vv);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float nm = fmaxf(m[j], kk[j]);
-                s[j] = s[j] * expf(m[j] - nm) + expf(kk[j] - nm);
+                float nm = m[j];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) nm = fmaxf(nm, kk[u][j]);
+                float acc = s[j] * expf(m[j] - nm);
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) acc += expf(kk[u][j] - nm);    // exp(-3e38 - nm) = 0 for the padding slots
+                s[j] = acc;
                 m[j] = nm;
             }
         }
@@ -175,23 +191,37 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const int nch = (Nseq + 31) / 32;
+    // register prefetch: the K/V rows of chunk ch+1 are requested before the MFMAs of chunk ch
+    constexpr int SPT = (32 * C4) / 256;            // float4 (row, column) slots per thread per chunk
+    f32x4 pk[SPT], pv[SPT];
+    auto prefetch_kv = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int i = tid + 256 * j;
+            const int n = ch * 32 + i / C4;
+            pk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pv[j] = pk[j];
+            if (n < Nseq) load_kv(n, (i % C4) * 4, pk[j], pv[j]);
+        }
+    };
+    prefetch_kv(0);
     for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
-        for (int j = 0; j < (32 * C4) / 256; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             const int i = tid + 256 * j;
             const int row = i / C4, c4 = (i % C4) * 4;
             const int n = ch * 32 + row;
-            f32x4 e = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 e = {0.f, 0.f, 0.f, 0.f};
             if (n < Nseq) {
-                f32x4 kk;
-                load_kv(n, c4, kk, vv);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = expf(kk[q] - s_m[c4 + q]) / s_s[c4 + q];
+                for (int q = 0; q < 4; ++q) e[q] = expf(pk[j][q] - s_m[c4 + q]) / s_s[c4 + q];
             }
             *reinterpret_cast<f32x4*>(Ks + row * LP + c4) = e;
-            *reinterpret_cast<f32x4*>(Vs + row * LP + c4) = vv;
+            *reinterpret_cast<f32x4*>(Vs + row * LP + c4) = pv[j];
         }
         __syncthreads();
+        if (ch + 1 < nch) prefetch_kv(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ABOVE the MFMAs (the scheduler otherwise sinks them to their use)
         if (mm_active) {
 #pragma unroll 4
             for (int ks = 0; ks < 16; ++ks) {
@@ -211,38 +241,46 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
     // lane (l = 32*wave + (lane&31), half hf) holds A2[d][l] for d = 32 dt + 8 q + 4 hf + i in acc[dt][4q+i]:
     // exactly the B operand of k-group (dt, q); the A operand Q[t][same d] is one b128 read.
     const int ntc = (T + 31) / 32;
+    constexpr int SEG = L / 8;                       // 8 threads per query row
+    const int qrow = tid >> 3, qsub = tid & 7;
+    float qv[SEG];
+    auto prefetch_q = [&](int tc) {
+        const int t = tc * 32 + qrow;
+        if (t < T) {
+            const float* r = mf + (((long)b * T + t) * H + h) * D4 + 3 * L + qsub * SEG;
+#pragma unroll
+            for (int j = 0; j < SEG; j += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(r + j);
+                qv[j] = x[0]; qv[j + 1] = x[1]; qv[j + 2] = x[2]; qv[j + 3] = x[3];
+            }
+        }
+    };
+    prefetch_q(0);
     for (int tc = 0; tc < ntc; ++tc) {
         {
-            const int row = tid >> 3, sub = tid & 7;
-            const int t = tc * 32 + row;
-            constexpr int SEG = L / 8;
-            float v[SEG];
+            const int t = tc * 32 + qrow;
             float mx = -3e38f;
             if (t < T) {
-                const float* r = mf + (((long)b * T + t) * H + h) * D4 + 3 * L + sub * SEG;
 #pragma unroll
-                for (int j = 0; j < SEG; j += 4) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(r + j);
-                    v[j] = x[0]; v[j + 1] = x[1]; v[j + 2] = x[2]; v[j + 3] = x[3];
-                }
-#pragma unroll
-                for (int j = 0; j < SEG; ++j) mx = fmaxf(mx, v[j]);
+                for (int j = 0; j < SEG; ++j) mx = fmaxf(mx, qv[j]);
             }
             mx = group_max(mx, 8);
             float s = 0.f;
             if (t < T) {
 #pragma unroll
-                for (int j = 0; j < SEG; ++j) { v[j] = expf(v[j] - mx); s += v[j]; }
+                for (int j = 0; j < SEG; ++j) { qv[j] = expf(qv[j] - mx); s += qv[j]; }
             }
             s = group_sum(s, 8);
 #pragma unroll
             for (int j = 0; j < SEG; j += 4) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                if (t < T) o = f32x4{v[j] / s, v[j + 1] / s, v[j + 2] / s, v[j + 3] / s};
-                *reinterpret_cast<f32x4*>(Qs + row * LP + sub * SEG + j) = o;
+                if (t < T) o = f32x4{qv[j] / s, qv[j + 1] / s, qv[j + 2] / s, qv[j + 3] / s};
+                *reinterpret_cast<f32x4*>(Qs + qrow * LP + qsub * SEG + j) = o;
             }
         }
         __syncthreads();
+        if (tc + 1 < ntc) prefetch_q(tc + 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (mm_active) {
             f32x16 o;
 #pragma unroll

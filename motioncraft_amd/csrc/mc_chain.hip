@@ -61,15 +61,23 @@ __device__ __forceinline__ f32x16 chunk_mma(const float* Wc, const f32x4 (&xf)[N
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
     const float* wp = Wc + (lane & 31) * LDW + (lane >> 5) * 4;
+    // explicit software pipeline: the weight fragments of k-groups j+CH.. are read while the
+    // 4*CH MFMAs of k-groups j.. execute
+    f32x4 w[CH], wn[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) w[c] = *reinterpret_cast<const f32x4*>(wp + 8 * c);
 #pragma unroll
     for (int j = 0; j < NJ; j += CH) {
-        f32x4 w[CH];
+        if (j + CH < NJ) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) w[c] = *reinterpret_cast<const f32x4*>(wp + 8 * (j + c));
+            for (int c = 0; c < CH; ++c) wn[c] = *reinterpret_cast<const f32x4*>(wp + 8 * (j + CH + c));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][i], xf[j + c][i], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) w[c] = wn[c];
     }
 #pragma unroll
     for (int c = 1; c < CH; ++c)
@@ -115,8 +123,10 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
     constexpr int NJ = L / 8, NT = L / 32, HC = 32;
     using S1 = ChunkStage<HC, L>;      // W1 chunk  [32 hidden][L]
     using S2 = ChunkStage<L, HC>;      // W2^T chunk [L out][32 hidden]
-    __shared__ __attribute__((aligned(16))) float smem[2 * (HC * S1::LDS_LD + L * S2::LDS_LD)];
+    constexpr int MAXHID = 1024;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (HC * S1::LDS_LD + L * S2::LDS_LD) + MAXHID];
     constexpr int BUFSZ = HC * S1::LDS_LD + L * S2::LDS_LD;
+    float* s_b1 = smem + 2 * BUFSZ;      // first-layer bias of this group (hidden <= 1024)
     auto W1s = [&](int b) { return smem + b * BUFSZ; };
     auto W2s = [&](int b) { return smem + b * BUFSZ + HC * S1::LDS_LD; };
 
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
     const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
     const float* __restrict__ b2 = g.b2 + (long)grp * L;
 
+    for (int i = tid; i < g.hidden; i += 256) s_b1[i] = b1[i];
     const int r = wave * 32 + (lane & 31);
     const bool rok = r < nrows;
     const int kq = (lane >> 5) * 4;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
         f32x4 hf[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + hc * HC + 8 * q + kq);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + hc * HC + 8 * q + kq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) hf[q][i] = gelu_exact(a1[4 * q + i] + bb[i]);
         }
@@ -227,7 +238,7 @@ template <int L>
 __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
     constexpr int NJ = L / 8, PC = 256 / 32, MAXE = 16, LDS_SIM = 256 + 4;
     using SP = ChunkStage<32, L>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 32 * LDS_SIM];
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 32 * LDS_SIM + 256];
     __shared__ int s_cnt[2 * MAXE];
     auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
     float* s_simT = smem + 2 * 32 * SP::LDS_LD;    // [32 expert rows (>= E zero)][256 + 4]: sim_n^T as an MFMA "A" operand
@@ -236,6 +247,8 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
         const int e = i >> 8, j = i & 255;
         s_simT[e * LDS_SIM + j] = e < g.E ? g.sim_n[j * g.E + e] : 0.f;
     }
+    float* s_bp = s_simT + 32 * LDS_SIM;           // projector bias [256]
+    s_bp[tid] = g.bp[tid];
     if (tid < 2 * MAXE) s_cnt[tid] = 0;
     const long tok = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool rok = tok < g.N;
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
         const f32x16 p = chunk_mma<NJ>(Ws(buf), zf, lane);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bp + c * 32 + 8 * q + kq);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bp + c * 32 + 8 * q + kq);
             const f32x4 sv = *reinterpret_cast<const f32x4*>(simp + c * 32 + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -352,9 +365,11 @@ template <int L, int KIND>   // KIND 0: combproj, 1: lnqkv
 __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     constexpr int NJ = L / 8;
     using SP = ChunkStage<32, L>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD];
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 4 * L];
     auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
+    float* s_bias = smem + 2 * 32 * SP::LDS_LD;      // whole bias vector (Nout <= 4L): a global load per chunk would sit on the critical path
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < g.Nout; i += 256) s_bias[i] = g.bias[i];
     const long tok = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool rok = tok < g.N;
     const int kq = (lane >> 5) * 4;
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
         const f32x16 a = chunk_mma<NJ>(Ws(c & 1), xf, lane);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + c * 32 + 8 * q + kq);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + c * 32 + 8 * q + kq);
             const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]};
             if (rok) *reinterpret_cast<f32x4*>(orow + c * 32 + 8 * q) = v;
         }
@@ -413,7 +428,7 @@ int tune_bits() {
 
 bool mc_chain_enabled(int which) { return (tune_bits() >> which) & 1; }
 
-bool mc_mlp_supported(int L, int hidden) { return (L == 32 || L == 64 || L == 128) && hidden % 32 == 0 && hidden >= 32; }
+bool mc_mlp_supported(int L, int hidden) { return (L == 32 || L == 64 || L == 128) && hidden % 32 == 0 && hidden >= 32 && hidden <= 1024; }
 
 int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStream_t s) {
     MC_REQUIRE(mc_mlp_supported(g.L, g.hidden), "fused mlp: L=%d hidden=%d unsupported", g.L, g.hidden);
