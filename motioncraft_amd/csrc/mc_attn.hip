@@ -308,15 +308,18 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
 
 int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* wsm, float* ys,
                    long frames, int H, int L, int G, hipStream_t s) {
-    MC_REQUIRE(G == 8 && H == 12 && (L == 32 || L == 64 || L == 128), "body: H=%d L=%d G=%d unsupported", H, L, G);
+    MC_REQUIRE(G == 8 && (H == 12 || H == 8) && (L == 32 || L == 64 || L == 128), "body: H=%d L=%d G=%d unsupported", H, L, G);
     if (frames <= 0) return MC_OK;
     const int hd = L / G;
     const long groups = frames * G;               // (frame, head) groups of hd lanes
     const long waves = (groups * hd + 63) / 64;
     dim3 grid((unsigned)((waves + 3) / 4));
-    if (hd == 16) hipLaunchKernelGGL((body_reg_k<16, 12>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
-    else if (hd == 8) hipLaunchKernelGGL((body_reg_k<8, 12>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
-    else hipLaunchKernelGGL((body_reg_k<4, 12>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
+#define MC_BODY_CASE(HH)                                                                                          \
+    if (hd == 16) hipLaunchKernelGGL((body_reg_k<16, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);    \
+    else if (hd == 8) hipLaunchKernelGGL((body_reg_k<8, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames); \
+    else hipLaunchKernelGGL((body_reg_k<4, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
+    if (H == 12) { MC_BODY_CASE(12) } else { MC_BODY_CASE(8) }   // motionx: 12 parts; human_ml3d / kit_ml: 8
+#undef MC_BODY_CASE
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -53,9 +53,11 @@ class STMoGenTransformer:
                 or time_embedding_type != 'sinusoidal':
             raise NotImplementedError('option outside the shipped stmogen configs')
         for c in (pose_encoder_cfg, pose_decoder_cfg):
-            if c.get('dataset_name') != 'motionx' or c.get('joints', False) or c.get('body_graph', False):
-                raise NotImplementedError("the MI355X path covers dataset_name='motionx' (12 parts, 322-d SMPL-X); "
-                                          'human_ml3d is listed as "next" (SURVEY.md section 8f.4)')
+            if c.get('dataset_name') not in ('motionx', 'human_ml3d', 'kit_ml') or c.get('joints', False) \
+                    or c.get('body_graph', False) or c.get('dataset_name') != pose_encoder_cfg.get('dataset_name'):
+                raise NotImplementedError("the MI355X path covers the part-wise pose layouts of dataset_name="
+                                          "'motionx' (12 parts, 322-d), 'human_ml3d' (8 parts, 263-d) and 'kit_ml' "
+                                          '(8 parts, 251-d); joints=True / body_graph / rot6d / openpose17 are not shipped')
         if isinstance(ffn_cfg, list):
             raise NotImplementedError('per-layer ffn_cfg lists are not used by the shipped configs')
         self.ca_block = build_attention(ca_block_cfg)
@@ -73,7 +75,8 @@ class STMoGenTransformer:
             raise NotImplementedError('use_text_proj=True is not used by the shipped configs')
         self.dims = dict(input_feats=input_feats, max_seq_len=max_seq_len, L=a.latent_dim, H=a.num_heads,
                          NL=num_layers, F=ffn_cfg['ffn_dim'], Te=time_embed_dim, Dt=a.text_latent_dim,
-                         Nt=a.max_text_seq_len, E=a.num_experts, topk=a.topk)
+                         Nt=a.max_text_seq_len, E=a.num_experts, topk=a.topk,
+                         dataset=pose_encoder_cfg.get('dataset_name'))
         self.training = False
         self._native = None
         self._ctx = {}

@@ -41,22 +41,64 @@ def smplx_part_slices():
     return d
 
 
+def _hml_joint_channels(j, nj):
+    """Channels of joint ``j`` in a HumanML3D-style vector of ``nj`` joints:
+    [root 4 | ric (nj-1)*3 | rot6d (nj-1)*6 | vel nj*3 | foot 4]; the root joint owns the
+    4 root scalars, its velocity and the foot contacts (reference stmogen.py:12-52)."""
+    ric, rot, vel = 4, 4 + 3 * (nj - 1), 4 + 9 * (nj - 1)
+    foot = vel + 3 * nj
+    if j == 0:
+        return [0, 1, 2, 3, vel, vel + 1, vel + 2] + list(range(foot, foot + 4))
+    return ([ric + 3 * (j - 1) + c for c in range(3)] + [rot + 6 * (j - 1) + c for c in range(6)]
+            + [vel + 3 * j + c for c in range(3)])
+
+
+_SKELETON_PARTS = {
+    # dataset -> (num joints, part -> joint ids)   (reference stmogen.py:188-209 PoseEncoder.__init__)
+    'human_ml3d': (22, OrderedDict(head=[12, 15], stem=[3, 6, 9], larm=[14, 17, 19, 21], rarm=[13, 16, 18, 20],
+                                   lleg=[2, 5, 8, 11], rleg=[1, 4, 7, 10], root=[0])),
+    'kit_ml': (21, OrderedDict(head=[4], stem=[1, 2, 3], larm=[8, 9, 10], rarm=[5, 6, 7],
+                               lleg=[16, 17, 18, 19, 20], rleg=[11, 12, 13, 14, 15], root=[0])),
+}
+
+
+def part_layout(dataset='motionx'):
+    """(part names, part -> channel list, channel list fed to ``body_embed``) of a dataset's pose vector.
+    motionx: 11 parts + body over the 322-d SMPL-X vector (body = the parts concatenated);
+    human_ml3d / kit_ml: 7 parts + body over the 263-d / 251-d vector (body = joints in index order)."""
+    if dataset == 'motionx':
+        sl = smplx_part_slices()
+        return list(PART_NAMES), sl, [c for n in PART_NAMES for c in sl[n]]
+    if dataset in _SKELETON_PARTS:
+        nj, parts = _SKELETON_PARTS[dataset]
+        sl = OrderedDict((n, [c for j in js for c in _hml_joint_channels(j, nj)]) for n, js in parts.items())
+        return list(parts), sl, [c for j in range(nj) for c in _hml_joint_channels(j, nj)]
+    raise NotImplementedError(f"pose layout of dataset_name={dataset!r} is not on the MI355X path "
+                              "(motionx, human_ml3d, kit_ml)")
+
+
 def default_dims(**over):
     """0.125b config (reference configs/stmogen/T2M_motionx_align_Finedance_Beats2_face_no_loss_0_125b.py:26-83)."""
     d = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77,
-             E=16, topk=2, scale=6.5, dyn_heads=8)
+             E=16, topk=2, scale=6.5, dyn_heads=8, dataset='motionx')
     d.update(over)
     return d
+
+
+def humanml3d_dims(**over):
+    """reference configs/stmogen/T2M_humanml3d.py:26-83 (263-d HumanML3D, 8 parts x 64)."""
+    return default_dims(**{**dict(input_feats=263, L=64, H=8, F=256, dataset='human_ml3d'), **over})
 
 
 def param_shapes(dims):
     """name -> shape for the denoiser's state dict."""
     L, H, NL, F, Te, Dt, Nt, E = (dims[k] for k in ('L', 'H', 'NL', 'F', 'Te', 'Dt', 'Nt', 'E'))
     D, C, Tm = L * H, dims['input_feats'], dims['max_seq_len']
-    sl = smplx_part_slices()
+    names, sl, body = part_layout(dims.get('dataset', 'motionx'))
+    assert H == len(names) + 1 and len(body) == C, (H, len(names), len(body), C)
     s = OrderedDict()
     s['sequence_embedding'] = (Tm, D)
-    for p in PART_NAMES:
+    for p in names:
         s[f'joint_embed.{p}_embed.weight'] = (L, len(sl[p]))
         s[f'joint_embed.{p}_embed.bias'] = (L,)
     s['joint_embed.body_embed.weight'] = (L, C)
@@ -109,7 +151,7 @@ def param_shapes(dims):
             s[ff + f'linear2_list.{p}.weight'] = (L, F)
             s[ff + f'linear2_list.{p}.bias'] = (L,)
         stylization(ff + 'proj_out.')
-    for p in PART_NAMES:
+    for p in names:
         s[f'out.{p}_out.weight'] = (len(sl[p]), L)
         s[f'out.{p}_out.bias'] = (len(sl[p]),)
     s['out.body_out.weight'] = (C, L)
@@ -190,7 +232,7 @@ def reference_model_cfg(dims):
                           dynamic_body=True),
         ffn_cfg=dict(latent_dim=L, ffn_dim=dims['F'], dropout=0, time_embed_dim=dims['Te'], num_heads=H),
         text_encoder=None,
-        pose_encoder_cfg=dict(dataset_name='motionx', latent_dim=L, input_dim=dims['input_feats']),
-        pose_decoder_cfg=dict(dataset_name='motionx', latent_dim=L, output_dim=dims['input_feats']),
+        pose_encoder_cfg=dict(dataset_name=dims.get('dataset', 'motionx'), latent_dim=L, input_dim=dims['input_feats']),
+        pose_decoder_cfg=dict(dataset_name=dims.get('dataset', 'motionx'), latent_dim=L, output_dim=dims['input_feats']),
         scale_func_cfg=dict(scale=dims['scale']), moe_route_loss_weight=10.0,
         template_kl_loss_weight=0.0001, use_pos_embedding=True)

@@ -12,7 +12,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .synthetic import PART_NAMES, smplx_part_slices  # 322-d motionx part layout (reference stmogen.py:53-68)
+from .synthetic import part_layout  # pose-vector part layouts (reference stmogen.py:12-112,188-230)
 
 
 def strip_prefix(state_dict):
@@ -91,17 +91,16 @@ def pack_state_dict(state_dict, dims):
     L, H, NL, C = dims['L'], dims['H'], dims['NL'], dims['input_feats']
     D = L * H
     Cp = (C + 3) // 4 * 4
-    sl = smplx_part_slices()
-    assert H == len(PART_NAMES) + 1, 'only the 12-part motionx layout is on this path'
+    names, sl, body = part_layout(dims.get('dataset', 'motionx'))
+    assert H == len(names) + 1 and len(body) == C, 'num_heads / input_feats do not match the dataset part layout'
     out = OrderedDict()
 
     # PoseEncoder -> one dense [D, Cp] weight (rows = output channel (part, j); columns = pose channel)
     enc_w = torch.zeros(D, Cp)
     enc_b = torch.zeros(D)
-    for p, n in enumerate(PART_NAMES):
+    for p, n in enumerate(names):
         enc_w[p * L:(p + 1) * L, sl[n]] = sd[f'joint_embed.{n}_embed.weight'].float()
         enc_b[p * L:(p + 1) * L] = sd[f'joint_embed.{n}_embed.bias'].float()
-    body = [c for n in PART_NAMES for c in sl[n]]
     enc_w[(H - 1) * L:, body] = sd['joint_embed.body_embed.weight'].float()
     enc_b[(H - 1) * L:] = sd['joint_embed.body_embed.bias'].float()
     out['enc.w'], out['enc.b'] = _f(enc_w), _f(enc_b)
@@ -112,7 +111,7 @@ def pack_state_dict(state_dict, dims):
     # PoseDecoder -> one dense [C, D] weight, (scatter + body_out) / 2 folded in; body_out is NOT un-permuted
     dec_w = torch.zeros(C, D)
     dec_b = torch.zeros(C)
-    for p, n in enumerate(PART_NAMES):
+    for p, n in enumerate(names):
         dec_w[sl[n], p * L:(p + 1) * L] = 0.5 * sd[f'out.{n}_out.weight'].float()
         dec_b[sl[n]] = 0.5 * sd[f'out.{n}_out.bias'].float()
     dec_w[:, (H - 1) * L:] = 0.5 * sd['out.body_out.weight'].float()

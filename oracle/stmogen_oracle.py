@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import tutel_restated
-from .weights import PART_NAMES, smplx_part_slices
+from .weights import part_layout
 
 
 # ------------------------------------------------------------------------------------
@@ -50,32 +50,25 @@ def time_embed(p, timesteps, D):
 # ------------------------------------------------------------------------------------
 # a9 / a14: pose encoder / decoder (motionx, joints=False, patch_size 1)
 # ------------------------------------------------------------------------------------
-def body_slice():
-    sl = smplx_part_slices()
-    out = []
-    for n in PART_NAMES:
-        out += sl[n]
-    return out
-
-
-def pose_encoder(p, motion):
-    """mogen/models/transformers/stmogen.py:336-353,376-378."""
-    sl = smplx_part_slices()
+def pose_encoder(p, motion, dataset='motionx'):
+    """mogen/models/transformers/stmogen.py:336-353 (motionx), :354-365 (human_ml3d / kit_ml), :376-378."""
+    names, sl, body = part_layout(dataset)
     feats = [F.linear(motion[:, :, sl[n]], p[f'joint_embed.{n}_embed.weight'], p[f'joint_embed.{n}_embed.bias'])
-             for n in PART_NAMES]
-    feats.append(F.linear(motion[:, :, body_slice()], p['joint_embed.body_embed.weight'],
+             for n in names]
+    feats.append(F.linear(motion[:, :, body], p['joint_embed.body_embed.weight'],
                           p['joint_embed.body_embed.bias']))
     return torch.cat(feats, dim=-1)
 
 
-def pose_decoder(p, h, L, out_dim=322):
-    """mogen/models/transformers/stmogen.py:505-544.  NB body_out is added WITHOUT un-permuting."""
-    sl = smplx_part_slices()
+def pose_decoder(p, h, L, out_dim=322, dataset='motionx'):
+    """mogen/models/transformers/stmogen.py:505-544 (motionx), :545-562 (human_ml3d / kit_ml).
+    NB body_out is added WITHOUT un-permuting."""
+    names, sl, _ = part_layout(dataset)
     B, T, _ = h.shape
     out = torch.zeros(B, T, out_dim, dtype=h.dtype)
-    for i, n in enumerate(PART_NAMES):
+    for i, n in enumerate(names):
         out[:, :, sl[n]] = F.linear(h[:, :, i * L:(i + 1) * L], p[f'out.{n}_out.weight'], p[f'out.{n}_out.bias'])
-    body = F.linear(h[:, :, len(PART_NAMES) * L:], p['out.body_out.weight'], p['out.body_out.bias'])
+    body = F.linear(h[:, :, len(names) * L:], p['out.body_out.weight'], p['out.body_out.bias'])
     return (out + body) / 2.0
 
 
@@ -226,7 +219,7 @@ def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_nu
     pb = {k[len('base_model.'):]: v for k, v in p.items() if k.startswith('base_model.')}
     ts = torch.full((B,), int(t_orig), dtype=torch.long)
     emb = time_embed(pb, ts, D)
-    h = pose_encoder(pb, x_t)
+    h = pose_encoder(pb, x_t, dims.get('dataset', 'motionx'))
     cc = control_forward_c(p, c, T)
     h = h + pb['sequence_embedding'].unsqueeze(0)[:, :T, :]
     cond = torch.cat((torch.ones(B, 1, 1), torch.zeros(B, 1, 1)), dim=0)
@@ -256,7 +249,7 @@ def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_nu
         h = layer(pb, f'temporal_decoder_blocks.{index}.', h + c_skip)
     for index in range(copy_blocks_num + 1, NL):
         h = layer(pb, f'temporal_decoder_blocks.{index}.', h)
-    out = pose_decoder(pb, h, L, C).view(2 * B, T, -1)
+    out = pose_decoder(pb, h, L, C, dims.get('dataset', 'motionx')).view(2 * B, T, -1)
     if cap is not None:
         cap['out2'] = out
     w = (1 - (1000 - int(t_orig)) / 1000) * dims['scale'] + 1
@@ -272,7 +265,7 @@ def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None
     D = L * H
     ts = torch.full((B,), int(t_orig), dtype=torch.long)
     emb = time_embed(p, ts, D)
-    h = pose_encoder(p, x_t) + p['sequence_embedding'].unsqueeze(0)[:, :T, :]
+    h = pose_encoder(p, x_t, dims.get('dataset', 'motionx')) + p['sequence_embedding'].unsqueeze(0)[:, :T, :]
     if cap is not None:
         cap['h0'] = h
         cap['emb'] = emb
@@ -293,7 +286,7 @@ def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None
         if lcap is not None:
             lcap['after_ffn'] = h
             cap[f'layer{i}'] = lcap
-    out = pose_decoder(p, h, L, C).view(2 * B, T, -1)
+    out = pose_decoder(p, h, L, C, dims.get('dataset', 'motionx')).view(2 * B, T, -1)
     if cap is not None:
         cap['out2'] = out
     w = (1 - (1000 - int(t_orig)) / 1000) * dims['scale'] + 1       # stmogen.py:655-659

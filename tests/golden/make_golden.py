@@ -21,6 +21,8 @@ Fixtures
   small_ddim.npz        reduced config: 50-step DDIM trajectory (every 10th x_t) + final
   small_ddpm.npz        reduced config: 1000-step schedule, first 20 DDPM steps
   control_small.npz     ControlT2MHalf (copy_blocks_num=2, 35-d condition of 20 frames, NL=3): x0 at t=640, 3
+  skeleton_parts.npz    8-part layouts: human_ml3d (263-d) and kit_ml (251-d) reduced configs (x0 at two t + 50-step
+                        DDIM final), and the shipped T2M_humanml3d.py architecture (L=64, H=8) x0 at t=500
   full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
   full_ddim.npz         0.125b config, B=1: final sample of the 50-step DDIM loop
 """
@@ -246,6 +248,45 @@ def control():
     np.savez_compressed(os.path.join(OUT, 'control_small.npz'), **save)
 
 
+HML_SMALL = W.humanml3d_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
+KIT_SMALL = W.humanml3d_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8, input_feats=251, dataset='kit_ml')
+HML_FULL = W.humanml3d_dims()
+
+
+def skeleton_parts():
+    """the 8-part PoseEncoder/PoseDecoder layouts (reference stmogen.py:188-209,354-365,545-562)."""
+    save = {}
+    for tag, dims in (('hml', HML_SMALL), ('kit', KIT_SMALL)):
+        B, T = 2, 24
+        m, sd = build_ref(dims, SMALL_SEED)
+        x_T, xf, mask = synth_inputs(dims, B, T, seed=31, lengths=[24, 17])
+        save[f'{tag}_x_t'], save[f'{tag}_xf_out'], save[f'{tag}_motion_mask'] = x_T.numpy(), xf.numpy(), mask.numpy()
+        for t in (901, 12):
+            with torch.no_grad():
+                r = m(x_T, torch.full((B,), t, dtype=torch.long), **model_kwargs(xf, mask))
+            o = O.denoise(sd, dims, x_T, t, xf, mask)
+            print(f'skeleton_parts {tag} t={t}: oracle vs reference {maxabs(r, o):.2e}')
+            assert maxabs(r, o) <= 1e-5
+            save[f'{tag}_x0_t{t}'] = r.numpy()
+        diff = ref_shim.build_reference_diffusion(DIFF_DDIM)
+        tr = run_ref_loop(m, diff, 'ddim', x_T, xf, mask, seed=8)
+        to = run_oracle_loop(sd, dims, O.Schedule(1000, DIFF_DDIM['respace']), 'ddim', x_T, xf, mask, seed=8)
+        e = [maxabs(a, b) for a, b in zip(tr, to)]
+        print(f'skeleton_parts {tag} ddim: oracle vs reference max {max(e):.2e}')
+        assert max(e) <= 1e-5
+        save[f'{tag}_ddim_final'] = tr[-1].numpy()
+    dims, B, T = HML_FULL, 1, 196
+    m, sd = build_ref(dims)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=32, lengths=[163])
+    with torch.no_grad():
+        r = m(x_T, torch.full((B,), 500, dtype=torch.long), **model_kwargs(xf, mask))
+    o = O.denoise(sd, dims, x_T, 500, xf, mask)
+    print(f'skeleton_parts T2M_humanml3d arch t=500 len=163: oracle vs reference {maxabs(r, o):.2e}')
+    assert maxabs(r, o) <= 1e-5
+    save['hmlfull_x0_t500_len163'] = r.numpy()
+    np.savez_compressed(os.path.join(OUT, 'skeleton_parts.npz'), **save)
+
+
 def full():
     dims, B, T = FULL, 1, 196
     t0 = time.time()
@@ -289,12 +330,15 @@ def full():
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-full', action='store_true')
+    ap.add_argument('--only', default=None, help='comma list of fixture groups to regenerate')
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
-    schedules()
-    small_modules()
-    small_loops()
-    control()
-    if not a.skip_full:
-        full()
+    groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
+                  skeleton_parts=skeleton_parts, full=full)
+    for name, fn in groups.items():
+        if a.only is not None and name not in a.only.split(','):
+            continue
+        if name == 'full' and a.skip_full and a.only is None:
+            continue
+        fn()
     print('golden fixtures written to', OUT)

@@ -12,6 +12,9 @@ FULL = W.default_dims()
 SMALL_SEED = 2
 CTRL = W.default_dims(max_seq_len=24, L=32, NL=3, F=64, Te=64, Dt=32, Nt=8)
 CTRL_COPY, CTRL_FEATS, CTRL_TC = 2, 35, 20
+HML_SMALL = W.humanml3d_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
+KIT_SMALL = W.humanml3d_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8, input_feats=251, dataset='kit_ml')
+HML_FULL = W.humanml3d_dims()          # reference configs/stmogen/T2M_humanml3d.py architecture
 
 
 def synth_inputs(dims, B, T, seed, lengths=None):

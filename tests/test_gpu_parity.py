@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CTRL, CTRL_COPY, CTRL_FEATS, FULL, SMALL, SMALL_SEED, load, step_noise_from_seed, synth_inputs
+from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
+                     step_noise_from_seed, synth_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -340,3 +341,46 @@ def test_control_branch_vs_reference_golden():
     with pytest.raises(NotImplementedError):                                  # raw audio needs the WavEncoder first
         arch.model(x_t, ts, motion_mask=mask, xf_out=xf, c=torch.zeros(2, 100, 2))
     arch.model.release()
+
+
+def test_skeleton_part_layouts_vs_reference_golden():
+    """the 8-part human_ml3d (263-d) / kit_ml (251-d) layouts -- odd channel counts (padded
+    to a multiple of 4 inside the library), H=8 body kernel -- single calls, the 50-step DDIM loop, and the shipped
+    T2M_humanml3d.py architecture (L=64, H=8, F=256) at T=196 with a padded sample."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    g = load('skeleton_parts.npz')
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    for tag, dims in (('hml', HML_SMALL), ('kit', KIT_SMALL)):
+        sd = W.make_state_dict(dims, SMALL_SEED)
+        nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+        x, xf, mask = T_(g[f'{tag}_x_t']), T_(g[f'{tag}_xf_out']), T_(g[f'{tag}_motion_mask'])
+        B, T, C = x.shape
+        ctx = nm.context(B, T, max_steps=50)
+        ctx.set_timesteps([901, 12])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        for s_, t in ((0, 901), (1, 12)):
+            out2 = ctx.denoise(x.cuda(), s_)
+            w = (1 - (1000 - t) / 1000) * dims['scale'] + 1
+            assert maxabs(out2[:B] * w + out2[B:] * (1 - w), T_(g[f'{tag}_x0_t{t}'])) <= TOL_STEP, (tag, t)
+        ctx.set_timesteps(d.timestep_map)
+        noises = step_noise_from_seed(8, (B, T, C), 50)
+        xc = x.cuda()
+        for n, i in enumerate(range(49, -1, -1)):
+            xc = ctx.sample_step(xc, i, d.step_coefs(i, 'ddim', dims['scale']), noises[n].cuda())
+        assert maxabs(xc, T_(g[f'{tag}_ddim_final'])) <= TOL_FINAL, tag
+        ctx.close()
+        nm.close()
+    sd = W.make_state_dict(HML_FULL, 0)
+    nm = NativeModel(HML_FULL, sd, cfg_scale=HML_FULL['scale'])
+    x, xf, mask = synth_inputs(HML_FULL, 1, 196, seed=32, lengths=[163])
+    ctx = nm.context(1, 196, max_steps=1)
+    ctx.set_timesteps([500])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    out2 = ctx.denoise(x.cuda(), 0)
+    w = (1 - (1000 - 500) / 1000) * HML_FULL['scale'] + 1
+    assert maxabs(out2[:1] * w + out2[1:] * (1 - w), T_(g['hmlfull_x0_t500_len163'])) <= TOL_STEP
+    ctx.close()
+    nm.close()

@@ -41,12 +41,12 @@ def test_reference_configs_load_and_build_unchanged():
     for n in names:
         cfg = mc.Config.fromfile(os.path.join(REF_CFG, n))
         assert cfg.model.type == 'MotionDiffusion'
-        if n == 'T2M_humanml3d.py':
-            with pytest.raises(NotImplementedError):   # 263-d / 8-part variant is "next" 
-                mc.build_architecture(cfg.model)
-            continue
         arch = mc.build_architecture(cfg.model)
-        assert arch.model.dims['H'] == 12 and arch.model.dims['L'] in (64, 128)
+        if n == 'T2M_humanml3d.py':                     # 263-d HumanML3D, 8 parts x 64
+            d = arch.model.dims
+            assert (d['H'], d['L'], d['input_feats'], d['dataset']) == (8, 64, 263, 'human_ml3d')
+        else:
+            assert arch.model.dims['H'] == 12 and arch.model.dims['L'] in (64, 128)
         assert arch.diffusion_test.num_timesteps == 50 and arch.inference_type == 'ddim'
 
 
@@ -78,7 +78,7 @@ def test_build_architecture_small_and_unsupported_options():
     cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
     arch = mc.build_architecture(cfg.model)
     assert arch.model.dims == dict(input_feats=322, max_seq_len=24, L=32, H=12, NL=2, F=64, Te=64, Dt=32, Nt=8,
-                                   E=16, topk=2)
+                                   E=16, topk=2, dataset='motionx')
     assert arch.model.cfg_scale == 6.5
     with pytest.raises(NotImplementedError):
         arch.train()
@@ -151,6 +151,35 @@ def test_weight_packing_layouts():
     # full-size parameter budget of SURVEY.md: 127.9 M
     n = sum(int(np.prod(s)) for s in synthetic.param_shapes(FULL).values())
     assert abs(n / 1e6 - 127.9) < 0.1
+
+
+def test_skeleton_part_layouts_and_packing():
+    """8-part layouts: every channel of the 263-d / 251-d vector is owned by exactly one
+    part, body_embed sees joints in index order, and the dense packing reproduces the part-wise encoder/decoder."""
+    for dataset, C, nj in (('human_ml3d', 263, 22), ('kit_ml', 251, 21)):
+        names, sl, body = synthetic.part_layout(dataset)
+        assert names == ['head', 'stem', 'larm', 'rarm', 'lleg', 'rleg', 'root']
+        owned = sorted(c for n in names for c in sl[n])
+        assert owned == list(range(C)) and sorted(body) == list(range(C))
+        assert body[:11] == [0, 1, 2, 3, 4 + 9 * (nj - 1), 5 + 9 * (nj - 1), 6 + 9 * (nj - 1), C - 4, C - 3, C - 2, C - 1]
+        assert len(sl['root']) == 11 and all(len(sl[n]) % 12 == 0 for n in names[:-1])
+        dims = synthetic.humanml3d_dims(max_seq_len=24, L=32, NL=1, F=64, Te=64, Dt=32, Nt=8, input_feats=C, dataset=dataset)
+        sd = synthetic.make_state_dict(dims, 0)
+        p = weights.pack_state_dict(sd, dims)
+        L, H = 32, 8
+        assert p['enc.w'].shape == (L * H, (C + 3) // 4 * 4) and p['dec.w'].shape == (C, L * H)
+        x = torch.randn(3, C)
+        feats = [x[:, sl[n]] @ sd[f'joint_embed.{n}_embed.weight'].T + sd[f'joint_embed.{n}_embed.bias'] for n in names]
+        feats.append(x[:, body] @ sd['joint_embed.body_embed.weight'].T + sd['joint_embed.body_embed.bias'])
+        assert torch.allclose(torch.cat(feats, 1), x @ p['enc.w'][:, :C].T + p['enc.b'], atol=1e-5)
+        h = torch.randn(3, L * H)
+        out = torch.zeros(3, C)
+        for i, n in enumerate(names):
+            out[:, sl[n]] = h[:, i * L:(i + 1) * L] @ sd[f'out.{n}_out.weight'].T + sd[f'out.{n}_out.bias']
+        out = (out + h[:, 7 * L:] @ sd['out.body_out.weight'].T + sd['out.body_out.bias']) / 2
+        assert torch.allclose(out, h @ p['dec.w'].T + p['dec.b'], atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        synthetic.part_layout('openpose17')
 
 
 def test_c_abi_library_exports_every_declared_symbol():

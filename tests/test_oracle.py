@@ -11,6 +11,10 @@ def T_(a):
     return torch.from_numpy(np.asarray(a))
 
 
+def maxabs(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
 def test_schedule_tables_match_reference():
     g = load('schedules.npz')
     for tag, respace in (('ddim50', '15,15,8,6,6'), ('ddpm1000', None)):
@@ -131,3 +135,17 @@ def test_control_branch_against_reference_golden():
         assert float((out - T_(g[f'x0_t{t}'])).abs().max()) <= 1e-5
     # the condition must matter (otherwise the zero-init projections would make the test vacuous)
     assert float((T_(g['x0_t640']) - T_(g['x0_noc_t640'])).abs().max()) > 0.1
+
+
+def test_skeleton_part_layouts_against_reference_golden():
+    """human_ml3d (263-d) and kit_ml (251-d) 8-part PoseEncoder/PoseDecoder + the T2M_humanml3d.py architecture."""
+    from helpers import HML_FULL, HML_SMALL, KIT_SMALL
+    g = load('skeleton_parts.npz')
+    for tag, dims in (('hml', HML_SMALL), ('kit', KIT_SMALL)):
+        sd = W.make_state_dict(dims, SMALL_SEED)
+        x, xf, mask = T_(g[f'{tag}_x_t']), T_(g[f'{tag}_xf_out']), T_(g[f'{tag}_motion_mask'])
+        for t in (901, 12):
+            assert maxabs(O.denoise(sd, dims, x, t, xf, mask), T_(g[f'{tag}_x0_t{t}'])) <= 1e-5
+    sd = W.make_state_dict(HML_FULL, 0)
+    x, xf, mask = synth_inputs(HML_FULL, 1, 196, seed=32, lengths=[163])
+    assert maxabs(O.denoise(sd, HML_FULL, x, 500, xf, mask), T_(g['hmlfull_x0_t500_len163'])) <= 1e-5
