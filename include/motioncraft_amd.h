@@ -14,6 +14,8 @@
  *   mc_ctx_set_control    ControlT2MHalf.forward_c + before_proj           mogen/models/transformers/controlnet.py:66,186-199
  *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
  *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
+ *   mc_sample_step_inpaint  the same with y = {gt, outpainting_mask}   gaussian_diffusion.py:492-501, 855-877
+ *   mc_op_renoise         GaussianDiffusion._undo (resampling jumps)   gaussian_diffusion.py:429-435, 1113-1118
  *
  * Conventions: plain pointers and sizes only.  `*_dev` pointers are device (HBM) addresses owned
  * by the caller (e.g. torch allocations); `stream` is a hipStream_t passed as void*.  All tensors
@@ -72,6 +74,15 @@ typedef struct mc_step_coefs {
     float nonzero;            /* (t != 0)                                           */
 } mc_step_coefs;
 
+/* RePaint / outpainting operands of one step (long-sequence windows): model_kwargs['y'] of the reference */
+typedef struct mc_inpaint {
+    const float* gt_dev;          /* y['gt'] [B,T,C]                                                  */
+    const uint8_t* keep_dev;      /* y['outpainting_mask'] [B,T,C], one byte per element (torch.bool)  */
+    const float* gt_noise_dev;    /* 2nd randn_like of ddim_sample (:868) [B,T,C]; unused for DDPM     */
+    const float* blend_w_dev;     /* linspace(0,1,overlap_len) (:873); may be NULL when blend_len == 0 */
+    int32_t blend_len;            /* overlap_len if sqrt(1-alpha_bar_prev) < 0.2 and opt.addBlend, else 0 */
+} mc_inpaint;
+
 const char* mc_last_error(void);
 int mc_device_count(int* n);
 int mc_set_device(int dev);
@@ -107,6 +118,11 @@ int mc_denoise(mc_ctx* c, const float* x_t_dev, int32_t step_index, float* out2_
 int mc_sample_step(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
                    const float* noise_dev, float* x_prev_dev, float* x0_dev, void* stream);
 
+/* mc_sample_step with the kept region of x0 / of the new sample taken from gt (RePaint) */
+int mc_sample_step_inpaint(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
+                           const float* noise_dev, const mc_inpaint* inpaint, float* x_prev_dev, float* x0_dev,
+                           void* stream);
+
 /* ---- introspection for tests --------------------------------------------------------- */
 /* named context buffers: "h","z","proj","mf","qkv","ys","yt","a","z2","out2","emb","ss","tf",
  * "idx","gate","comb_w","key","cap_idx","cap_w" (layer selects tf / ss / cap slices) */
@@ -120,6 +136,9 @@ int mc_op_ln_rows(const float* x_dev, int64_t ldx, const float* gamma_dev, const
 int mc_op_sampler_update(const float* x_t_dev, const float* out_text_dev, const float* out_none_dev,
                          const float* noise_dev, float* x_prev_dev, float* x0_dev, int64_t n,
                          const mc_step_coefs* coefs, void* stream);
+
+/* out = a * x + b * noise over n elements (out may alias x) */
+int mc_op_renoise(const float* x_dev, const float* noise_dev, float a, float b, float* out_dev, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,19 @@ int mc_launch_sampler_update(const float* x_t, const float* out_text, const floa
                              const float* noise, float* x_prev, float* x0_out, long n,
                              SamplerCoefs c, hipStream_t s);
 
+// RePaint / outpainting (gaussian_diffusion.py:492-501, 855-877)
+struct InpaintArgs {
+    const float* gt;            // [B][T][C]
+    const uint8_t* keep;        // [B][T][C] bool outpainting_mask
+    const float* gt_noise;      // [B][T][C] second randn_like of ddim_sample (DDIM only)
+    const float* blend_w;       // [blend_len] linspace(0, 1, overlap_len)
+    int blend_len;              // 0 = no cross-fade at this step
+    int T, C;
+};
+int mc_launch_sampler_inpaint(const float* x_t, const float* out_text, const float* out_none, const float* noise,
+                              InpaintArgs ip, float* x_prev, float* x0_out, long n, SamplerCoefs c, hipStream_t s);
+int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s);
+
 // ---- mc_route.hip ---------------------------------------------------------------------
 struct RouteBufs {
     // per (token, choice)

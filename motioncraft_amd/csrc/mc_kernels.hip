@@ -176,6 +176,58 @@ __global__ __launch_bounds__(256) void sampler_update_k(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// RePaint / outpainting variant of the sampler update (long-sequence windows):
+//   x0      <- gt on the kept region                                  (gaussian_diffusion.py:492-501)
+//   sample  <- p_sample / ddim_sample of (x_t, x0)
+//   DDIM only: sample <- sqrt(ab_prev) gt + sqrt(1-ab_prev) gt_noise on the kept region, cross-faded
+//   into the model's sample over the first blend_len frames (weights blend_w)      (:855-877)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sampler_inpaint_k(const float* __restrict__ x_t, const float* __restrict__ o_text,
+                                                         const float* __restrict__ o_none, const float* __restrict__ noise,
+                                                         InpaintArgs ip, float* __restrict__ x_prev,
+                                                         float* __restrict__ x0_out, long n, SamplerCoefs c) {
+    const float sigma_ddpm = c.nonzero * expf(0.5f * c.log_var);
+    float sq_abp = 0.f, dir = 0.f, sigma = 0.f, nw = 0.f;
+    if (c.mode == 1) {
+        sigma = c.eta * sqrtf((1.f - c.ab_prev) / (1.f - c.ab)) * sqrtf(1.f - c.ab / c.ab_prev);
+        sq_abp = sqrtf(c.ab_prev);
+        dir = sqrtf(1.f - c.ab_prev - sigma * sigma);
+        nw = sqrtf(1.f - c.ab_prev);
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = x_t[i];
+        const bool keep = ip.keep[i] != 0;
+        const float g = keep ? ip.gt[i] : 0.f;
+        const float x0 = keep ? g : o_text[i] * c.text_coef + o_none[i] * c.none_coef;
+        float out;
+        if (c.mode == 0) {
+            out = c.c1 * x0 + c.c2 * x + sigma_ddpm * noise[i];
+        } else {
+            const float eps = (c.sqrt_recip * x - x0) / c.sqrt_recipm1;
+            out = x0 * sq_abp + dir * eps + c.nonzero * sigma * noise[i];
+            if (keep) {
+                float wg = sq_abp * g + nw * ip.gt_noise[i];
+                const int frame = (int)((i / ip.C) % ip.T);
+                if (frame < ip.blend_len) {
+                    const float lw = ip.blend_w[frame];
+                    wg = wg * (1.f - lw) + out * lw;
+                }
+                out = wg;
+            }
+        }
+        x_prev[i] = out;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+// out = a x + b noise  (the forward "undo" step of the resampling schedule, gaussian_diffusion.py:429-435)
+__global__ __launch_bounds__(256) void axpby_k(const float* __restrict__ x, const float* __restrict__ y, float a, float b,
+                                               float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i];
+}
+
 }  // namespace
 
 int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, const float* beta,
@@ -234,6 +286,28 @@ int mc_launch_sampler_update(const float* x_t, const float* out_text, const floa
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sampler_update_k, dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev,
                        x0_out, n, c);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_sampler_inpaint(const float* x_t, const float* out_text, const float* out_none, const float* noise,
+                              InpaintArgs ip, float* x_prev, float* x0_out, long n, SamplerCoefs c, hipStream_t s) {
+    MC_REQUIRE(ip.gt && ip.keep && ip.T > 0 && ip.C > 0, "inpaint: gt / keep mask / shape missing");
+    MC_REQUIRE(c.mode == 0 || ip.gt_noise, "inpaint: DDIM needs the gt re-noising draw");
+    MC_REQUIRE(ip.blend_len == 0 || ip.blend_w, "inpaint: blend weights missing");
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sampler_inpaint_k, dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, ip, x_prev,
+                       x0_out, n, c);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s) {
+    if (n <= 0) return MC_OK;
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(axpby_k, dim3(blocks), dim3(256), 0, s, x, y, a, b, out, n);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

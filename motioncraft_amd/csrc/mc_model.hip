@@ -599,6 +599,25 @@ int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coef
     return mc_launch_sampler_update(x_t, c->out2, c->out2 + n, noise, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
 }
 
+int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
+                           const mc_inpaint* ip, float* x_prev, float* x0, void* stream) {
+    MC_REQUIRE(c && x_t && k && noise && x_prev && ip, "null argument");
+    int r = mc_denoise(c, x_t, step, nullptr, -1, stream);
+    if (r != MC_OK) return r;
+    const int C = c->m->cfg.input_feats;
+    const long n = (long)c->B * c->T * C;
+    InpaintArgs a;
+    a.gt = ip->gt_dev; a.keep = ip->keep_dev; a.gt_noise = ip->gt_noise_dev; a.blend_w = ip->blend_w_dev;
+    a.blend_len = ip->blend_len; a.T = c->T; a.C = C;
+    MC_REQUIRE(a.blend_len >= 0 && a.blend_len <= c->T, "blend_len %d outside the %d-frame window", a.blend_len, c->T);
+    return mc_launch_sampler_inpaint(x_t, c->out2, c->out2 + n, noise, a, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
+}
+
+int mc_op_renoise(const float* x, const float* noise, float a, float b, float* out, int64_t n, void* stream) {
+    MC_REQUIRE(x && noise && out && n >= 0, "bad argument");
+    return mc_launch_axpby(x, noise, a, b, out, (long)n, (hipStream_t)stream);
+}
+
 int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr, int64_t* numel) {
     MC_REQUIRE(c && name && dev_ptr && numel, "null argument");
     const mc_model_config& g = c->m->cfg;

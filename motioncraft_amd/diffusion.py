@@ -4,8 +4,10 @@ Mirrors the sampling half of the reference's ``mogen/models/utils/gaussian_diffu
 (``get_named_beta_schedule`` :235-260, ``space_timesteps`` :1346-1404, ``GaussianDiffusion`` tables
 :336-387, ``p_sample_loop`` :698-797, ``ddim_sample_loop`` :925-1049, ``SpacedDiffusion`` :1407-1448)
 so callers written against it keep working; the per-step arithmetic itself (network, CFG combine,
-posterior / DDIM update) runs in libmotioncraft_amd.so.  Training losses, learned variances,
-cond_fn guidance and the RePaint/outpainting mode are outside this path and raise loudly.
+posterior / DDIM update) runs in libmotioncraft_amd.so.  The RePaint / outpainting mode of the DDIM loop
+(``y = {gt, outpainting_mask}``: :492-501, :855-877, the resampling ``harmonize`` loop :1050-1118 and its jump
+schedule ``mogen/models/utils/scheduler.py:178-208``) is covered too.  Training losses, learned variances and
+cond_fn guidance are outside this path and raise loudly.
 """
 import enum
 import math
@@ -110,9 +112,28 @@ class GaussianDiffusion:
                                       '(diffusion_architecture.py:177-191 passes clip_denoised=False)')
         if pre_seq is not None or transl_req is not None:
             raise NotImplementedError('pre_seq / transl_req seeding is not on this path (SURVEY.md section 8f)')
+
+    def _inpaint_operands(self, mode, model_kwargs, shape, device):
+        """y = {gt, outpainting_mask} of the long-sequence windows (tools/m2d_test.py:177-195) -> device operands,
+        or None when the mode is off (no mask / all-False mask, like the reference's ``True in mask`` tests)."""
         y = (model_kwargs or {}).get('y', {}) or {}
-        if 'outpainting_mask' in y:
-            raise NotImplementedError('RePaint / outpainting mode is listed as "next" (SURVEY.md section 8f.1)')
+        if 'outpainting_mask' not in y:
+            return None
+        keep = y['outpainting_mask']
+        if keep.dtype != torch.bool or tuple(keep.shape) != tuple(shape):
+            raise AssertionError('outpainting_mask must be a bool tensor of the shape of the sample')
+        if not bool(keep.any()):
+            return None
+        if 'gt' not in y:
+            if mode == 'ddpm':
+                return None                 # p_mean_variance :493-496 needs both keys, p_sample has no other use
+            raise KeyError('gt')
+        if tuple(y['gt'].shape) != tuple(shape):
+            raise AssertionError('gt must have the shape of the sample')
+        if mode == 'ddim' and self.opt is None:
+            raise ValueError("the outpainting mode of ddim_sample reads opt.overlap_len / opt.addBlend: build the "
+                             "architecture with cfg.model['opt'] = args as the reference tools do")
+        return dict(keep=keep.to(device).contiguous(), gt=y['gt'].to(device=device, dtype=torch.float32).contiguous())
 
     def step_coefs(self, i, mode, scale, eta=0.0):
         """fp64 tables -> fp32 scalars exactly like _extract_into_tensor(...).float()."""
@@ -137,26 +158,77 @@ class GaussianDiffusion:
         B, T, C = shape
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
+        inp = self._inpaint_operands(mode, model_kwargs, shape, device)
         ctx = model.sampling_context(B, T, self.timestep_map, model_kwargs, device)
         if noise is not None:
             img = noise.to(device=device, dtype=torch.float32).contiguous().clone()
         else:
             img = torch.randn(*shape, device=device, generator=generator)
-        indices = list(range(self.num_timesteps))[::-1]
-        if num_steps is not None:
-            indices = indices[:num_steps]
+        # the schedule: (i, True) = denoise at spaced index i, (i, False) = forward "undo" step with beta[i]
+        if inp is not None and mode == 'ddim' and not getattr(self.opt, 'no_repaint', False):
+            if num_steps is not None:
+                raise ValueError('num_steps truncation is not defined for the resampling schedule')
+            n_ddim = int(str(self.opt.timestep_respacing)[4:])
+            if getattr(self.opt, 'no_resample', False):
+                times = get_schedule_jump_cjm_ddim(n_ddim)
+            else:
+                times = get_schedule_jump_cjm_ddim(n_ddim, jump_length=self.opt.jump_length,
+                                                   jump_n_sample=self.opt.jump_n_sample)
+            if max(times) >= self.num_timesteps:
+                raise ValueError(f'opt.timestep_respacing={self.opt.timestep_respacing!r} starts the resampling loop at '
+                                 f'step {max(times)} of a {self.num_timesteps}-step schedule')
+            plan = [(a, b < a) for a, b in zip(times[:-1], times[1:])]
+        else:
+            indices = list(range(self.num_timesteps))[::-1]
+            if num_steps is not None:
+                indices = indices[:num_steps]
+            plan = [(i, True) for i in indices]
         if progress:
             from tqdm.auto import tqdm
-            indices = tqdm(indices)
+            plan = tqdm(plan)
+        draw_no = [0]
+
+        def draw(i):
+            """the next randn_like(x) of the reference loop; in the outpainting mode several are drawn per step,
+            so there ``step_noise`` is an iterator (or a callable of the running draw number)."""
+            n = draw_no[0]
+            draw_no[0] += 1
+            if step_noise is None:
+                return torch.randn(*shape, device=device, generator=generator)
+            if hasattr(step_noise, '__next__'):
+                e = next(step_noise)
+            elif callable(step_noise):
+                e = step_noise(n if inp is not None else i)
+            else:
+                e = step_noise[i]
+            return e.to(device=device, dtype=torch.float32).contiguous()
+
+        blend_w = None
+        if inp is not None and mode == 'ddim':
+            ov = int(self.opt.overlap_len)
+            if not 0 <= ov <= T:
+                raise ValueError(f'opt.overlap_len={ov} outside the {T}-frame window')
+            blend_w = torch.linspace(0, 1, ov, device=device) if ov > 0 else None
         nxt = torch.empty_like(img)
         x0 = torch.empty_like(img) if trajectory is not None else None
-        for i in indices:
-            if step_noise is None:
-                eps = torch.randn(*shape, device=device, generator=generator)   # drawn every step, DDIM too
+        for i, denoise in plan:
+            if not denoise:                                                   # _undo (:429-435)
+                beta = np.float32(self.betas[i])
+                ctx.renoise(img, draw(i), np.sqrt(np.float32(1) - beta), np.sqrt(beta), out=nxt)
+            elif inp is None:
+                eps = draw(i)                                                 # drawn every step, DDIM too
+                ctx.sample_step(img, i, self.step_coefs(i, mode, model.cfg_scale, eta), eps, x_prev=nxt, x0=x0)
             else:
-                eps = step_noise(i) if callable(step_noise) else step_noise[i]
-                eps = eps.to(device=device, dtype=torch.float32).contiguous()
-            ctx.sample_step(img, i, self.step_coefs(i, mode, model.cfg_scale, eta), eps, x_prev=nxt, x0=x0)
+                eps = draw(i)
+                gt_noise, blend_len = None, 0
+                if mode == 'ddim':
+                    gt_noise = draw(i)                                        # :868
+                    noise_weight = np.sqrt(np.float32(1) - np.float32(self.alphas_cumprod_prev[i]))
+                    if noise_weight < np.float32(0.2) and getattr(self.opt, 'addBlend', True) and blend_w is not None:
+                        blend_len = int(self.opt.overlap_len)                 # :872-875
+                ctx.sample_step_inpaint(img, i, self.step_coefs(i, mode, model.cfg_scale, eta), eps, inp['gt'],
+                                        inp['keep'], gt_noise=gt_noise, blend_w=blend_w, blend_len=blend_len,
+                                        x_prev=nxt, x0=x0)
             img, nxt = nxt, img
             if trajectory is not None:
                 trajectory.append((i, img.clone(), x0.clone()))
@@ -174,9 +246,31 @@ class GaussianDiffusion:
                          step_noise=None, generator=None, num_steps=None, trajectory=None):
         self._check_supported(clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq)
         if self.opt is not None and getattr(self.opt, 'same_overlap_noisy', False):
-            raise NotImplementedError('same_overlap_noisy belongs to the RePaint mode (SURVEY.md section 8f.1)')
+            raise NotImplementedError('opt.same_overlap_noisy: the reference writes self.saved_noisy_tail '
+                                      '(gaussian_diffusion.py:879-881) without ever creating it, so that option has '
+                                      'no defined behaviour to reproduce')
         return self._loop('ddim', model, shape, noise, model_kwargs, device, progress, float(eta), step_noise,
                           generator, num_steps, trajectory)
+
+
+def get_schedule_jump_cjm_ddim(time_respacing=25, jump_length=1, jump_n_sample=1):
+    """Visit order of the resampling ("harmonize") DDIM loop, mirrors mogen/models/utils/scheduler.py:178-208:
+    start 60 % into the schedule (step 15 of 25), walk down to 0, and the first jump_n_sample-1 times a multiple
+    of jump_length (below t_T - jump_length) is reached, walk jump_length steps back up first.  Ends with -1."""
+    t_T = 15 if time_respacing == 25 else int(time_respacing * 0.6)
+    revisits = dict.fromkeys(range(0, t_T - jump_length, jump_length), jump_n_sample - 1)
+    ts, t = [], t_T - 1
+    while t >= 0:
+        ts.append(t)
+        if revisits.get(t, 0) > 0:
+            revisits[t] -= 1
+            ts.extend(range(t + 1, t + jump_length + 1))
+            t += jump_length
+        t -= 1
+    ts.append(-1)
+    if any(abs(a - b) != 1 for a, b in zip(ts[:-1], ts[1:])) or ts[0] >= t_T:
+        raise AssertionError('inconsistent jump schedule')
+    return ts
 
 
 class SpacedDiffusion(GaussianDiffusion):

@@ -139,6 +139,37 @@ class NativeContext:
                                            _ptr(x_prev), _ptr(x0), _stream()), 'mc_sample_step')
         return x_prev
 
+    def sample_step_inpaint(self, x_t, step_index, coefs, noise, gt, keep, gt_noise=None, blend_w=None, blend_len=0,
+                            x_prev=None, x0=None):
+        """RePaint step: ``keep`` is the bool outpainting_mask, ``gt`` the kept motion (both [B,T,C] on the device)."""
+        x = _dev_f32(x_t, 'x_t')
+        n = _dev_f32(noise, 'noise')
+        g = _dev_f32(gt, 'gt')
+        if keep.dtype != torch.bool or not keep.is_cuda or not keep.is_contiguous() or keep.shape != x.shape \
+                or g.shape != x.shape:
+            raise ValueError('outpainting_mask must be a contiguous bool device tensor of the shape of x_t (and gt too)')
+        ip = _lib.Inpaint()
+        ip.gt_dev, ip.keep_dev = g.data_ptr(), keep.data_ptr()
+        gn = _dev_f32(gt_noise, 'gt_noise') if gt_noise is not None else None
+        ip.gt_noise_dev = gn.data_ptr() if gn is not None else None
+        bw = _dev_f32(blend_w, 'blend_w') if blend_len else None
+        ip.blend_w_dev, ip.blend_len = (bw.data_ptr() if bw is not None else None), int(blend_len)
+        if x_prev is None:
+            x_prev = torch.empty_like(x)
+        _lib.check(self.lib.mc_sample_step_inpaint(self.handle, _ptr(x), int(step_index), ctypes.byref(coefs), _ptr(n),
+                                                   ctypes.byref(ip), _ptr(x_prev), _ptr(x0), _stream()),
+                   'mc_sample_step_inpaint')
+        return x_prev
+
+    def renoise(self, x, noise, a, b, out=None):
+        """out = a x + b noise (the forward ``_undo`` step of the resampling schedule)."""
+        x, noise = _dev_f32(x, 'x'), _dev_f32(noise, 'noise')
+        if out is None:
+            out = torch.empty_like(x)
+        _lib.check(self.lib.mc_op_renoise(_ptr(x), _ptr(noise), float(a), float(b), _ptr(out), x.numel(), _stream()),
+                   'mc_op_renoise')
+        return out
+
     def buffer(self, name, layer=0, dtype=torch.float32):
         """Copy of a named workspace buffer (tests)."""
         p = ctypes.c_void_p()

@@ -29,6 +29,12 @@ class StepCoefs(ctypes.Structure):
 
 
 _P = ctypes.c_void_p
+class Inpaint(ctypes.Structure):
+    """mc_inpaint (include/motioncraft_amd.h): model_kwargs['y'] operands of one RePaint step."""
+    _fields_ = [('gt_dev', ctypes.c_void_p), ('keep_dev', ctypes.c_void_p), ('gt_noise_dev', ctypes.c_void_p),
+                ('blend_w_dev', ctypes.c_void_p), ('blend_len', ctypes.c_int32)]
+
+
 _SIGNATURES = {
     'mc_last_error': (ctypes.c_char_p, []),
     'mc_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
@@ -46,6 +52,8 @@ _SIGNATURES = {
     'mc_ctx_set_control': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'mc_denoise': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
     'mc_sample_step': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, _P, _P, _P]),
+    'mc_sample_step_inpaint': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P,
+                                              ctypes.POINTER(Inpaint), _P, _P, _P]),
     'mc_ctx_get_buffer': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P),
                                          ctypes.POINTER(ctypes.c_int64)]),
     'mc_op_gemm': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -53,6 +61,7 @@ _SIGNATURES = {
     'mc_op_ln_rows': (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int32, _P, ctypes.c_int64,
                                      ctypes.c_int32, _P]),
     'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
+    'mc_op_renoise': (ctypes.c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, ctypes.c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

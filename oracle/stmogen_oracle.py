@@ -410,3 +410,68 @@ def sample_loop(p, dims, sched, mode, x_T, xf_out, motion_mask, step_noise=None,
         if trajectory is not None:
             trajectory.append((i, x.clone(), x0.clone()))
     return x
+
+
+# ------------------------------------------------------------------------------------
+# RePaint / outpainting mode of the DDIM loop (long-sequence windows)
+# ------------------------------------------------------------------------------------
+def jump_schedule(time_respacing, jump_length=1, jump_n_sample=1):
+    """scheduler.py:178-208 ``get_schedule_jump_cjm_ddim``: descend from t_T-1 (t_T = 60 % of the DDIM steps, 15 for
+    25 steps) to 0; at every multiple of jump_length below t_T-jump_length climb back jump_length steps
+    (jump_n_sample-1 times).  Returns the visited indices followed by -1."""
+    t_T = 15 if time_respacing == 25 else int(time_respacing * 0.6)
+    budget = {j: jump_n_sample - 1 for j in range(0, t_T - jump_length, jump_length)}
+    t, ts = t_T, []
+    while t >= 1:
+        t -= 1
+        ts.append(t)
+        if budget.get(t, 0) > 0:
+            budget[t] -= 1
+            for _ in range(jump_length):
+                t += 1
+                ts.append(t)
+    ts.append(-1)
+    return ts
+
+
+def ddim_step_repaint(sched, i, x, x0_model, noise, keep, gt, gt_noise, overlap_len, add_blend=True, eta=0.0):
+    """p_mean_variance :492-501 (x0 overwritten by gt on the kept region) + ddim_sample :799-883 (sample on the kept
+    region replaced by gt re-noised to alpha_bar_prev; linear cross-fade over the first overlap_len frames once
+    sqrt(1 - alpha_bar_prev) < 0.2).  ``keep`` is the bool outpainting_mask, ``gt_noise`` the second randn_like."""
+    x0 = x0_model * ~keep + gt * keep
+    sample = ddim_step(sched, i, x, x0, noise, eta)
+    abp = _f32(sched.alphas_cumprod_prev[i])
+    noise_weight = torch.sqrt(1 - abp)
+    weighed_gt = torch.sqrt(abp) * gt + noise_weight * gt_noise
+    if float(noise_weight) < 0.2 and add_blend:
+        lw = torch.linspace(0, 1, overlap_len).view(1, -1, 1).expand(x.shape[0], -1, -1)
+        weighed_gt = weighed_gt.clone()
+        weighed_gt[:, :overlap_len, :] = weighed_gt[:, :overlap_len, :] * (1 - lw) + sample[:, :overlap_len, :] * lw
+    return weighed_gt * keep + sample * ~keep, x0
+
+
+def undo_step(sched, i, x, noise):
+    """_undo :429-435: one forward-diffusion step q(x_{i+1} | x_i) with beta[i]."""
+    beta = _f32(sched.betas[i])
+    return torch.sqrt(1 - beta) * x + torch.sqrt(beta) * noise
+
+
+def sample_loop_repaint(p, dims, sched, x_T, xf_out, motion_mask, keep, gt, draws, overlap_len, time_respacing,
+                        jump_length=3, jump_n_sample=5, no_resample=False, add_blend=True, trajectory=None):
+    """ddim_sample_loop :962-976 -> ddim_sample_loop_progressive_harmonize :1050-1118 (eta=0).
+    ``draws`` yields the randn_like tensors in the order the reference consumes them: two per denoise step
+    (DDIM noise, then the gt re-noising), one per undo step."""
+    times = jump_schedule(time_respacing) if no_resample else jump_schedule(time_respacing, jump_length, jump_n_sample)
+    text_feats = precompute_text(p, xf_out, dims)
+    x = x_T
+    draws = iter(draws)
+    for t_last, t_cur in zip(times[:-1], times[1:]):
+        if t_cur < t_last:
+            x0m = denoise(p, dims, x, sched.timestep_map[t_last], xf_out, motion_mask, text_feats=text_feats)
+            n1, n2 = next(draws), next(draws)
+            x, x0 = ddim_step_repaint(sched, t_last, x, x0m, n1, keep, gt, n2, overlap_len, add_blend)
+        else:
+            x = undo_step(sched, t_last, x, next(draws))
+        if trajectory is not None:
+            trajectory.append((t_last, t_cur, x.clone()))
+    return x

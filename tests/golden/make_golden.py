@@ -21,6 +21,8 @@ Fixtures
   small_ddim.npz        reduced config: 50-step DDIM trajectory (every 10th x_t) + final
   small_ddpm.npz        reduced config: 1000-step schedule, first 20 DDPM steps
   control_small.npz     ControlT2MHalf (copy_blocks_num=2, 35-d condition of 20 frames, NL=3): x0 at t=640, 3
+  repaint_small.npz     RePaint / outpainting DDIM mode (reduced config, first 6 frames kept): harmonize loop with
+                        resampling (jump 3 x 5), without resampling, and no_repaint (plain 50 steps + blending)
   skeleton_parts.npz    8-part layouts: human_ml3d (263-d) and kit_ml (251-d) reduced configs (x0 at two t + 50-step
                         DDIM final), and the shipped T2M_humanml3d.py architecture (L=64, H=8) x0 at t=500
   full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
@@ -248,6 +250,52 @@ def control():
     np.savez_compressed(os.path.join(OUT, 'control_small.npz'), **save)
 
 
+REPAINT_OVERLAP = 6
+
+
+def repaint():
+    """gaussian_diffusion.py:492-501, 855-883, 962-976, 1050-1118; scheduler.py:178-208."""
+    import types
+    dims, B, T = SMALL, 2, 24
+    m, sd = build_ref(dims, SMALL_SEED)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=41, lengths=[24, 21])
+    g = torch.Generator().manual_seed(42)
+    gt = torch.zeros(B, T, dims['input_feats'])
+    gt[:, :REPAINT_OVERLAP] = torch.randn(B, REPAINT_OVERLAP, dims['input_feats'], generator=g)
+    keep = torch.zeros(B, T, dims['input_feats'], dtype=torch.bool)
+    keep[:, :REPAINT_OVERLAP] = True
+    sched = O.Schedule(1000, DIFF_DDIM['respace'])
+    save = dict(x_T=x_T.numpy(), xf_out=xf.numpy(), motion_mask=mask.numpy(), gt=gt.numpy(), keep=keep.numpy(),
+                overlap_len=np.int64(REPAINT_OVERLAP), noise_seed=np.int64(9))
+    for tag, over in (('resample', {}), ('noresample', dict(no_resample=True)), ('norepaint', dict(no_repaint=True))):
+        opt = types.SimpleNamespace(same_overlap_noisy=False, no_repaint=False, addBlend=True, overlap_len=REPAINT_OVERLAP,
+                                    no_resample=False, jump_length=3, jump_n_sample=5, timestep_respacing='ddim50')
+        opt.__dict__.update(over)
+        diff = ref_shim.build_reference_diffusion(DIFF_DDIM, opt)
+        kw = model_kwargs(xf, mask)
+        kw['y'] = dict(gt=gt.clone(), outpainting_mask=keep.clone())
+        torch.manual_seed(9)
+        with torch.no_grad():
+            ref = diff.ddim_sample_loop(m, (B, T, dims['input_feats']), noise=x_T.clone(), clip_denoised=False,
+                                        model_kwargs=kw, eta=0)
+        gen = torch.Generator().manual_seed(9)
+        draws = (torch.randn(B, T, dims['input_feats'], generator=gen) for _ in range(10 ** 6))
+        if opt.no_repaint:
+            x = x_T
+            tf = O.precompute_text(sd, xf, dims)
+            for i in range(49, -1, -1):
+                x0m = O.denoise(sd, dims, x, sched.timestep_map[i], xf, mask, text_feats=tf)
+                x, _ = O.ddim_step_repaint(sched, i, x, x0m, next(draws), keep, gt, next(draws), REPAINT_OVERLAP)
+            orc = x
+        else:
+            orc = O.sample_loop_repaint(sd, dims, sched, x_T, xf, mask, keep, gt, draws, REPAINT_OVERLAP, 50,
+                                        no_resample=opt.no_resample)
+        print(f'repaint {tag}: oracle vs reference {maxabs(ref, orc):.2e}; |kept region - gt| {maxabs(ref[:, :1], gt[:, :1]):.2e}')
+        assert maxabs(ref, orc) <= 1e-5
+        save[f'final_{tag}'] = ref.numpy()
+    np.savez_compressed(os.path.join(OUT, 'repaint_small.npz'), **save)
+
+
 HML_SMALL = W.humanml3d_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
 KIT_SMALL = W.humanml3d_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8, input_feats=251, dataset='kit_ml')
 HML_FULL = W.humanml3d_dims()
@@ -334,7 +382,7 @@ if __name__ == '__main__':
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
-                  skeleton_parts=skeleton_parts, full=full)
+                  repaint=repaint, skeleton_parts=skeleton_parts, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):
             continue

@@ -384,3 +384,40 @@ def test_skeleton_part_layouts_vs_reference_golden():
     assert maxabs(out2[:1] * w + out2[1:] * (1 - w), T_(g['hmlfull_x0_t500_len163'])) <= TOL_STEP
     ctx.close()
     nm.close()
+
+
+def test_repaint_outpainting_mode_vs_reference_golden(small_model):
+    """y = {gt, outpainting_mask} (first 6 frames kept) through ddim_sample_loop: the resampling
+    harmonize loop (jump 3 x 5: 138 denoiser calls + 108 undo steps), no_resample, and no_repaint (plain 50 steps
+    with the per-step gt blend).  Draw order of the reference: DDIM noise, gt re-noising, one per undo."""
+    import types
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = small_model
+    g = load('repaint_small.npz')
+    x_T, xf, mask = T_(g['x_T']), T_(g['xf_out']), T_(g['motion_mask'])
+    gt, keep, ov = T_(g['gt']), T_(g['keep']), int(g['overlap_len'])
+
+    class M:
+        cfg_scale = SMALL['scale']
+
+        def sampling_context(self, B, T, tmap, kw, device=None):
+            self.ctx = nm.context(B, T, max_steps=len(tmap))
+            self.ctx.set_timesteps(tmap)
+            self.ctx.set_condition(kw['xf_out'].cuda(), kw['motion_mask'].cuda())
+            return self.ctx
+    for tag, over in (('resample', {}), ('noresample', dict(no_resample=True)), ('norepaint', dict(no_repaint=True))):
+        opt = types.SimpleNamespace(same_overlap_noisy=False, no_repaint=False, addBlend=True, overlap_len=ov,
+                                    no_resample=False, jump_length=3, jump_n_sample=5, timestep_respacing='ddim50')
+        opt.__dict__.update(over)
+        d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                                 model_var_type='fixed_large', respace='15,15,8,6,6'), opt=opt)
+        gen = torch.Generator().manual_seed(int(g['noise_seed']))
+        draws = (torch.randn(x_T.shape, generator=gen) for _ in range(10 ** 6))
+        m = M()
+        out = d.ddim_sample_loop(m, tuple(x_T.shape), noise=x_T, clip_denoised=False, eta=0, step_noise=draws,
+                                 model_kwargs=dict(xf_out=xf, motion_mask=mask, y=dict(gt=gt, outpainting_mask=keep)))
+        err = maxabs(out, T_(g[f'final_{tag}']))
+        print(f'repaint {tag}: |hip - reference| {err:.2e}')
+        assert err <= TOL_FINAL, tag
+        assert maxabs(out[:, 0], gt[:, 0]) <= 1e-6
+        m.ctx.close()

@@ -118,12 +118,35 @@ def test_sampler_rejects_options_outside_the_path():
                                model_var_type='fixed_large'))
     with pytest.raises(NotImplementedError):
         d.p_sample_loop(None, (1, 24, 322), clip_denoised=True, model_kwargs={})
+    keep = torch.ones(1, 24, 322, dtype=torch.bool)
+    with pytest.raises(ValueError):                 # outpainting mode needs opt (overlap_len, addBlend, ...)
+        d.ddim_sample_loop(None, (1, 24, 322), clip_denoised=False, device='cpu',
+                           model_kwargs={'y': {'outpainting_mask': keep, 'gt': torch.zeros(1, 24, 322)}})
+    with pytest.raises(KeyError):                   # ddim_sample reads y['gt'] whenever the mask has a True
+        d.ddim_sample_loop(None, (1, 24, 322), clip_denoised=False, device='cpu',
+                           model_kwargs={'y': {'outpainting_mask': keep}})
+    import types
+    d2 = D.build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                                model_var_type='fixed_large', respace='15,15,8,6,6'),
+                           opt=types.SimpleNamespace(same_overlap_noisy=True))
     with pytest.raises(NotImplementedError):
-        d.ddim_sample_loop(None, (1, 24, 322), clip_denoised=False,
-                           model_kwargs={'y': {'outpainting_mask': torch.ones(1, dtype=torch.bool)}})
+        d2.ddim_sample_loop(None, (1, 24, 322), clip_denoised=False, model_kwargs={})
     with pytest.raises(NotImplementedError):
         D.build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='epsilon',
                                model_var_type='fixed_large')).p_sample_loop(None, (1, 2, 3), clip_denoised=False)
+
+
+def test_resampling_jump_schedule():
+    """scheduler.py:178-208: starts 60 % into the DDIM schedule, +-1 moves only, every level below the top visited
+    jump_n_sample times on the way down."""
+    from oracle import stmogen_oracle as O
+    for a in ((50,), (50, 3, 5), (25,), (25, 3, 2), (50, 1, 1), (10, 2, 3), (100, 3, 5), (20, 5, 4)):
+        assert D.get_schedule_jump_cjm_ddim(*a) == O.jump_schedule(*a)
+    ts = D.get_schedule_jump_cjm_ddim(50, 3, 5)
+    assert ts[0] == 29 and ts[-2:] == [0, -1] and len(ts) == 247
+    assert sum(1 for a, b in zip(ts[:-1], ts[1:]) if b < a) == 30 + 9 * 4 * 3     # denoiser calls
+    assert D.get_schedule_jump_cjm_ddim(50) == list(range(29, -2, -1))
+    assert D.get_schedule_jump_cjm_ddim(25)[0] == 14
 
 
 def test_weight_packing_layouts():

@@ -149,3 +149,17 @@ def test_skeleton_part_layouts_against_reference_golden():
     sd = W.make_state_dict(HML_FULL, 0)
     x, xf, mask = synth_inputs(HML_FULL, 1, 196, seed=32, lengths=[163])
     assert maxabs(O.denoise(sd, HML_FULL, x, 500, xf, mask), T_(g['hmlfull_x0_t500_len163'])) <= 1e-5
+
+
+def test_repaint_mode_against_reference_golden():
+    """outpainting DDIM loop (resampling jumps 3 x 5) -- oracle vs the reference's ddim_sample_loop."""
+    g = load('repaint_small.npz')
+    sd = W.make_state_dict(SMALL, SMALL_SEED)
+    x_T, xf, mask = T_(g['x_T']), T_(g['xf_out']), T_(g['motion_mask'])
+    gt, keep, ov = T_(g['gt']), T_(g['keep']), int(g['overlap_len'])
+    gen = torch.Generator().manual_seed(int(g['noise_seed']))
+    draws = (torch.randn(x_T.shape, generator=gen) for _ in range(10 ** 6))
+    out = O.sample_loop_repaint(sd, SMALL, O.Schedule(1000, '15,15,8,6,6'), x_T, xf, mask, keep, gt, draws, ov, 50,
+                                no_resample=True)
+    assert maxabs(out, T_(g['final_noresample'])) <= 1e-5
+    assert maxabs(out[:, 0], gt[:, 0]) == 0.0        # frame 0 of the kept region: pure gt at alpha_bar_prev = 1
