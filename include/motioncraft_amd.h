@@ -15,6 +15,7 @@
  *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
  *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
  *   mc_sample_step_inpaint  the same with y = {gt, outpainting_mask}   gaussian_diffusion.py:492-501, 855-877
+ *   mc_postprocess_smplx  de-normalise + SMPL-X re-pack + temporal filter  tools/visualize.py:39-44,217-246; tools/s2g_test.py:289-297
  *   mc_op_renoise         GaussianDiffusion._undo (resampling jumps)   gaussian_diffusion.py:429-435, 1113-1118
  *
  * Conventions: plain pointers and sizes only.  `*_dev` pointers are device (HBM) addresses owned
@@ -136,6 +137,17 @@ int mc_op_ln_rows(const float* x_dev, int64_t ldx, const float* gamma_dev, const
 int mc_op_sampler_update(const float* x_t_dev, const float* out_text_dev, const float* out_none_dev,
                          const float* noise_dev, float* x_prev_dev, float* x0_dev, int64_t n,
                          const mc_step_coefs* coefs, void* stream);
+
+/* Result post-processing of the 322-d motion.  pred_dev [B,T,322] normalised; lengths_dev [B]
+ * int32 valid frames (NULL = T); mean/std_dev [322] fp64; taps_dev [4][MC_POST_MAXTAP] fp64 = normalised Gaussian
+ * taps of the 4 channel groups (body+jaw, hands, trans, expressions) centred at radius[g]; radius[g] < 0 leaves the
+ * group unfiltered.  stats_f32 != 0 de-normalises in fp32 like numpy does with float32 mean/std files.
+ * Outputs fp64: poses [B,T,165], expressions [B,T,100], trans [B,T,3]; frames >= length are 0. */
+#define MC_POST_MAXTAP 129
+int mc_postprocess_smplx(const float* pred_dev, const int32_t* lengths_dev, const double* mean_dev,
+                         const double* std_dev, const double* taps_dev, const int32_t radius[4], int32_t stats_f32,
+                         int32_t B, int32_t T, int32_t C, double* poses_dev, double* expr_dev, double* trans_dev,
+                         void* stream);
 
 /* out = a * x + b * noise over n elements (out may alias x) */
 int mc_op_renoise(const float* x_dev, const float* noise_dev, float a, float b, float* out_dev, int64_t n, void* stream);

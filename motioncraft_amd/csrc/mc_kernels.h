@@ -44,6 +44,13 @@ int mc_launch_sampler_inpaint(const float* x_t, const float* out_text, const flo
                               InpaintArgs ip, float* x_prev, float* x0_out, long n, SamplerCoefs c, hipStream_t s);
 int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s);
 
+// ---- mc_post.hip ----------------------------------------------------------------------
+// de-normalise + 322 -> (poses 165, expressions 100, trans 3) + Gaussian temporal filter (tools/visualize.py:217-246)
+int mc_launch_smplx_post(const float* pred, const int* lengths, const double* mean, const double* stdv,
+                         const double* taps, const int* radius, int stats_f32, int B, int T, int C,
+                         double* poses, double* expr, double* trans, hipStream_t s);
+int mc_smplx_post_maxtap();
+
 // ---- mc_route.hip ---------------------------------------------------------------------
 struct RouteBufs {
     // per (token, choice)

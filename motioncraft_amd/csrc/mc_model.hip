@@ -613,6 +613,16 @@ int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_s
     return mc_launch_sampler_inpaint(x_t, c->out2, c->out2 + n, noise, a, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
 }
 
+int mc_postprocess_smplx(const float* pred, const int32_t* lengths, const double* mean, const double* stdv,
+                         const double* taps, const int32_t radius[4], int32_t stats_f32, int32_t B, int32_t T, int32_t C,
+                         double* poses, double* expr, double* trans, void* stream) {
+    MC_REQUIRE(pred && mean && stdv && taps && radius && poses && expr && trans, "null argument");
+    static_assert(MC_POST_MAXTAP == 129, "header / kernel tap table size");
+    MC_REQUIRE(mc_smplx_post_maxtap() == MC_POST_MAXTAP, "tap table size mismatch");
+    return mc_launch_smplx_post(pred, lengths, mean, stdv, taps, radius, stats_f32, B, T, C, poses, expr, trans,
+                                (hipStream_t)stream);
+}
+
 int mc_op_renoise(const float* x, const float* noise, float a, float b, float* out, int64_t n, void* stream) {
     MC_REQUIRE(x && noise && out && n >= 0, "bad argument");
     return mc_launch_axpby(x, noise, a, b, out, (long)n, (hipStream_t)stream);

@@ -61,10 +61,13 @@ _SIGNATURES = {
     'mc_op_ln_rows': (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int32, _P, ctypes.c_int64,
                                      ctypes.c_int32, _P]),
     'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
+    'mc_postprocess_smplx': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32 * 4), ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
     'mc_op_renoise': (ctypes.c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, ctypes.c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+POST_MAXTAP = 129            # MC_POST_MAXTAP
 
 _lib = None
 

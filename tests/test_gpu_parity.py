@@ -421,3 +421,32 @@ def test_repaint_outpainting_mode_vs_reference_golden(small_model):
         assert err <= TOL_FINAL, tag
         assert maxabs(out[:, 0], gt[:, 0]) <= 1e-6
         m.ctx.close()
+
+
+def test_smplx_postprocessing_vs_scipy_restatement(tmp_path):
+    """de-normalise + 322 -> poses/expressions/trans + scipy gaussian_filter(mode='nearest') on the
+    device, against oracle/postprocess_oracle.py (the reference tools' own numpy/scipy lines), for float32 stats files
+    (motionx) and float64 ones (beats2 / finedance), mixed lengths (filter support clamps at each sample's end)."""
+    from motioncraft_amd import postprocess as P
+    from oracle import postprocess_oracle as PO
+    g = torch.Generator().manual_seed(3)
+    B, T = 3, 196
+    pred = torch.randn(B, T, 322, generator=g)
+    lens = [196, 64, 17]                       # 17 < filter radius (14): heavy edge replication
+    for dt in (np.float32, np.float64):
+        mean = torch.randn(322, generator=g).numpy().astype(dt)
+        std = (0.5 + torch.rand(322, generator=g)).numpy().astype(dt)
+        for sig, fn in ((P.SIGMAS_T2M, PO.t2m_result), (P.SIGMAS_S2G, PO.s2g_result)):
+            post = P.postprocess_smplx(pred.cuda(), lens, mean, std, sig)
+            for b, n in enumerate(lens):
+                pose, expr, trans = fn(pred[b, :n].numpy() * std + mean)
+                tol = 2e-6 if dt == np.float32 else 1e-9       # float32 stats: scipy rounds expr/trans to float32
+                assert np.abs(post['poses'][b, :n].cpu().numpy() - pose).max() <= 1e-9
+                assert np.abs(post['expressions'][b, :n].cpu().numpy() - expr).max() <= tol
+                assert np.abs(post['trans'][b, :n].cpu().numpy() - trans).max() <= tol
+                assert float(post['poses'][b, n:].abs().sum()) == 0.0
+    path = P.save_smplx_npz(str(tmp_path), 'a person walks. fast/slow', pred[:1].cuda(), [120], mean, std)
+    assert os.path.basename(path) == 'res_a_person_walks_fast_slow_120.npz'
+    z = np.load(path)
+    assert z['poses'].shape == (120, 165) and z['expressions'].shape == (120, 100) and z['trans'].shape == (120, 3)
+    assert z['betas'].shape == (300,) and str(z['model']) == 'smplx2020' and int(z['mocap_frame_rate']) == 30

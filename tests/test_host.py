@@ -149,6 +149,19 @@ def test_resampling_jump_schedule():
     assert D.get_schedule_jump_cjm_ddim(25)[0] == 14
 
 
+def test_gaussian_taps_match_scipy():
+    """postprocess.gaussian_taps == the kernel scipy.ndimage.gaussian_filter correlates with (delta response)."""
+    from scipy.ndimage import gaussian_filter
+    from motioncraft_amd.postprocess import gaussian_taps
+    for sigma in (1.0, 2.0, 2.5, 3.0, 3.5):
+        r, w = gaussian_taps(sigma)
+        d = np.zeros(4 * r + 1)
+        d[2 * r] = 1.0
+        resp = gaussian_filter(d, sigma=sigma, mode='nearest')
+        assert r == int(4 * sigma + 0.5) and np.abs(resp[2 * r - r:2 * r + r + 1] - w).max() <= 1e-15
+        assert resp[2 * r - r - 1] == 0.0
+
+
 def test_weight_packing_layouts():
     sd = synthetic.make_state_dict(SMALL, 0)
     p = weights.pack_state_dict({'model.' + k: v for k, v in sd.items()}, SMALL)   # checkpoint prefix stripped
