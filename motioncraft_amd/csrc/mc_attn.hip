@@ -6,6 +6,7 @@
 //               v_mfma_f32_32x32x2_f32, operands staged through LDS
 #include "mc_common.h"
 #include "mc_kernels.h"
+#include <utility>
 
 namespace {
 
@@ -18,6 +19,16 @@ namespace {
 //            with k/q broadcast inside the HD-lane group   (efficient_attention.py:25-46, mask == 1)
 // No LDS, no barriers; every load/store instruction of a wave covers 256 contiguous bytes.
 // ---------------------------------------------------------------------------------------
+template <class F, int... S>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, S...>) {
+    (f(std::integral_constant<int, S>{}), ...);
+}
+// f(integral_constant<int, s>) for s = 0..15: the DPP control word must be an immediate
+template <class F>
+__device__ __forceinline__ void static_for_16(F&& f) {
+    static_for_seq(f, std::make_integer_sequence<int, 16>{});
+}
+
 template <int HD, int H>
 __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, long ldmf, const float* __restrict__ qkv,
                                                    const float* __restrict__ wsm, float* __restrict__ ys, long frames) {
@@ -50,36 +61,61 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
         for (int h = 1; h < H; ++h) m = fmaxf(m, k[h]);
         float s = 0.f;
 #pragma unroll
-        for (int h = 0; h < H; ++h) { k[h] = expf(k[h] - m); s += k[h]; }
+        for (int h = 0; h < H; ++h) { k[h] = fast_exp2((k[h] - m) * LOG2E); s += k[h]; }
+        const float rs = __frcp_rn(s);
 #pragma unroll
-        for (int h = 0; h < H; ++h) k[h] /= s;
+        for (int h = 0; h < H; ++h) k[h] *= rs;
     }
     // query: softmax over the HD channels of the head
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         const float m = group_max(q[h], HD);
-        const float e = expf(q[h] - m);
-        q[h] = e / group_sum(e, HD);
-    }
-    // A[d][l] = sum_h k[h][d] v[h][l]  (this lane: column l, all d)
-    float A[HD];
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        float a = 0.f;
-#pragma unroll
-        for (int h = 0; h < H; ++h) a += __shfl(k[h], d, HD) * v[h];
-        A[d] = a;
+        const float e = fast_exp2((q[h] - m) * LOG2E);
+        q[h] = e * __frcp_rn(group_sum(e, HD));
     }
     float* out = ys + frame * (H * L) + c;
+    if constexpr (HD == 16) {
+        // The head is one DPP row: both contractions over d walk the row by rotation.  With
+        // src(s) = the lane a rotation by s reads, A_[s] = A[d = src(s)][l] and q[h] read through the SAME
+        // rotation pair up again in y[h][l] = sum_s q[h][src(s)] A_[s] -- no lane ever needs to know d.
+        float A_[16];
+        auto contract_kv = [&](auto S) {
+            float a = 0.f;
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-        float st = 0.f;
+            for (int h = 0; h < H; ++h) a += row_ror<decltype(S)::value>(k[h]) * v[h];
+            A_[decltype(S)::value] = a;
+        };
+        static_for_16(contract_kv);
 #pragma unroll
-        for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
-        float dy = 0.f;
+        for (int h = 0; h < H; ++h) {
+            float st = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dy += __shfl(q[h], d, HD) * A[d];
-        out[h * L] = st + (bv[h] + dy);
+            for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
+            float dy = 0.f;
+            auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(q[h]) * A_[decltype(S)::value]; };
+            static_for_16(contract_qa);
+            out[h * L] = st + (bv[h] + dy);
+        }
+    } else {
+        // A[d][l] = sum_h k[h][d] v[h][l]  (this lane: column l, all d)
+        float A[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            float a = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) a += __shfl(k[h], d, HD) * v[h];
+            A[d] = a;
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float st = 0.f;
+#pragma unroll
+            for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
+            float dy = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dy += __shfl(q[h], d, HD) * A[d];
+            out[h * L] = st + (bv[h] + dy);
+        }
     }
 }
 
@@ -94,21 +130,21 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
 // chunk, softmax_L(Q) rows through a [32][L+4] slab read as b128 A fragments.
 // ---------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
+__global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                      const float* __restrict__ mask, float* __restrict__ yt,
                                                      int B, int T, int Nt, int H) {
     constexpr int NT = L / 32;           // 32-wide d tiles (= active waves)
     constexpr int LP = L + 4;
     constexpr int C4 = L / 4;            // float4 columns per row
     constexpr int NSL = 256 / C4;        // row slices in the stats pass
-    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP + 32 * LP];
+    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP];
     float* s_m = sm;
     float* s_s = s_m + L;
     float* s_pm = s_s + L;               // [NSL][L]
     float* s_ps = s_pm + NSL * L;        // [NSL][L]
     float* Ks = s_ps + NSL * L;          // [32][LP]
     float* Vs = Ks + 32 * LP;            // [32][LP]
-    float* Qs = Vs + 32 * LP;            // [32][LP]
+    float* Qs = Ks;                      // [32][LP]  phase 3 reuses the K slab (43 KB total -> 3 workgroups per CU)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -119,24 +155,31 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
     const long D4 = 4 * L;
     const int hf = lane >> 5;
 
-    auto load_kv = [&](int n, int c4, f32x4& kk, f32x4& vv) {
-        if (n < Nt) {
-            const float* r = tf + ((long)b * Nt + n) * 2 * L + c4;
-            kk = *reinterpret_cast<const f32x4*>(r);
-            vv = *reinterpret_cast<const f32x4*>(r + L);
-            const float add = (1.f - cnd) * NEG;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { kk[j] += add; vv[j] *= cnd; }
-        } else {
-            const int t = n - Nt;
-            const float m = mrow[t];
-            const float* r = mf + (((long)b * T + t) * H + h) * D4 + c4;
-            kk = *reinterpret_cast<const f32x4*>(r + L);
-            vv = *reinterpret_cast<const f32x4*>(r + 2 * L);
-            const float add = (1.f - m) * NEG;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { kk[j] += add; vv[j] *= m; }
-        }
+    // Branch-free row fetch: the loads of a batch are issued back to back and nothing touches their
+    // results until finish_kv (mask arithmetic at load time makes the compiler wait per row: one exposed
+    // L2/HBM latency per row).  Row n >= Nseq is clamped (its result is discarded by the caller).
+    auto row_ptr = [&](int n, int c4, int& t) -> const float* {
+        const int nc = n < Nseq ? n : Nseq - 1;
+        const bool txt = nc < Nt;
+        t = txt ? 0 : nc - Nt;
+        const float* rt = tf + ((long)b * Nt + (txt ? nc : 0)) * 2 * L + c4;            // [key | value]
+        const float* rm = mf + (((long)b * T + t) * H + h) * D4 + L + c4;               // [.. | key | value | ..]
+        return txt ? rt : rm;
+    };
+    auto issue_kv = [&](int n, int c4, f32x4& kk, f32x4& vv, float& mv) {
+        int t;
+        const float* r = row_ptr(n, c4, t);
+        kk = *reinterpret_cast<const f32x4*>(r);
+        vv = *reinterpret_cast<const f32x4*>(r + L);
+        const float mm = mrow[t];
+        mv = n < Nt ? cnd : mm;
+    };
+    auto issue_k = [&](int n, int c4, f32x4& kk, float& mv) {
+        int t;
+        const float* r = row_ptr(n, c4, t);
+        kk = *reinterpret_cast<const f32x4*>(r);
+        const float mm = mrow[t];
+        mv = n < Nt ? cnd : mm;
     };
 
     // ---- phase 1: column max / sum over the sequence (softmax dim=1, st_attention.py:155) ----
@@ -144,27 +187,29 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
     // global-load latency per row); one rescale per batch instead of per row
     {
         const int c4 = (tid % C4) * 4, sl = tid / C4;
+        // log2 domain: k2 = k * log2(e); exp(k - m) = exp2(k2 - m2) is one v_exp_f32
         f32x4 m = {-3e38f, -3e38f, -3e38f, -3e38f}, s = {0.f, 0.f, 0.f, 0.f};
         constexpr int BATCH = 8;
         for (int n0 = sl; n0 < Nseq; n0 += NSL * BATCH) {
             f32x4 kk[BATCH];
+            float mv[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) issue_k(n0 + u * NSL, c4, kk[u], mv[u]);
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int n = n0 + u * NSL;
-                kk[u] = f32x4{-3e38f, -3e38f, -3e38f, -3e38f};
-                if (n < Nseq) {
-                    f32x4 vv;
-                    load_kv(n, c4, kk[u], vv);
-                }
+                const bool ok = n0 + u * NSL < Nseq;
+                const float add = (1.f - mv[u]) * NEG;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[u][j] = ok ? (kk[u][j] + add) * LOG2E : -3e38f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float nm = m[j];
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u) nm = fmaxf(nm, kk[u][j]);
-                float acc = s[j] * expf(m[j] - nm);
+                float acc = s[j] * fast_exp2(m[j] - nm);
 #pragma unroll
-                for (int u = 0; u < BATCH; ++u) acc += expf(kk[u][j] - nm);    // exp(-3e38 - nm) = 0 for the padding slots
+                for (int u = 0; u < BATCH; ++u) acc += fast_exp2(kk[u][j] - nm);    // exp2(-3e38 - nm) = 0 for the padding slots
                 s[j] = acc;
                 m[j] = nm;
             }
@@ -177,9 +222,9 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
         float M = -3e38f;
         for (int i = 0; i < NSL; ++i) M = fmaxf(M, s_pm[i * L + tid]);
         float S = 0.f;
-        for (int i = 0; i < NSL; ++i) S += s_ps[i * L + tid] * expf(s_pm[i * L + tid] - M);
-        s_m[tid] = M;
-        s_s[tid] = S;
+        for (int i = 0; i < NSL; ++i) S += s_ps[i * L + tid] * fast_exp2(s_pm[i * L + tid] - M);
+        s_m[tid] = M;                 // column max in the log2 domain
+        s_s[tid] = 1.f / S;           // reciprocal of the column sum
     }
     __syncthreads();
 
@@ -194,14 +239,12 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
     // register prefetch: the K/V rows of chunk ch+1 are requested before the MFMAs of chunk ch
     constexpr int SPT = (32 * C4) / 256;            // float4 (row, column) slots per thread per chunk
     f32x4 pk[SPT], pv[SPT];
+    float pm[SPT];
     auto prefetch_kv = [&](int ch) {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int i = tid + 256 * j;
-            const int n = ch * 32 + i / C4;
-            pk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pv[j] = pk[j];
-            if (n < Nseq) load_kv(n, (i % C4) * 4, pk[j], pv[j]);
+            issue_kv(ch * 32 + i / C4, (i % C4) * 4, pk[j], pv[j], pm[j]);
         }
     };
     prefetch_kv(0);
@@ -211,13 +254,17 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
             const int i = tid + 256 * j;
             const int row = i / C4, c4 = (i % C4) * 4;
             const int n = ch * 32 + row;
-            f32x4 e = {0.f, 0.f, 0.f, 0.f};
+            f32x4 e = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
             if (n < Nseq) {
+                const float add = (1.f - pm[j]) * NEG;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = expf(pk[j][q] - s_m[c4 + q]) / s_s[c4 + q];
+                for (int q = 0; q < 4; ++q) {
+                    e[q] = fast_exp2(fmaf(pk[j][q] + add, LOG2E, -s_m[c4 + q])) * s_s[c4 + q];
+                    v[q] = pv[j][q] * pm[j];
+                }
             }
             *reinterpret_cast<f32x4*>(Ks + row * LP + c4) = e;
-            *reinterpret_cast<f32x4*>(Vs + row * LP + c4) = pv[j];
+            *reinterpret_cast<f32x4*>(Vs + row * LP + c4) = v;
         }
         __syncthreads();
         if (ch + 1 < nch) prefetch_kv(ch + 1);
@@ -268,13 +315,13 @@ __global__ __launch_bounds__(256, 2) void temporal_k(const float* __restrict__ m
             float s = 0.f;
             if (t < T) {
 #pragma unroll
-                for (int j = 0; j < SEG; ++j) { qv[j] = expf(qv[j] - mx); s += qv[j]; }
+                for (int j = 0; j < SEG; ++j) { qv[j] = fast_exp2((qv[j] - mx) * LOG2E); s += qv[j]; }
             }
-            s = group_sum(s, 8);
+            s = 1.f / group_sum(s, 8);
 #pragma unroll
             for (int j = 0; j < SEG; j += 4) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                if (t < T) o = f32x4{qv[j] / s, qv[j + 1] / s, qv[j + 2] / s, qv[j + 3] / s};
+                if (t < T) o = f32x4{qv[j] * s, qv[j + 1] * s, qv[j + 2] * s, qv[j + 3] * s};
                 *reinterpret_cast<f32x4*>(Qs + qrow * LP + qsub * SEG + j) = o;
             }
         }

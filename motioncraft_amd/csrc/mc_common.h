@@ -37,6 +37,10 @@ void mc_set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device math --------------------------------------------------------------------
+constexpr float LOG2E = 1.44269504088896340736f;
+// 2^x as the bare v_exp_f32 (1 ulp, flushes results below 2^-126 to 0): softmax numerators exp(x - max) are
+// evaluated as fast_exp2(x * LOG2E - max * LOG2E), 2 VALU instructions instead of the ~20 of expf
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float gelu_exact(float x) {
     // nn.GELU() default / F.gelu: x * Phi(x), Phi(x) = 0.5 (1 + erf(x / sqrt 2)).
     // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level; the resulting
@@ -63,13 +67,39 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// reductions across `width` consecutive lanes (width power of two <= 64)
+// DPP cross-lane reads (gfx9 encodings): a modifier on the consuming VALU op, no LDS round trip --
+// __shfl / __shfl_xor compile to ds_bpermute_b32 + s_waitcnt, ~50x the cost.
+//   quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141,
+//   row_ror:n = 0x120 + n (rotate within each row of 16 lanes)
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ float row_ror(float x) {
+    if constexpr (N == 0) return x;
+    else return dpp_read<0x120 + N>(x);
+}
+
+// all-reduce across `width` consecutive lanes (width a power of two <= 64, groups aligned to width): the
+// butterfly steps below 16 lanes are DPP (after the xor-1 and xor-2 steps a quad is uniform, so the mirrors
+// act as xor-4 / xor-8); only the 16- and 32-lane steps go through the LDS crossbar.
 __device__ __forceinline__ float group_sum(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (width >= 2) v += dpp_read<0xB1>(v);
+    if (width >= 4) v += dpp_read<0x4E>(v);
+    if (width >= 8) v += dpp_read<0x141>(v);
+    if (width >= 16) v += dpp_read<0x140>(v);
+    if (width >= 32) v += __shfl_xor(v, 16, 64);
+    if (width >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float group_max(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (width >= 2) v = fmaxf(v, dpp_read<0xB1>(v));
+    if (width >= 4) v = fmaxf(v, dpp_read<0x4E>(v));
+    if (width >= 8) v = fmaxf(v, dpp_read<0x141>(v));
+    if (width >= 16) v = fmaxf(v, dpp_read<0x140>(v));
+    if (width >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (width >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
