@@ -155,14 +155,12 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
     const int kq = (lane >> 5) * 4;
     f32x4 xf[NJ];
     {
-        long srow = row0 + r;
+        long srow = rok ? row0 + r : row0;
         if constexpr (MODE == MLP_EXPERT) srow = rok ? g.src_row[row0 + r] : 0;
         const float* xp = g.X + (long)grp * g.x_gstride + srow * g.ldx + kq;
+        // (rows past nrows read a valid row -- srow 0 / the last row of the matrix -- and are never stored)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            xf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rok) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
-        }
+        for (int j = 0; j < NJ; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
     }
     f32x16 acc2[NT];
 #pragma unroll
@@ -256,22 +254,23 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
     // z = LN(x) * gamma + beta + embedding[(t,h)]
     f32x4 zf[NJ];
     {
-        const float* xp = g.X + tok * g.ldx + kq;
+        // rows past N read row N-1 instead (never stored): loads under `if (rok)` cost one exposed latency each
+        const long tk = rok ? tok : g.N - 1;
+        const float* xp = g.X + tk * g.ldx + kq;
+        const float* ep = g.emb + (tk % g.emb_mod) * L + kq;
+        f32x4 ef[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            zf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rok) zf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+            zf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+            ef[j] = *reinterpret_cast<const f32x4*>(ep + 8 * j);
         }
         frag_layernorm<NJ>(zf, g.gamma, g.beta, kq);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) zf[j] += ef[j];
         if (rok) {
-            const float* ep = g.emb + (tok % g.emb_mod) * L + kq;
             float* zp = g.Z + tok * L + kq;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const f32x4 e = *reinterpret_cast<const f32x4*>(ep + 8 * j);
-                zf[j] += e;
-                *reinterpret_cast<f32x4*>(zp + 8 * j) = zf[j];
-            }
+            for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(zp + 8 * j) = zf[j];
         }
     }
     // p = z Wp^T + bp in 8 chunks of 32 columns; |p|^2 on the VALU, p . sim_n chained on the MFMA
@@ -375,23 +374,28 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     const int kq = (lane >> 5) * 4;
     f32x4 xf[NJ];
     if constexpr (KIND == 0) {
-        const float w0 = rok ? g.comb_w[2 * tok] : 0.f, w1 = rok ? g.comb_w[2 * tok + 1] : 0.f;
-        const float* y0 = g.X + 2 * tok * L + kq;
+        const long tk = rok ? tok : 0;
+        const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
+        const float* y0 = g.X + 2 * tk * L + kq;
+        // all 2*NJ row loads are issued unconditionally and back to back (a load under `if (w != 0)` makes the
+        // compiler wait for each one in its own basic block); rows of dropped choices were never written, so
+        // their (possibly NaN) contents are discarded by a select, not multiplied by 0
+        f32x4 ya[NJ], yb[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (w0 != 0.f) a = *reinterpret_cast<const f32x4*>(y0 + 8 * j);        // dropped choices were never written
-            if (w1 != 0.f) b = *reinterpret_cast<const f32x4*>(y0 + L + 8 * j);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xf[j][i] = gelu_exact(w0 * a[i] + w1 * b[i]);
+            ya[j] = *reinterpret_cast<const f32x4*>(y0 + 8 * j);
+            yb[j] = *reinterpret_cast<const f32x4*>(y0 + L + 8 * j);
         }
+        const bool k0 = w0 != 0.f, k1 = w1 != 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[j][i] = gelu_exact((k0 ? w0 * ya[j][i] : 0.f) + (k1 ? w1 * yb[j][i] : 0.f));
     } else {
-        const float* xp = g.X + tok * g.ldx + kq;
+        // rows past N read row N-1 instead (never stored): a load under `if (rok)` costs one exposed latency per j
+        const float* xp = g.X + (rok ? tok : g.N - 1) * g.ldx + kq;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            xf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rok) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
-        }
+        for (int j = 0; j < NJ; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
         frag_layernorm<NJ>(xf, g.gamma, g.beta, kq);
     }
     const int nc = g.Nout / 32;
@@ -401,16 +405,22 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     if (nc > 1) sp.fetch(g.W, L, 32, 0, tid);
     __syncthreads();
     float* orow = g.Y + tok * g.ldy + kq;
+    // Order inside an iteration: MFMAs(c) -> commit(c+1) -> stores(c) -> fetch(c+2).  gfx9 counts loads and
+    // stores in ONE in-order vmcnt, and the wait the compiler places before the commit must be valid on the
+    // loop-entry path too, so it always drains everything issued before the fetch it waits for.  With the fetch
+    // issued AFTER the stores of the same iteration, what gets drained is one MFMA phase old (free); with the
+    // fetch issued before them (the obvious order) every chunk stalls on the write latency of its own stores.
     for (int c = 0; c < nc; ++c) {
-        if (c + 1 < nc) sp.commit(Ws((c & 1) ^ 1), tid);
-        if (c + 2 < nc) sp.fetch(g.W, L, (c + 2) * 32, 0, tid);
         const f32x16 a = chunk_mma<NJ>(Ws(c & 1), xf, lane);
+        if (c + 1 < nc) sp.commit(Ws((c & 1) ^ 1), tid);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + c * 32 + 8 * q + kq);
             const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]};
             if (rok) *reinterpret_cast<f32x4*>(orow + c * 32 + 8 * q) = v;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nc) sp.fetch(g.W, L, (c + 2) * 32, 0, tid);
         __syncthreads();
     }
 }
