@@ -15,6 +15,7 @@
  *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
  *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
  *   mc_sample_step_inpaint  the same with y = {gt, outpainting_mask}   gaussian_diffusion.py:492-501, 855-877
+ *   mc_wavenc_*           WavEncoder (audio condition pre-encoder)     mogen/models/utils/blocks.py:11-71; controlnet.py:90-105,187
  *   mc_postprocess_smplx  de-normalise + SMPL-X re-pack + temporal filter  tools/visualize.py:39-44,217-246; tools/s2g_test.py:289-297
  *   mc_op_renoise         GaussianDiffusion._undo (resampling jumps)   gaussian_diffusion.py:429-435, 1113-1118
  *
@@ -148,6 +149,18 @@ int mc_postprocess_smplx(const float* pred_dev, const int32_t* lengths_dev, cons
                          const double* std_dev, const double* taps_dev, const int32_t radius[4], int32_t stats_f32,
                          int32_t B, int32_t T, int32_t C, double* poses_dev, double* expr_dev, double* trans_dev,
                          void* stream);
+
+/* ---- WavEncoder: step-invariant audio condition encoder of the speech-to-gesture configs ------------------ */
+typedef struct mc_wavenc mc_wavenc;
+int mc_wavenc_create(int32_t audio_in, int32_t out_dim, mc_wavenc** out);
+void mc_wavenc_destroy(mc_wavenc* e);
+/* BatchNorm-folded, tap-major conv weights from host memory: "b{i}.conv1.w" [planes][ceil4(15*cin)], "b{i}.conv1.b",
+ * "b{i}.conv2.w" [planes][15*planes], "b{i}.conv2.b", "b{i}.down.w", "b{i}.down.b" (blocks 0,1,3,5), i = 0..5 */
+int mc_wavenc_set_param(mc_wavenc* e, const char* name, const float* host, int64_t numel);
+int mc_wavenc_finalize(mc_wavenc* e);
+int mc_wavenc_out_len(const mc_wavenc* e, int32_t samples, int32_t* frames);
+/* wav_dev [B, samples, audio_in] -> out_dev [B, frames, out_dim] (channels-last, like WavEncoder.forward's return) */
+int mc_wavenc_forward(mc_wavenc* e, const float* wav_dev, int32_t B, int32_t samples, float* out_dev, void* stream);
 
 /* out = a * x + b * noise over n elements (out may alias x) */
 int mc_op_renoise(const float* x_dev, const float* noise_dev, float a, float b, float* out_dev, int64_t n, void* stream);

@@ -23,7 +23,9 @@ struct GemmArgs {
     long c_gstride = 0;
     const float* R = nullptr;
     long ldr = 0;
+    long r_gstride = -1;         // group stride of R (-1: same as c_gstride)
     int act = 0;
+    int act_after_res = 0;       // 0: act(acc + bias) + R    1: act(acc + bias + R)   (residual conv blocks)
     const float* add = nullptr;  // C += add[(r % add_mod) * ld_add + n]
     int add_mod = 1;
     long ld_add = 0;

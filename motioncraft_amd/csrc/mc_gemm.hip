@@ -158,7 +158,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, int grp, int row
                                              int lane, f32x16 (&acc)[2][2]) {
     const float* __restrict__ bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
     float* __restrict__ Cb = g.C + (long)grp * g.c_gstride + g.c_col;
-    const float* __restrict__ Rb = g.R ? g.R + (long)grp * g.c_gstride + g.c_col : nullptr;
+    const float* __restrict__ Rb = g.R ? g.R + (long)grp * (g.r_gstride >= 0 ? g.r_gstride : g.c_gstride) + g.c_col : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int m = wm * 64 + mi * 32 + (lane & 31);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, int grp, int row
         float* crow = Cb + drow * g.ldc;
         const float* rrow = Rb ? Rb + drow * g.ldr : nullptr;
         const float* arow = nullptr;
-        if constexpr (MODE == GM_ENC) arow = g.add + (long)((row0 + m) % g.add_mod) * g.ld_add;
+        if constexpr (MODE == GM_ENC) arow = g.add ? g.add + (long)((row0 + m) % g.add_mod) * g.ld_add : nullptr;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -177,12 +177,17 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, int grp, int row
                 if (GUARD && n >= g.N) continue;
                 f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
                 if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+                if (g.act_after_res && rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
-                if constexpr (MODE == GM_ENC) v += *reinterpret_cast<const f32x4*>(arow + n);
-                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+                if constexpr (MODE == GM_ENC) {
+                    if (arow) v += *reinterpret_cast<const f32x4*>(arow + n);
+                }
+                if (!g.act_after_res && rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
                 *reinterpret_cast<f32x4*>(crow + n) = v;
-                if constexpr (MODE == GM_ENC) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
+                if constexpr (MODE == GM_ENC) {
+                    if (g.dup_rows) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
+                }
             }
         }
     }
@@ -194,7 +199,7 @@ __device__ __forceinline__ void epilogue_scalar(const GemmArgs& g, int grp, int 
                                                 int lane, f32x16 (&acc)[2][2]) {
     const float* __restrict__ bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
     float* __restrict__ Cb = g.C + (long)grp * g.c_gstride + g.c_col;
-    const float* __restrict__ Rb = g.R ? g.R + (long)grp * g.c_gstride + g.c_col : nullptr;
+    const float* __restrict__ Rb = g.R ? g.R + (long)grp * (g.r_gstride >= 0 ? g.r_gstride : g.c_gstride) + g.c_col : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int m = wm * 64 + mi * 32 + (lane & 31);
@@ -209,8 +214,9 @@ __device__ __forceinline__ void epilogue_scalar(const GemmArgs& g, int grp, int 
                 if (n >= g.N) continue;
                 float v = acc[mi][ni][reg];
                 if (bias) v += bias[n];
+                if (g.act_after_res && Rb) v += Rb[drow * g.ldr + n];
                 v = apply_act(v, g.act);
-                if (Rb) v += Rb[drow * g.ldr + n];
+                if (!g.act_after_res && Rb) v += Rb[drow * g.ldr + n];
                 Cb[drow * g.ldc + n] = v;
             }
         }
@@ -292,16 +298,18 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
     }
 
     const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_col % 4 == 0) && (g.c_gstride % 4 == 0) &&
-                     (!g.R || g.ldr % 4 == 0);
+                     (!g.R || (g.ldr % 4 == 0 && (g.r_gstride < 0 || g.r_gstride % 4 == 0)));
     if (!vec) {
         epilogue_scalar<MODE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
     } else if (full) {
         if (g.act == ACT_GELU) epilogue_vec<MODE, false, ACT_GELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else if (g.act == ACT_SILU) epilogue_vec<MODE, false, ACT_SILU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else if (g.act == ACT_LRELU) epilogue_vec<MODE, false, ACT_LRELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else epilogue_vec<MODE, false, ACT_NONE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
     } else {
         if (g.act == ACT_GELU) epilogue_vec<MODE, true, ACT_GELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else if (g.act == ACT_SILU) epilogue_vec<MODE, true, ACT_SILU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else if (g.act == ACT_LRELU) epilogue_vec<MODE, true, ACT_LRELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else epilogue_vec<MODE, true, ACT_NONE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
     }
 }

@@ -63,6 +63,12 @@ _SIGNATURES = {
     'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
     'mc_postprocess_smplx': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32 * 4), ctypes.c_int32,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    'mc_wavenc_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    'mc_wavenc_destroy': (None, [_P]),
+    'mc_wavenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),
+    'mc_wavenc_finalize': (ctypes.c_int, [_P]),
+    'mc_wavenc_out_len': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    'mc_wavenc_forward': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
     'mc_op_renoise': (ctypes.c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, ctypes.c_int64, _P]),
 }
 

@@ -81,7 +81,8 @@ class STMoGenTransformer:
         self._native = None
         self._ctx = {}
         self._state = None
-        self._control = None            # set by ControlT2MHalf: dict(copy_blocks_num, cond_feats, condition_cfg, pre_encode)
+        self._control = None            # set by ControlT2MHalf: dict(copy_blocks_num, cond_feats, raw_feats, condition_cfg, pre_encode)
+        self._wavenc = None
 
     # ---- nn.Module-ish surface used by the tools ---------------------------------------------
     def eval(self):
@@ -116,6 +117,9 @@ class STMoGenTransformer:
         if self._native is not None:
             self._native.close()
         self._native = None
+        if self._wavenc is not None:
+            self._wavenc.close()
+        self._wavenc = None
 
     # ---- native plumbing ------------------------------------------------------------------------
     @property
@@ -130,15 +134,36 @@ class STMoGenTransformer:
                                    f"{self._control['copy_blocks_num']}")
         return self._native
 
+    WAV_KEY = 'condition_pre_encoder.pre_encoder.feat_extractor.'
+
+    @property
+    def wav_encoder(self):
+        """ConditionEncoder -> WavEncoder (controlnet.py:90-105) built from the checkpoint's own keys, on the device."""
+        if self._wavenc is None:
+            from .wav_encoder import NativeWavEncoder
+            if self._state is None:
+                raise RuntimeError('load_state_dict() has not been called: no weights to run')
+            hit = [k for k in self._state if self.WAV_KEY in k]
+            if not hit:
+                raise RuntimeError(f"condition_pre_encode=True but the checkpoint has no '{self.WAV_KEY}*' weights")
+            prefix = hit[0][:hit[0].index(self.WAV_KEY) + len(self.WAV_KEY)]
+            self._wavenc = NativeWavEncoder(self._control['cond_feats'], self._control['raw_feats'], self._state, prefix)
+        return self._wavenc
+
     def _encode_control(self, c, dev):
-        """The step-invariant condition pre-encoder sits before the path (WavEncoder for BEAT2 audio,
-        identity for FineDance music features): the library consumes its OUTPUT."""
+        """The step-invariant condition pre-encoder (ControlT2MHalf.forward_c line 1, controlnet.py:187): WavEncoder
+        for BEAT2 audio (raw [B, samples, audio_in] -> [B, frames, D]), identity for FineDance music features."""
         c = c.to(device=dev, dtype=torch.float32).contiguous()
+        if self._control.get('pre_encode'):
+            if c.dim() == 2:
+                c = c.unsqueeze(-1)
+            if c.dim() != 3 or c.shape[-1] != self._control['raw_feats']:
+                raise ValueError(f"raw audio condition of shape {tuple(c.shape)}: expected [B, samples, "
+                                 f"{self._control['raw_feats']}]")
+            c = self.wav_encoder(c)
         want = self.native.control_cond_feats
         if c.dim() != 3 or c.shape[-1] != want:
-            raise NotImplementedError(
-                f'control condition of shape {tuple(c.shape)}: expected [B, Tc, {want}] = the output of the condition '
-                'pre-encoder (raw audio needs the reference WavEncoder first; SURVEY.md section 8f.2)')
+            raise ValueError(f'control condition of shape {tuple(c.shape)}: expected [B, Tc, {want}]')
         return c
 
     def sampling_context(self, B, T, timestep_map, model_kwargs, device=None):
@@ -214,8 +239,8 @@ class ControlT2MHalf:
     """Mirror of the reference's plug-and-play control wrapper (controlnet.py:107-439):
     ``model.model = ControlT2MHalf(model.model, copy_blocks_num, control_cond_feats, cfg)`` as in
     tools/s2g_test.py:592-601 and tools/m2d_test.py:372-381.  The copied DecoderLayers, the zero-init
-    before/after projections and ``control_cond_input`` run inside the library; the condition
-    pre-encoder (WavEncoder) is step-invariant and stays outside the per-step path."""
+    before/after projections and ``control_cond_input`` run inside the library; the step-invariant condition
+    pre-encoder (WavEncoder) runs once per condition through ``mc_wavenc_forward``."""
 
     def __init__(self, base_model, copy_blocks_num=2, control_cond_feats=438, cfg=None, joint_embed_unfreeze=True,
                  unfreeze_mode='all'):
@@ -230,8 +255,11 @@ class ControlT2MHalf:
         self.base_model = base_model
         self.copy_blocks_num = copy_blocks_num
         pre = bool(ce.get('condition_pre_encode', False))
+        if pre and (ce.get('dataset_name') != 'beats2' or ce.get('condition_pre_encode_type') != 'wav'):
+            raise NotImplementedError("condition_pre_encode: the reference only defines dataset_name='beats2' with "
+                                      "condition_pre_encode_type='wav' (controlnet.py:93-99)")
         feats = ce.get('condition_latent_dim', base_model.latent_dim) if pre else control_cond_feats
-        base_model._control = dict(copy_blocks_num=copy_blocks_num, cond_feats=feats,
+        base_model._control = dict(copy_blocks_num=copy_blocks_num, cond_feats=feats, raw_feats=control_cond_feats,
                                    condition_cfg=bool(ce.get('condition_cfg', False)), pre_encode=pre)
         self.cfg = cfg
         self.training = False

@@ -159,6 +159,27 @@ def param_shapes(dims):
     return s
 
 
+def control_wav_param_shapes(dims, copy_blocks_num, audio_in):
+    """ControlT2MHalf with condition_pre_encode=True / 'wav' (S2G): control_cond_input takes the WavEncoder's D-wide
+    output and the encoder's own parameters sit under condition_pre_encoder.pre_encoder.feat_extractor."""
+    from .wav_encoder import wav_encoder_param_shapes
+    D = dims['L'] * dims['H']
+    s = control_param_shapes(dims, copy_blocks_num, D)
+    for k, v in wav_encoder_param_shapes(D, audio_in).items():
+        s['condition_pre_encoder.pre_encoder.feat_extractor.' + k] = v
+    return s
+
+
+def make_control_wav_state(dims, copy_blocks_num, audio_in, seed=0):
+    shapes = control_wav_param_shapes(dims, copy_blocks_num, audio_in)
+    pre = 'condition_pre_encoder.pre_encoder.feat_extractor.'
+    wav = make_wav_encoder_state(dims['L'] * dims['H'], audio_in, seed)
+    sd = OrderedDict()
+    for k, v in shapes.items():
+        sd[k] = wav[k[len(pre):]] if k.startswith(pre) else make_param(seed, k, tuple(v))
+    return sd
+
+
 def control_param_shapes(dims, copy_blocks_num, cond_feats):
     """Extra state-dict entries of ``ControlT2MHalf`` (reference controlnet.py:107-183) for the
     ``condition_pre_encode=False`` form (pre-encoded / raw feature condition of width ``cond_feats``).
@@ -211,6 +232,25 @@ def make_param(seed, name, shape):
             scale *= 0.5
         return scale * r
     raise KeyError(name)
+
+
+def make_wav_encoder_state(out_dim, audio_in, seed=0):
+    """Deterministic non-trivial WavEncoder weights (BatchNorm running stats included) keyed like the reference."""
+    from .wav_encoder import wav_encoder_param_shapes
+    sd = OrderedDict()
+    for k, shape in wav_encoder_param_shapes(out_dim, audio_in).items():
+        r = _randn(seed, 'wav.' + k, shape) if shape else torch.zeros(())
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.tensor(100, dtype=torch.long)
+        elif k.endswith('running_var'):
+            sd[k] = 0.5 + r.abs()
+        elif k.endswith('running_mean') or k.endswith('.bias'):
+            sd[k] = 0.1 * r
+        elif 'bn' in k or 'downsample.1' in k:      # BatchNorm gamma
+            sd[k] = 1.0 + 0.1 * r
+        else:                                        # conv weight [Cout, Cin, 15]: keep activations O(1)
+            sd[k] = r / math.sqrt(shape[1] * shape[2])
+    return sd
 
 
 def make_state_dict(dims, seed=0, shapes=None):

@@ -138,8 +138,9 @@ def build_reference_denoiser(model_cfg):
     return m
 
 
-def build_reference_control(model_cfg, copy_blocks_num, control_cond_feats, condition_cfg=True):
-    """ControlT2MHalf around a reference base model, condition_pre_encode=False."""
+def build_reference_control(model_cfg, copy_blocks_num, control_cond_feats, condition_cfg=True, wav_pre_encode=False):
+    """ControlT2MHalf around a reference base model: condition_pre_encode=False (M2D form, raw
+    feature condition) or, with ``wav_pre_encode``, the S2G form (dataset 'beats2', WavEncoder on raw audio)."""
     import torch.nn as _nn
     install()
     ctl = importlib.import_module('mogen.models.transformers.controlnet')
@@ -150,8 +151,10 @@ def build_reference_control(model_cfg, copy_blocks_num, control_cond_feats, cond
     class _Cfg(dict):
         __getattr__ = dict.__getitem__
     mcfg = _Cfg(model=_Cfg(model=_Cfg({k: v for k, v in dict(model_cfg).items()})),
-                condition_encode_cfg=_Cfg(dataset_name='nothing', condition_pre_encode=False,
-                                          condition_pre_encode_type='nothing', control_cond_feats=control_cond_feats,
+                condition_encode_cfg=_Cfg(dataset_name='beats2' if wav_pre_encode else 'nothing',
+                                          condition_pre_encode=bool(wav_pre_encode),
+                                          condition_pre_encode_type='wav' if wav_pre_encode else 'nothing',
+                                          control_cond_feats=control_cond_feats,
                                           condition_latent_dim=model_cfg['latent_dim'], condition_cfg=condition_cfg))
     m = ctl.ControlT2MHalf(base, copy_blocks_num=copy_blocks_num, control_cond_feats=control_cond_feats, cfg=mcfg)
     m.eval()

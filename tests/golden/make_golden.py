@@ -23,8 +23,10 @@ Fixtures
   control_small.npz     ControlT2MHalf (copy_blocks_num=2, 35-d condition of 20 frames, NL=3): x0 at t=640, 3
   repaint_small.npz     RePaint / outpainting DDIM mode (reduced config, first 6 frames kept): harmonize loop with
                         resampling (jump 3 x 5), without resampling, and no_repaint (plain 50 steps + blending)
+  wav_encoder.npz       WavEncoder(out_dim=64, audio_in=2), eval mode: 2 x 4000 samples -> reference output
   skeleton_parts.npz    8-part layouts: human_ml3d (263-d) and kit_ml (251-d) reduced configs (x0 at two t + 50-step
                         DDIM final), and the shipped T2M_humanml3d.py architecture (L=64, H=8) x0 at t=500
+  control_wav_small.npz ControlT2MHalf S2G form: condition_pre_encode='wav' (WavEncoder on 9000 x 2 raw audio -> 17 frames)
   full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
   full_ddim.npz         0.125b config, B=1: final sample of the 50-step DDIM loop
 """
@@ -250,6 +252,36 @@ def control():
     np.savez_compressed(os.path.join(OUT, 'control_small.npz'), **save)
 
 
+WAV_DIM, WAV_IN, WAV_SAMPLES = 64, 2, 4000
+
+
+def wav_encoder():
+    """the reference class itself (mogen/models/utils/blocks.py:56-71), eval mode."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_blocks', os.path.join(ref_shim.REF, 'mogen/models/utils/blocks.py'))
+    blocks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(blocks)
+    from oracle import wav_encoder_oracle as WO
+    from motioncraft_amd.wav_encoder import wav_encoder_param_shapes
+    m = blocks.WavEncoder(out_dim=WAV_DIM, audio_in=WAV_IN)
+    shapes = wav_encoder_param_shapes(WAV_DIM, WAV_IN)
+    ref_sd = m.feat_extractor.state_dict()
+    assert set(ref_sd) == set(shapes), sorted(set(ref_sd) ^ set(shapes))[:8]
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sd = W.make_wav_encoder_state(WAV_DIM, WAV_IN, seed=3)
+    m.feat_extractor.load_state_dict(sd)
+    m.eval()
+    g = torch.Generator().manual_seed(51)
+    wav = torch.randn(2, WAV_SAMPLES, WAV_IN, generator=g)
+    with torch.no_grad():
+        ref = m(wav)
+    orc = WO.wav_encoder(sd, wav)
+    print(f'wav_encoder: out {tuple(ref.shape)}, |out| mean {float(ref.abs().mean()):.3f}; oracle vs reference {maxabs(ref, orc):.2e}')
+    assert maxabs(ref, orc) <= 1e-6
+    np.savez_compressed(os.path.join(OUT, 'wav_encoder.npz'), wav=wav.numpy(), out=ref.numpy(), seed=np.int64(3))
+
+
 REPAINT_OVERLAP = 6
 
 
@@ -335,6 +367,34 @@ def skeleton_parts():
     np.savez_compressed(os.path.join(OUT, 'skeleton_parts.npz'), **save)
 
 
+CTRL_WAV_IN, CTRL_WAV_SAMPLES = 2, 9000
+
+
+def control_wav():
+    """S2G form of the control branch (configs/stmogen/S2G_*: condition_pre_encode=True, type 'wav', beats2)."""
+    from oracle import wav_encoder_oracle as WO
+    dims, B, T = CTRL, 2, 24
+    m = ref_shim.build_reference_control(W.reference_model_cfg(dims), CTRL_COPY, CTRL_WAV_IN, wav_pre_encode=True)
+    shapes = W.control_wav_param_shapes(dims, CTRL_COPY, CTRL_WAV_IN)
+    assert set(m.state_dict().keys()) == set(shapes.keys()), sorted(set(m.state_dict()) ^ set(shapes))[:8]
+    sd = W.make_control_wav_state(dims, CTRL_COPY, CTRL_WAV_IN, SMALL_SEED)
+    torch.nn.Module.load_state_dict(m, sd)
+    m.eval()
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=15, lengths=[24, 19])
+    g = torch.Generator().manual_seed(16)
+    audio = torch.randn(B, CTRL_WAV_SAMPLES, CTRL_WAV_IN, generator=g)
+    with torch.no_grad():
+        ref = m(x_T, torch.full((B,), 420), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+                num_intervals=1, c=audio, xf_out=xf, y={}, patch_size=1, sample_idx=None)
+    pre = 'condition_pre_encoder.pre_encoder.feat_extractor.'
+    c_enc = WO.wav_encoder({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, audio)
+    out = O.denoise_control({k: v for k, v in sd.items() if not k.startswith(pre)}, dims, x_T, 420, xf, mask, c_enc, CTRL_COPY)
+    print(f'control_wav: WavEncoder frames {c_enc.shape[1]}; oracle vs reference {maxabs(ref, out):.2e}')
+    assert maxabs(ref, out) <= 1e-5
+    np.savez_compressed(os.path.join(OUT, 'control_wav_small.npz'), x_t=x_T.numpy(), xf_out=xf.numpy(),
+                        motion_mask=mask.numpy(), audio=audio.numpy(), x0_t420=ref.numpy())
+
+
 def full():
     dims, B, T = FULL, 1, 196
     t0 = time.time()
@@ -382,7 +442,7 @@ if __name__ == '__main__':
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
-                  repaint=repaint, skeleton_parts=skeleton_parts, full=full)
+                  repaint=repaint, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):
             continue

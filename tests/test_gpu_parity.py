@@ -338,7 +338,7 @@ def test_control_branch_vs_reference_golden():
         assert maxabs(x0, T_(g[f'x0_t{t}'])) <= TOL_STEP, t
         x0n = arch.model(x_t, ts, motion_mask=mask, xf_out=xf, c=None)        # forward_test with c=None
         assert maxabs(x0n, T_(g[f'x0_noc_t{t}'])) <= TOL_STEP, t
-    with pytest.raises(NotImplementedError):                                  # raw audio needs the WavEncoder first
+    with pytest.raises(ValueError):                                           # condition of the wrong width
         arch.model(x_t, ts, motion_mask=mask, xf_out=xf, c=torch.zeros(2, 100, 2))
     arch.model.release()
 
@@ -450,3 +450,58 @@ def test_smplx_postprocessing_vs_scipy_restatement(tmp_path):
     z = np.load(path)
     assert z['poses'].shape == (120, 165) and z['expressions'].shape == (120, 100) and z['trans'].shape == (120, 3)
     assert z['betas'].shape == (300,) and str(z['model']) == 'smplx2020' and int(z['mocap_frame_rate']) == 30
+
+
+def test_wav_encoder_vs_reference_golden_and_oracle():
+    """WavEncoder as implicit-GEMM convolutions (channels-last, padding in the buffer, BN folded,
+    LeakyReLU / residual in the GEMM epilogue) vs the reference class (golden) and vs the CPU oracle on a longer clip
+    (ragged tile counts, the unaligned first layer Cin=2 and Cin=1, both shortcut kinds)."""
+    from motioncraft_amd.wav_encoder import NativeWavEncoder
+    from oracle import wav_encoder_oracle as WO
+    from oracle import weights as W
+    g = load('wav_encoder.npz')
+    sd = W.make_wav_encoder_state(64, 2, seed=int(g['seed']))
+    enc = NativeWavEncoder(64, 2, {'pre_encoder.feat_extractor.' + k: v for k, v in sd.items()},
+                           prefix='pre_encoder.feat_extractor.')
+    out = enc(T_(g['wav']).cuda())
+    assert tuple(out.shape) == tuple(g['out'].shape)
+    assert maxabs(out, T_(g['out'])) <= 2e-5
+    enc.close()
+    torch.set_num_threads(min(32, os.cpu_count()))
+    for dim, cin, B, S in ((256, 2, 3, 20000), (128, 1, 2, 9001)):
+        sd = W.make_wav_encoder_state(dim, cin, seed=7)
+        enc = NativeWavEncoder(dim, cin, sd)
+        gen = torch.Generator().manual_seed(S)
+        wav = torch.randn(B, S, cin, generator=gen)
+        ref = WO.wav_encoder(sd, wav if cin > 1 else wav[..., 0])
+        out = enc(wav.cuda() if cin > 1 else wav[..., 0].cuda())
+        assert tuple(out.shape) == tuple(ref.shape) and out.shape[1] == enc.out_len(S)
+        err = maxabs(out, ref)
+        print(f'wav encoder dim={dim} cin={cin}: out {tuple(out.shape)}, |hip - oracle| {err:.2e} (|ref| max {float(ref.abs().max()):.2f})')
+        assert err <= 5e-5
+        enc.close()
+
+
+def test_speech_to_gesture_control_form_vs_reference_golden():
+    """S2G form of the control branch (configs/stmogen/S2G_*: condition_pre_encode=True, type 'wav', dataset beats2):
+    raw audio [B, 9000, 2] -> device WavEncoder (17 frames x D) -> control_cond_input -> copied blocks, through the
+    reference-style wrapper API, weights taken from one reference-keyed state dict."""
+    import motioncraft_amd as mc
+    from oracle import weights as W
+    g = load('control_wav_small.npz')
+    sd = W.make_control_wav_state(CTRL, CTRL_COPY, 2, SMALL_SEED)
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    cfg.model.model.num_layers = 3
+    cfg.merge_from_dict({'condition_encode_cfg': dict(dataset_name='beats2', condition_pre_encode=True,
+                                                      condition_pre_encode_type='wav', control_cond_feats=2,
+                                                      condition_latent_dim=CTRL['L'] * CTRL['H'], condition_cfg=True)})
+    arch = mc.build_architecture(cfg.model)
+    arch.model = mc.ControlT2MHalf(arch.model, copy_blocks_num=CTRL_COPY, control_cond_feats=2, cfg=cfg)
+    arch.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    x_t, xf, mask, audio = (T_(g[k]) for k in ('x_t', 'xf_out', 'motion_mask', 'audio'))
+    x0 = arch.model(x_t, torch.full((2,), 420), motion_mask=mask, xf_out=xf, c=audio)
+    err = maxabs(x0, T_(g['x0_t420']))
+    print(f'S2G control form: |hip - reference| {err:.2e}')
+    assert err <= TOL_STEP
+    assert arch.model.base_model.wav_encoder.out_len(9000) == 17
+    arch.model.release()

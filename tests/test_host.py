@@ -162,6 +162,25 @@ def test_gaussian_taps_match_scipy():
         assert resp[2 * r - r - 1] == 0.0
 
 
+def test_wav_encoder_bn_folding_and_tap_major_layout():
+    """The packed GEMM weight applied to the im2col VIEW of a channels-last, zero-padded signal == conv1d + eval BN."""
+    import torch.nn.functional as F
+    from motioncraft_amd import wav_encoder as WE
+    sd = synthetic.make_wav_encoder_state(64, 2, seed=1)
+    packed = WE.pack_wav_encoder({'feat_extractor.' + k: v for k, v in sd.items()}, prefix='feat_extractor.')
+    assert set(packed) == {f'b{i}.{c}.{t}' for i in range(6) for c in ('conv1', 'conv2') for t in 'wb'} | \
+        {f'b{i}.down.{t}' for i in WE.BLOCKS_WITH_DOWNSAMPLE for t in 'wb'}
+    assert packed['b0.conv1.w'].shape == (16, 32) and packed['b1.conv1.w'].shape == (16, 240)     # 15*2 -> 32, 15*16
+    x = torch.randn(1, 16, 50)                                   # block 1: Cin=16, stride 6, pad 0
+    ref = F.batch_norm(F.conv1d(x, sd['1.conv1.weight'], sd['1.conv1.bias'], stride=6), sd['1.bn1.running_mean'],
+                       sd['1.bn1.running_var'], sd['1.bn1.weight'], sd['1.bn1.bias'], training=False, eps=1e-5)
+    xl = x[0].T.contiguous().reshape(-1)                         # channels-last [T, C] flattened
+    T1 = (50 - 15) // 6 + 1
+    rows = torch.stack([xl[t * 6 * 16:t * 6 * 16 + 240] for t in range(T1)])       # overlapping-row view, row stride 6*16
+    out = rows @ packed['b1.conv1.w'].T + packed['b1.conv1.b']
+    assert torch.allclose(out.T, ref[0], atol=1e-5)
+
+
 def test_weight_packing_layouts():
     sd = synthetic.make_state_dict(SMALL, 0)
     p = weights.pack_state_dict({'model.' + k: v for k, v in sd.items()}, SMALL)   # checkpoint prefix stripped

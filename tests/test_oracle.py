@@ -163,3 +163,11 @@ def test_repaint_mode_against_reference_golden():
                                 no_resample=True)
     assert maxabs(out, T_(g['final_noresample'])) <= 1e-5
     assert maxabs(out[:, 0], gt[:, 0]) == 0.0        # frame 0 of the kept region: pure gt at alpha_bar_prev = 1
+
+
+def test_wav_encoder_against_reference_golden():
+    """oracle/wav_encoder_oracle.py vs the reference WavEncoder class (eval-mode BatchNorm)."""
+    from oracle import wav_encoder_oracle as WO
+    g = load('wav_encoder.npz')
+    sd = W.make_wav_encoder_state(64, 2, seed=int(g['seed']))
+    assert maxabs(WO.wav_encoder(sd, T_(g['wav'])), T_(g['out'])) <= 1e-6
