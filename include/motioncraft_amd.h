@@ -15,6 +15,8 @@
  *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
  *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
  *   mc_sample_step_inpaint  the same with y = {gt, outpainting_mask}   gaussian_diffusion.py:492-501, 855-877
+ *   mc_textenc_*          DiffusionTransformer.encode_text (CLIP text tower, text_pre_proj, textTransEncoder, text_ln)
+ *                                                                      mogen/models/transformers/diffusion_transformer.py:109-172
  *   mc_wavenc_*           WavEncoder (audio condition pre-encoder)     mogen/models/utils/blocks.py:11-71; controlnet.py:90-105,187
  *   mc_postprocess_smplx  de-normalise + SMPL-X re-pack + temporal filter  tools/visualize.py:39-44,217-246; tools/s2g_test.py:289-297
  *   mc_op_renoise         GaussianDiffusion._undo (resampling jumps)   gaussian_diffusion.py:429-435, 1113-1118
@@ -149,6 +151,34 @@ int mc_postprocess_smplx(const float* pred_dev, const int32_t* lengths_dev, cons
                          const double* std_dev, const double* taps_dev, const int32_t radius[4], int32_t stats_f32,
                          int32_t B, int32_t T, int32_t C, double* poses_dev, double* expr_dev, double* trans_dev,
                          void* stream);
+
+/* ---- text condition encoder (encode_text, diffusion_transformer.py:142-172); run once per prompt batch -------- */
+typedef struct mc_textenc mc_textenc;
+typedef struct mc_textenc_config {
+    int32_t clip_dim;         /* 512: width of the CLIP text features                          */
+    int32_t text_latent_dim;  /* text_encoder.latent_dim (256)                                 */
+    int32_t num_layers;       /* text_encoder.num_layers (2) of nn.TransformerEncoder          */
+    int32_t ff_size;          /* text_encoder.ff_size (2048)                                   */
+    int32_t num_heads;        /* text_encoder.num_heads (4); head_dim must be 64               */
+    int32_t max_len;          /* 77 tokens                                                     */
+    int32_t clip_layers;      /* 12 (0: the CLIP tower is not used, clip_feat is an input)     */
+    int32_t clip_heads;       /* 8                                                             */
+    int32_t clip_ff;          /* 2048                                                          */
+    int32_t vocab;            /* 49408                                                         */
+} mc_textenc_config;
+int mc_textenc_create(const mc_textenc_config* cfg, mc_textenc** out);
+void mc_textenc_destroy(mc_textenc* e);
+/* fp32 parameters from host memory under the reference's own state-dict keys (relative to the denoiser):
+ * "text_pre_proj.weight/bias", "textTransEncoder.layers.{i}.{self_attn.in_proj_weight,...}", "text_ln.weight/bias",
+ * and optionally "clip.token_embedding.weight", "clip.positional_embedding", "clip.transformer.resblocks.{i}.*",
+ * "clip.ln_final.*" */
+int mc_textenc_set_param(mc_textenc* e, const char* name, const float* host, int64_t numel);
+int mc_textenc_finalize(mc_textenc* e);
+/* clip_feat_dev [B, max_len, clip_dim] -> xf_out_dev [B, max_len, text_latent_dim]  (encode_text with clip_feat given) */
+int mc_textenc_forward_feat(mc_textenc* e, const float* clip_feat_dev, int32_t B, float* xf_out_dev, void* stream);
+/* tokens_dev int32 [B, max_len] (clip.tokenize ids) -> xf_out_dev; clip_feat_out_dev may be NULL */
+int mc_textenc_forward_tokens(mc_textenc* e, const int32_t* tokens_dev, int32_t B, float* clip_feat_out_dev,
+                              float* xf_out_dev, void* stream);
 
 /* ---- WavEncoder: step-invariant audio condition encoder of the speech-to-gesture configs ------------------ */
 typedef struct mc_wavenc mc_wavenc;

@@ -60,11 +60,12 @@ __device__ __forceinline__ float gelu_exact(float x) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 // activation codes shared by host + device
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_LRELU = 3 };   // LRELU: nn.LeakyReLU() default slope 0.01
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_LRELU = 3, ACT_QUICKGELU = 4 };   // LRELU: nn.LeakyReLU() slope 0.01; QUICKGELU: x sigmoid(1.702 x) (CLIP)
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_GELU) return gelu_exact(v);
     if (act == ACT_SILU) return silu_f(v);
     if (act == ACT_LRELU) return v >= 0.f ? v : 0.01f * v;
+    if (act == ACT_QUICKGELU) return v / (1.0f + expf(-1.702f * v));
     return v;
 }
 

@@ -305,11 +305,13 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
         if (g.act == ACT_GELU) epilogue_vec<MODE, false, ACT_GELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else if (g.act == ACT_SILU) epilogue_vec<MODE, false, ACT_SILU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else if (g.act == ACT_LRELU) epilogue_vec<MODE, false, ACT_LRELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else if (g.act == ACT_QUICKGELU) epilogue_vec<MODE, false, ACT_QUICKGELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else epilogue_vec<MODE, false, ACT_NONE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
     } else {
         if (g.act == ACT_GELU) epilogue_vec<MODE, true, ACT_GELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else if (g.act == ACT_SILU) epilogue_vec<MODE, true, ACT_SILU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else if (g.act == ACT_LRELU) epilogue_vec<MODE, true, ACT_LRELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
+        else if (g.act == ACT_QUICKGELU) epilogue_vec<MODE, true, ACT_QUICKGELU>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
         else epilogue_vec<MODE, true, ACT_NONE>(g, grp, row0, nrows, tn, wm, wn, lane, acc);
     }
 }

@@ -35,6 +35,11 @@ class Inpaint(ctypes.Structure):
                 ('blend_w_dev', ctypes.c_void_p), ('blend_len', ctypes.c_int32)]
 
 
+class TextEncConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('clip_dim', 'text_latent_dim', 'num_layers', 'ff_size', 'num_heads', 'max_len',
+                                              'clip_layers', 'clip_heads', 'clip_ff', 'vocab')]
+
+
 _SIGNATURES = {
     'mc_last_error': (ctypes.c_char_p, []),
     'mc_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
@@ -63,6 +68,12 @@ _SIGNATURES = {
     'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
     'mc_postprocess_smplx': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32 * 4), ctypes.c_int32,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    'mc_textenc_create': (ctypes.c_int, [ctypes.POINTER(TextEncConfig), ctypes.POINTER(_P)]),
+    'mc_textenc_destroy': (None, [_P]),
+    'mc_textenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),
+    'mc_textenc_finalize': (ctypes.c_int, [_P]),
+    'mc_textenc_forward_feat': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, _P]),
+    'mc_textenc_forward_tokens': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, _P, _P]),
     'mc_wavenc_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     'mc_wavenc_destroy': (None, [_P]),
     'mc_wavenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),

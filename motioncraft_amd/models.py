@@ -83,6 +83,7 @@ class STMoGenTransformer:
         self._state = None
         self._control = None            # set by ControlT2MHalf: dict(copy_blocks_num, cond_feats, raw_feats, condition_cfg, pre_encode)
         self._wavenc = None
+        self._textenc = None
 
     # ---- nn.Module-ish surface used by the tools ---------------------------------------------
     def eval(self):
@@ -120,6 +121,9 @@ class STMoGenTransformer:
         if self._wavenc is not None:
             self._wavenc.close()
         self._wavenc = None
+        if self._textenc is not None:
+            self._textenc.close()
+        self._textenc = None
 
     # ---- native plumbing ------------------------------------------------------------------------
     @property
@@ -197,12 +201,33 @@ class STMoGenTransformer:
         return ctx
 
     # ---- reference API ----------------------------------------------------------------------------
+    @property
+    def text_encoder(self):
+        """build_text_encoder (diffusion_transformer.py:109-141) from the checkpoint's own keys, on the device."""
+        if self._textenc is None:
+            from .text_encoder import NativeTextEncoder
+            from .weights import strip_prefix
+            if self.text_encoder_cfg is None:
+                raise RuntimeError('the config has text_encoder=None: pass xf_out')
+            if self._state is None:
+                raise RuntimeError('load_state_dict() has not been called: no weights to run')
+            self._textenc = NativeTextEncoder(self.text_encoder_cfg, strip_prefix(self._state), max_len=self.dims['Nt'])
+        return self._textenc
+
+    def encode_text(self, text, clip_feat, device):
+        """diffusion_transformer.py:142-172: CLIP features (given, or computed from the tokenized prompts) ->
+        text_pre_proj -> textTransEncoder -> text_ln."""
+        enc = self.text_encoder
+        dev = device if device is not None and torch.device(device).type == 'cuda' else \
+            torch.device('cuda', torch.cuda.current_device())
+        if clip_feat is not None:
+            return enc.encode_feat(clip_feat.to(device=dev, dtype=torch.float32))
+        return enc.encode_text(text, dev)
+
     def get_precompute_condition(self, text=None, motion_length=None, xf_out=None, re_dict=None, device=None,
                                  sample_idx=None, clip_feat=None, **kwargs):
         if xf_out is None:
-            raise NotImplementedError(
-                'the CLIP text tower + textTransEncoder run once per batch, off the per-step path, and need external '
-                'weights (SURVEY.md section 8f.2): pass the frozen condition embedding as xf_out [B, 77, text_latent_dim]')
+            xf_out = self.encode_text(text, clip_feat, device)
         return {'xf_out': xf_out}
 
     def post_process(self, motion):

@@ -234,6 +234,51 @@ def make_param(seed, name, shape):
     raise KeyError(name)
 
 
+def text_encoder_param_shapes(Dt, num_layers, ff, clip_width=512, clip_layers=0, clip_ff=2048, vocab=49408, context=77):
+    """reference keys (relative to the denoiser) of text_pre_proj / textTransEncoder / text_ln and, optionally, the
+    parameters of the CLIP text tower (clip.* as registered by ``self.clip``)."""
+    s = OrderedDict()
+    if clip_width != Dt:
+        s['text_pre_proj.weight'], s['text_pre_proj.bias'] = (Dt, clip_width), (Dt,)
+    for i in range(num_layers):
+        p = f'textTransEncoder.layers.{i}.'
+        s[p + 'self_attn.in_proj_weight'], s[p + 'self_attn.in_proj_bias'] = (3 * Dt, Dt), (3 * Dt,)
+        s[p + 'self_attn.out_proj.weight'], s[p + 'self_attn.out_proj.bias'] = (Dt, Dt), (Dt,)
+        s[p + 'linear1.weight'], s[p + 'linear1.bias'] = (ff, Dt), (ff,)
+        s[p + 'linear2.weight'], s[p + 'linear2.bias'] = (Dt, ff), (Dt,)
+        for n in ('norm1', 'norm2'):
+            s[p + n + '.weight'], s[p + n + '.bias'] = (Dt,), (Dt,)
+    s['text_ln.weight'], s['text_ln.bias'] = (Dt,), (Dt,)
+    if clip_layers:
+        w = clip_width
+        s['clip.token_embedding.weight'], s['clip.positional_embedding'] = (vocab, w), (context, w)
+        for i in range(clip_layers):
+            p = f'clip.transformer.resblocks.{i}.'
+            s[p + 'attn.in_proj_weight'], s[p + 'attn.in_proj_bias'] = (3 * w, w), (3 * w,)
+            s[p + 'attn.out_proj.weight'], s[p + 'attn.out_proj.bias'] = (w, w), (w,)
+            s[p + 'mlp.c_fc.weight'], s[p + 'mlp.c_fc.bias'] = (clip_ff, w), (clip_ff,)
+            s[p + 'mlp.c_proj.weight'], s[p + 'mlp.c_proj.bias'] = (w, clip_ff), (w,)
+            for n in ('ln_1', 'ln_2'):
+                s[p + n + '.weight'], s[p + n + '.bias'] = (w,), (w,)
+        s['clip.ln_final.weight'], s['clip.ln_final.bias'] = (w,), (w,)
+    return s
+
+
+def make_text_encoder_state(shapes, seed=0):
+    sd = OrderedDict()
+    for k, shape in shapes.items():
+        r = _randn(seed, 'text.' + k, shape)
+        if k.endswith('.bias') or k.endswith('_bias'):
+            sd[k] = (0.1 if ('norm' in k or 'ln' in k) else 0.02) * r
+        elif 'norm' in k or '.ln_' in k or 'text_ln' in k or 'ln_final' in k:
+            sd[k] = 1.0 + 0.1 * r
+        elif k.endswith('embedding.weight') or k.endswith('positional_embedding'):
+            sd[k] = 0.5 * r
+        else:
+            sd[k] = r / math.sqrt(shape[-1])
+    return sd
+
+
 def make_wav_encoder_state(out_dim, audio_in, seed=0):
     """Deterministic non-trivial WavEncoder weights (BatchNorm running stats included) keyed like the reference."""
     from .wav_encoder import wav_encoder_param_shapes

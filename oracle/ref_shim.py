@@ -89,7 +89,13 @@ def install():
     for name, mod in (('mmcv', mmcv), ('mmcv.cnn', mmcv_cnn), ('mmcv.utils', mmcv_utils),
                       ('mmcv.runner', mmcv_runner)):
         sys.modules[name] = mod
-    sys.modules['clip'] = types.ModuleType('clip')
+    clip = types.ModuleType('clip')          # encode_text only touches clip.tokenize / self.clip.dtype when clip_feat is given
+
+    class _ClipStub(nn.Module):
+        dtype = __import__('torch').float32
+    clip.load = lambda name, device='cpu', **k: (_ClipStub(), None)
+    clip.tokenize = lambda text, truncate=True: __import__('torch').zeros(len(text), 77, dtype=__import__('torch').long)
+    sys.modules['clip'] = clip
 
     tutel = types.ModuleType('tutel')
     moe = types.ModuleType('tutel.moe')
@@ -134,6 +140,17 @@ def build_reference_denoiser(model_cfg):
     cfg['text_encoder'] = None
     m = ref.stmogen.STMoGenTransformer(**cfg)
     m.use_text_proj = False  # attribute otherwise undefined (diffusion_transformer.py:118,212)
+    m.eval()
+    return m
+
+
+def build_reference_text_encoder(model_cfg, text_encoder_cfg):
+    """The reference denoiser WITH its text encoder (text_pre_proj, textTransEncoder, text_ln); the CLIP tower itself is a
+    stub (un-vendored package), so only ``encode_text(text, clip_feat=...)`` is meaningful."""
+    ref = load()
+    cfg = {k: v for k, v in dict(model_cfg).items() if k != 'type'}
+    cfg['text_encoder'] = dict(text_encoder_cfg)
+    m = ref.stmogen.STMoGenTransformer(**cfg)
     m.eval()
     return m
 

@@ -23,6 +23,7 @@ Fixtures
   control_small.npz     ControlT2MHalf (copy_blocks_num=2, 35-d condition of 20 frames, NL=3): x0 at t=640, 3
   repaint_small.npz     RePaint / outpainting DDIM mode (reduced config, first 6 frames kept): harmonize loop with
                         resampling (jump 3 x 5), without resampling, and no_repaint (plain 50 steps + blending)
+  text_encoder.npz      encode_text(text, clip_feat): text_pre_proj + 2-layer nn.TransformerEncoder + text_ln (Dt=256)
   wav_encoder.npz       WavEncoder(out_dim=64, audio_in=2), eval mode: 2 x 4000 samples -> reference output
   skeleton_parts.npz    8-part layouts: human_ml3d (263-d) and kit_ml (251-d) reduced configs (x0 at two t + 50-step
                         DDIM final), and the shipped T2M_humanml3d.py architecture (L=64, H=8) x0 at t=500
@@ -252,6 +253,32 @@ def control():
     np.savez_compressed(os.path.join(OUT, 'control_small.npz'), **save)
 
 
+TEXT_CFG = dict(pretrained_model='clip', latent_dim=256, num_layers=2, ff_size=2048, dropout=0, use_text_proj=False)
+
+
+def text_encoder():
+    """the reference's own encode_text (diffusion_transformer.py:142-172) with clip_feat given."""
+    from oracle import text_encoder_oracle as TO
+    dims = W.default_dims(max_seq_len=24, L=32, NL=1, F=64, Te=64, Dt=256, Nt=77)
+    m = ref_shim.build_reference_text_encoder(W.reference_model_cfg(dims), TEXT_CFG)
+    shapes = W.text_encoder_param_shapes(256, 2, 2048)
+    ref_sd = {k: v for k, v in m.state_dict().items() if k.split('.')[0] in ('text_pre_proj', 'textTransEncoder', 'text_ln')}
+    assert set(ref_sd) == set(shapes), sorted(set(ref_sd) ^ set(shapes))[:8]
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sd = W.make_text_encoder_state(shapes, seed=4)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(not k.startswith(('text_', 'textTrans')) for k in missing)
+    g = torch.Generator().manual_seed(61)
+    feat = torch.randn(3, 77, 512, generator=g)
+    with torch.no_grad():
+        ref = m.encode_text(['a', 'b', 'c'], feat, 'cpu')
+    orc = TO.finetune_encoder(sd, feat, 2)
+    print(f'text_encoder: xf_out {tuple(ref.shape)}; oracle vs reference {maxabs(ref, orc):.2e}')
+    assert maxabs(ref, orc) <= 1e-5        # torch's fused encoder-layer fast path orders the fp32 sums differently
+    np.savez_compressed(os.path.join(OUT, 'text_encoder.npz'), clip_feat=feat.numpy(), xf_out=ref.numpy(), seed=np.int64(4))
+
+
 WAV_DIM, WAV_IN, WAV_SAMPLES = 64, 2, 4000
 
 
@@ -442,7 +469,7 @@ if __name__ == '__main__':
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
-                  repaint=repaint, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, full=full)
+                  repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):
             continue

@@ -505,3 +505,79 @@ def test_speech_to_gesture_control_form_vs_reference_golden():
     assert err <= TOL_STEP
     assert arch.model.base_model.wav_encoder.out_len(9000) == 17
     arch.model.release()
+
+
+def test_text_encoder_vs_reference_golden_and_clip_tower_vs_oracle():
+    """SURVEY.md 8f.2.  Stage A (text_pre_proj -> 2-layer nn.TransformerEncoder -> text_ln) vs the reference's own
+    encode_text(clip_feat=...) golden; stage B (CLIP text transformer from token ids: causal pre-LN blocks, QuickGELU)
+    vs the restated architecture in oracle/text_encoder_oracle.py (the `clip` package is un-vendored: parity unpinned),
+    with a reduced tower (3 layers, 1000-token vocabulary) of the true width / head count."""
+    from motioncraft_amd.text_encoder import NativeTextEncoder
+    from oracle import text_encoder_oracle as TO
+    from oracle import weights as W
+    g = load('text_encoder.npz')
+    cfg = dict(pretrained_model='clip', latent_dim=256, num_layers=2, ff_size=2048, dropout=0, use_text_proj=False)
+    sd = W.make_text_encoder_state(W.text_encoder_param_shapes(256, 2, 2048), seed=int(g['seed']))
+    enc = NativeTextEncoder(cfg, sd)
+    out = enc.encode_feat(T_(g['clip_feat']).cuda())
+    err = maxabs(out, T_(g['xf_out']))
+    print(f'text encoder stage A: |hip - reference| {err:.2e}')
+    assert err <= 5e-5
+    with pytest.raises(RuntimeError):           # no clip.* weights loaded -> loud failure
+        enc.encode_tokens(torch.zeros(1, 77, dtype=torch.int32).cuda())
+    enc.close()
+    shapes = W.text_encoder_param_shapes(256, 2, 2048, clip_layers=3, vocab=1000)
+    sd = W.make_text_encoder_state(shapes, seed=9)
+    enc = NativeTextEncoder(cfg, sd, clip=dict(layers=3))
+    gen = torch.Generator().manual_seed(2)
+    tokens = torch.randint(0, 1000, (4, 77), generator=gen)
+    xf, feat = enc.encode_tokens(tokens.cuda(), return_clip_feat=True)
+    feat_ref = TO.clip_text_features(sd, tokens, 3)
+    xf_ref = TO.finetune_encoder(sd, feat_ref, 2)
+    e1, e2 = maxabs(feat, feat_ref), maxabs(xf, xf_ref)
+    print(f'text encoder stage B (CLIP tower): |hip - oracle| features {e1:.2e}, xf_out {e2:.2e}')
+    assert e1 <= 1e-4 and e2 <= 1e-4
+    # causality: changing a later token must not change earlier positions of the CLIP features
+    tokens2 = tokens.clone()
+    tokens2[:, 40:] = (tokens2[:, 40:] + 1) % 1000
+    _, feat2 = enc.encode_tokens(tokens2.cuda(), return_clip_feat=True)
+    assert torch.equal(feat[:, :40], feat2[:, :40]) and not torch.equal(feat[:, 40:], feat2[:, 40:])
+    enc.close()
+
+
+def test_text_to_motion_call_with_clip_features_through_the_reference_api():
+    """get_precompute_condition(clip_feat=...) (stmogen.py:676-688 -> encode_text) feeding the sampler: the whole
+    clip_feat -> xf_out -> 50-step DDIM call stays on the device; xf_out is checked against the oracle's stage A and
+    the sample against the oracle driven with that xf_out."""
+    import motioncraft_amd as mc
+    from oracle import stmogen_oracle as O, text_encoder_oracle as TO, weights as W
+    dims = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=256, Nt=77)
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    cfg.model.model.ca_block_cfg.text_latent_dim = 256
+    cfg.model.model.ca_block_cfg.max_text_seq_len = 77
+    cfg.model.model.text_encoder.latent_dim = 256
+    arch = mc.build_architecture(cfg.model)
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    tsd = W.make_text_encoder_state(W.text_encoder_param_shapes(256, cfg.model.model.text_encoder.num_layers,
+                                                                cfg.model.model.text_encoder.ff_size), seed=5)
+    arch.load_state_dict({'model.' + k: v for k, v in {**sd, **tsd}.items()})
+    g = torch.Generator().manual_seed(77)
+    B, T = 2, 24
+    feat = torch.randn(B, 77, 512, generator=g)
+    xf = arch.model.get_precompute_condition(clip_feat=feat)['xf_out']
+    xf_ref = TO.finetune_encoder(tsd, feat, cfg.model.model.text_encoder.num_layers)
+    assert maxabs(xf, xf_ref) <= 5e-5
+    x_T = torch.randn(B, T, 322, generator=g)
+    mask = torch.ones(B, T)
+    mask[1, 20:] = 0
+    noises = step_noise_from_seed(3, (B, T, 322), 50)
+    res = arch(motion=torch.zeros(B, T, 322), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+               motion_metas=[{'text': 'a'}, {'text': 'b'}], clip_feat=feat,
+               inference_kwargs=dict(noise=x_T, step_noise=lambda i: noises[49 - i]))
+    final = torch.stack([r['pred_motion'] for r in res])
+    ref = O.sample_loop(sd, dims, O.Schedule(1000, '15,15,8,6,6'), 'ddim', x_T, xf_ref, mask,
+                        step_noise=lambda i: noises[49 - i])
+    err = maxabs(final, ref)
+    print(f'clip_feat -> motion, 50-step DDIM: |hip - oracle| {err:.2e}')
+    assert err <= TOL_FINAL
+    arch.model.release()

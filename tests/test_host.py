@@ -82,8 +82,9 @@ def test_build_architecture_small_and_unsupported_options():
     assert arch.model.cfg_scale == 6.5
     with pytest.raises(NotImplementedError):
         arch.train()
-    with pytest.raises(NotImplementedError):        # text encoder is off-path: xf_out must be given
+    with pytest.raises(RuntimeError):               # text encoder: no weights loaded -> loud failure
         arch.model.get_precompute_condition(text=['a person walks'])
+    assert arch.model.get_precompute_condition(xf_out='given')['xf_out'] == 'given'
     with pytest.raises(RuntimeError):               # no weights loaded -> loud failure, no fallback
         arch.model.native
     bad = cfg.model.model.ca_block_cfg

@@ -171,3 +171,11 @@ def test_wav_encoder_against_reference_golden():
     g = load('wav_encoder.npz')
     sd = W.make_wav_encoder_state(64, 2, seed=int(g['seed']))
     assert maxabs(WO.wav_encoder(sd, T_(g['wav'])), T_(g['out'])) <= 1e-6
+
+
+def test_text_encoder_against_reference_golden():
+    """oracle/text_encoder_oracle.py stage A vs the reference's encode_text(text, clip_feat)."""
+    from oracle import text_encoder_oracle as TO
+    g = load('text_encoder.npz')
+    sd = W.make_text_encoder_state(W.text_encoder_param_shapes(256, 2, 2048), seed=int(g['seed']))
+    assert maxabs(TO.finetune_encoder(sd, T_(g['clip_feat']), 2), T_(g['xf_out'])) <= 1e-5
