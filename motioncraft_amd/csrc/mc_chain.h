@@ -56,6 +56,7 @@ struct RowChainArgs {
     long ldy = 0;
     long N = 0;
     int L = 0, Nout = 0;
+    long twin_from = 0;            // kind 0: tokens >= twin_from (> 0) read the expert outputs of token - twin_from
 };
 
 bool mc_chain_enabled(int which);   // 0: fused mlp, 1: gate, 2: rowchain (proj, qkv)   (env MC_CHAIN bitmask, default all)

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     if constexpr (KIND == 0) {
         const long tk = rok ? tok : 0;
         const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
-        const float* y0 = g.X + 2 * tk * L + kq;
+        const long ty = (g.twin_from > 0 && tk >= g.twin_from) ? tk - g.twin_from : tk;    // CFG twin: same expert outputs
+        const float* y0 = g.X + 2 * ty * L + kq;
         // all 2*NJ row loads are issued unconditionally and back to back (a load under `if (w != 0)` makes the
         // compiler wait for each one in its own basic block); rows of dropped choices were never written, so
         // their (possibly NaN) contents are discarded by a select, not multiplied by 0
@@ -429,7 +430,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 7;
+        v = e ? atoi(e) : 23;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 side stream at any batch, 4 CFG twin dedupe in layer 0
     }
     return v;
 }

@@ -70,7 +70,7 @@ size_t mc_route_state_ints(int E);
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
                           RouteBufs rb, hipStream_t s);
 // capacity/BPR drop decision + slot compaction + tile map (tile rows = 128)
-int mc_launch_route(long N, int E, int capacity, RouteBufs rb, hipStream_t s);
+int mc_launch_route(long N, long Nsrc, int E, int capacity, RouteBufs rb, hipStream_t s);   // Nsrc = N, or N/2 (twin mode)
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb);
 
 // ---- mc_attn.hip ----------------------------------------------------------------------

@@ -197,7 +197,7 @@ int dense(const float* A, long lda, const float* W, long ldw, const float* bias,
 // One tutel MoE layer + GELU + proj (class MOE, st_attention.py:49-56) over Ntok tokens whose
 // gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
 // `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
-int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, bool gated, hipStream_t s) {
+int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, bool gated, bool twin, hipStream_t s) {
     const mc_model_config& g = c->m->cfg;
     const int E = g.num_experts, din = w.din, hid = 4 * w.din;
     int r;
@@ -207,7 +207,7 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
         if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
     }
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
-    if ((r = mc_launch_route(Ntok, E, capacity, c->rb, s))) return r;
+    if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, E, capacity, c->rb, s))) return r;
     const int max_tiles = cdiv(2 * Ntok, 128) + E;
     if (mc_chain_enabled(0) && mc_mlp_supported(din, hid)) {
         // fused expert FFN: hidden activations stay on chip (mc_mlp.hip)
@@ -237,6 +237,7 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
         RowChainArgs p;
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.proj_w; p.bias = w.proj_b;
         p.Y = out; p.ldy = ldout; p.N = Ntok; p.L = din; p.Nout = w.dout;
+        p.twin_from = twin ? Ntok / 2 : 0;
         return mc_launch_rowchain(0, p, s);
     }
     GemmArgs p;
@@ -257,25 +258,33 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
 
 // One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
 // `i` selects the layer slot (weights, text K/V, FiLM tables): base layers first, control copies after.
-int run_layer(mc_ctx* c, int i, float* hs, int step, hipStream_t s) {
+int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, hipStream_t s) {
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
     const LayerW& w = c->lw[i];
     int r;
         // ---- STMA ----
         const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
+        // The two CFG halves enter base layer 0 with the same residual stream (the pose encoder output is written to
+        // both, stmogen.py:736-740), so gate scores and expert outputs of token i + N/2 equal those of token i:
+        // gate and experts run on the first half only, routing still ranks all N tokens ("twin" mode, mc_route.hip).
+        const bool twin = twin_ok && fused_gate && mc_chain_enabled(2) && mc_chain_enabled(4) && (c->N % 2 == 0);
         if (fused_gate) {
             GateArgs ga;
             ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
             ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
-            ga.N = c->N; ga.E = g.num_experts; ga.L = L;
+            ga.N = twin ? c->N / 2 : c->N; ga.E = g.num_experts; ga.L = L;
             ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
             if ((r = mc_launch_gate(ga, s))) return r;
         } else {
             if ((r = mc_launch_ln_rows(hs, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
         }
-        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, fused_gate, s))) return r;
+        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, fused_gate, twin, s))) return r;
         if (c->cap_idx) {
+            if (twin) {     // expert ids exist for the first half only: the twins have the same ones
+                MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
+                MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N + c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
+            } else
             MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
             MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
         }
@@ -525,7 +534,7 @@ int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_d
         const LayerW& w = c->lw[i];
         if ((r = mc_launch_ln_rows(xf_out_dev, Dt, 0, w.tnorm_g, w.tnorm_b, w.tm.emb, Nt, c->xfn, Dt, half, Dt, s))) return r;
         MC_HIP(hipMemcpyAsync(c->xfn + half * Dt, c->xfn, sizeof(float) * half * Dt, hipMemcpyDeviceToDevice, s));
-        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, false, s))) return r;
+        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, false, false, s))) return r;
     }
     c->have_cond = true;
     return MC_OK;
@@ -596,11 +605,11 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
             if (j == 0) {
                 if ((r = mc_launch_add_rows(c->hc, c->h, c->cb, nullptr, c->rows, D, s))) return r;   // x + before_proj(c)
             }
-            if ((r = run_layer(c, slot, c->hc, step, s))) return r;                                     // copied_block
+            if ((r = run_layer(c, slot, c->hc, step, false, s))) return r;                                     // copied_block
             const LayerW& cw = c->lw[slot];
             if ((r = dense(c->hc, D, cw.after_w, D, cw.after_b, c->h, D, c->h, D, c->rows, D, D, ACT_NONE, s))) return r;  // h += after_proj(c)
         }
-        if ((r = run_layer(c, i, c->h, step, s))) return r;
+        if ((r = run_layer(c, i, c->h, step, i == 0, s))) return r;
     }
     if (stop_after >= 0) return MC_OK;
     // PoseDecoder as one dense [D -> C] GEMM (stmogen.py:505-544), /2 folded into the packed weight

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void gate_finish_k(const float* __restrict__ p
 }
 
 // problem setup: limit per (choice, expert); active when the expert overflows.
-__global__ void route_init_k(int* __restrict__ state, int E, int capacity) {
+__global__ void route_init_k(int* __restrict__ state, int E, int capacity, int cnt_mul) {
     const int p = threadIdx.x;  // 0..MAXP-1
     __shared__ int any;
     if (p == 0) any = 0;
@@ -106,8 +106,8 @@ __global__ void route_init_k(int* __restrict__ state, int E, int capacity) {
         const int choice = p / MAXE, e = p % MAXE;
         int act = 0, rank = 0;
         if (e < E) {
-            const int c0 = state[ST_CNT + e];
-            const int cnt = state[ST_CNT + p];
+            const int c0 = state[ST_CNT + e] * cnt_mul;
+            const int cnt = state[ST_CNT + p] * cnt_mul;
             const int limit = choice == 0 ? capacity : capacity - c0;   // second choices start at count_0[e]
             if (limit <= 0) act = cnt > 0 ? -1 : 0;
             else if (cnt > limit) { act = 1; rank = limit; }
@@ -125,8 +125,9 @@ __global__ void route_init_k(int* __restrict__ state, int E, int capacity) {
 }
 
 // one radix pass (byte `pass` from the top of the 64-bit composite key)
+// (idx / gate / key hold the first Nsrc tokens; token tok >= Nsrc is the twin of tok - Nsrc: same scores, own index)
 __global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx, const uint32_t* __restrict__ key,
-                                                    long N, int* __restrict__ state, int pass) {
+                                                    long N, long Nsrc, int* __restrict__ state, int pass) {
     if (state[ST_ANY] == 0) return;
     __shared__ int h[MAXP * 256];
     __shared__ int s_act[MAXP];
@@ -141,9 +142,10 @@ __global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx,
     const int shift = 56 - 8 * pass;
     for (long a = (long)blockIdx.x * 256 + threadIdx.x; a < 2 * N; a += (long)gridDim.x * 256) {
         const long tok = a >> 1;
-        const int p = (int)(a & 1) * MAXE + idx[a];
+        const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+        const int p = (int)(a & 1) * MAXE + idx[2 * ts + (a & 1)];
         if (s_act[p] != 1) continue;
-        const unsigned long long V = composite(key[tok], (uint32_t)tok);
+        const unsigned long long V = composite(key[ts], (uint32_t)tok);
         if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
         atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
     }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void route_pick_k(int* __restrict__ state) {
 
 // keep/drop + combine weights + per-expert kept counts
 __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx, const float* __restrict__ gate,
-                                                    const uint32_t* __restrict__ key, long N,
+                                                    const uint32_t* __restrict__ key, long N, long Nsrc,
                                                     float* __restrict__ comb_w, int* __restrict__ state) {
     __shared__ int s_act[MAXP];
     __shared__ unsigned long long s_thr[MAXP];
@@ -200,13 +202,15 @@ __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx,
     __syncthreads();
     for (long a = (long)blockIdx.x * 256 + threadIdx.x; a < 2 * N; a += (long)gridDim.x * 256) {
         const long tok = a >> 1;
-        const int e = idx[a];
+        const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+        const long as = 2 * ts + (a & 1);
+        const int e = idx[as];
         const int p = (int)(a & 1) * MAXE + e;
         bool keep = true;
         if (s_act[p] == -1) keep = false;
-        else if (s_act[p] == 1) keep = composite(key[tok], (uint32_t)tok) >= s_thr[p];
-        comb_w[a] = keep ? gate[a] : 0.f;
-        if (keep) atomicAdd(&s_kept[e], 1);
+        else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok) >= s_thr[p];
+        comb_w[a] = keep ? gate[as] : 0.f;
+        if (keep && tok < Nsrc) atomicAdd(&s_kept[e], 1);      // expert slots exist for the first Nsrc tokens only
     }
     __syncthreads();
     if (threadIdx.x < MAXE && s_kept[threadIdx.x]) atomicAdd(&state[ST_KEPT + threadIdx.x], s_kept[threadIdx.x]);
@@ -295,19 +299,24 @@ int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* lo
     return MC_OK;
 }
 
-int mc_launch_route(long N, int E, int capacity, RouteBufs rb, hipStream_t s) {
-    hipLaunchKernelGGL(route_init_k, dim3(1), dim3(256), 0, s, rb.state, E, capacity);
+// Nsrc == N: the plain case.  Nsrc == N/2 ("twin" mode): tokens [N/2, N) are exact copies of [0, N/2) (the two CFG
+// halves enter the first decoder layer with the same residual stream), gate outputs exist for the first half only;
+// the capacity test still ranks all N tokens (a twin ranks right behind its original: same score, larger index, so
+// "twin kept => original kept"), combine weights are produced for all N, expert slots only for the first half.
+int mc_launch_route(long N, long Nsrc, int E, int capacity, RouteBufs rb, hipStream_t s) {
+    MC_REQUIRE(Nsrc == N || 2 * Nsrc == N, "route: Nsrc=%ld must be N or N/2 (N=%ld)", Nsrc, N);
+    hipLaunchKernelGGL(route_init_k, dim3(1), dim3(256), 0, s, rb.state, E, capacity, (int)(N / Nsrc));
     int blocks = cdiv(2 * N, 256 * 8);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, rb.state, pass);
+        hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, Nsrc, rb.state, pass);
         hipLaunchKernelGGL(route_pick_k, dim3(MAXP), dim3(256), 0, s, rb.state);
     }
-    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, rb.comb_w, rb.state);
+    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, rb.comb_w, rb.state);
     hipLaunchKernelGGL(route_plan_k, dim3(1), dim3(256), 0, s, rb.state, E, rb.tile_group, rb.tile_row0, rb.tile_nrows,
                        rb.max_tiles);
-    hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * N, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, N, rb.state,
+    hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * Nsrc, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, Nsrc, rb.state,
                        rb.src_row, rb.dst_row);
     MC_LAUNCH_CHECK();
     return MC_OK;
