@@ -75,6 +75,9 @@ def pose_decoder(p, h, L, out_dim=322, dataset='motionx'):
 # ------------------------------------------------------------------------------------
 # a16 + MOE wrapper
 # ------------------------------------------------------------------------------------
+CAPACITY_FACTOR = 1.5      # st_attention.py:33 (hard-coded in the reference; tests shrink it to reach the overflow branches)
+
+
 def moe_wrapper(p, pre, z, return_routing=False, forced=None):
     """mogen/models/attentions/st_attention.py:49-56 (class MOE.forward); tutel boundary a16."""
     B, S, G, Din = z.shape
@@ -85,7 +88,7 @@ def moe_wrapper(p, pre, z, return_routing=False, forced=None):
         p[m + 'gates.0.sim_matrix'], p[m + 'gates.0.temperature'],
         p[m + 'experts.batched_fc1_w'], p[m + 'experts.batched_fc1_bias'],
         p[m + 'experts.batched_fc2_w'], p[m + 'experts.batched_fc2_bias'],
-        top_k=2, capacity_factor=1.5, batch_prioritized_routing=True, return_routing=return_routing, forced=forced)
+        top_k=2, capacity_factor=CAPACITY_FACTOR, batch_prioritized_routing=True, return_routing=return_routing, forced=forced)
     y, routing = r if return_routing else (r, None)
     y = F.linear(F.gelu(y), p[pre + 'proj.weight'], p[pre + 'proj.bias']).reshape(B, S, G, -1)
     return (y, routing) if return_routing else y
@@ -256,7 +259,20 @@ def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_nu
     return out[:B] * w + out[B:] * (1 - w)
 
 
-def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None, forced_routing=None):
+def denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None, forced_routing=None,
+            capacity_factor=None):
+    """``_denoise`` with the module-level tutel capacity factor temporarily replaced (test knob)."""
+    global CAPACITY_FACTOR
+    old = CAPACITY_FACTOR
+    if capacity_factor is not None:
+        CAPACITY_FACTOR = float(capacity_factor)
+    try:
+        return _denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats, cap, forced_routing)
+    finally:
+        CAPACITY_FACTOR = old
+
+
+def _denoise(p, dims, x_t, t_orig, xf_out, motion_mask, text_feats=None, cap=None, forced_routing=None):
     """mogen/models/transformers/diffusion_transformer.py:186-238 + stmogen.py:725-761.
     x_t [B,T,C]; t_orig: int original (un-spaced) timestep, identical for the batch;
     returns the CFG-combined x0 prediction [B,T,C]."""

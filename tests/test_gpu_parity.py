@@ -581,3 +581,54 @@ def test_text_to_motion_call_with_clip_features_through_the_reference_api():
     print(f'clip_feat -> motion, 50-step DDIM: |hip - oracle| {err:.2e}')
     assert err <= TOL_FINAL
     arch.model.release()
+
+
+@pytest.mark.parametrize('case', ['one_frame', 'fully_masked_sample', 'eight_experts', 'tiny_capacity', 'odd_tokens'])
+def test_edge_cases_vs_oracle(case):
+    """Shapes and routing regimes the reference's own paths can reach: a single frame (temporal softmax over the text
+    tokens + 1 frame), a sample whose motion mask is all zero (keys at -1e6: the column softmax degenerates to the
+    text rows / uniform), fewer experts than the 16 gate lanes, a capacity small enough that second choices are
+    dropped wholesale (limit <= 0 branch) and most first choices too, and an odd token count (no CFG twin tiles of
+    128, ragged everything)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    over, B, T, lengths, capf = {}, 2, 24, [24, 17], 1.5
+    if case == 'one_frame':
+        B, T, lengths = 3, 1, [1, 1, 1]
+    elif case == 'fully_masked_sample':
+        lengths = [24, 0]
+    elif case == 'eight_experts':
+        over = dict(E=8)
+    elif case == 'tiny_capacity':
+        capf = 0.5
+    elif case == 'odd_tokens':
+        B, T, lengths = 1, 7, [5]
+    dims = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8, **over)
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'], capacity_factor=capf)
+    x, xf, mask = synth_inputs(dims, B, T, seed=91, lengths=lengths)
+    ctx = nm.context(B, T, max_steps=2)
+    ctx.enable_capture()
+    ctx.set_timesteps([777, 0])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    for s_, t in ((0, 777), (1, 0)):
+        out2 = ctx.denoise(x.cuda(), s_)
+        assert torch.isfinite(out2).all()
+        w = (1 - (1000 - t) / 1000) * dims['scale'] + 1
+        got = out2[:B] * w + out2[B:] * (1 - w)
+        forced = [ctx.routing(l) for l in range(dims['NL'])]
+        cap = {}
+        ref = O.denoise(sd, dims, x, t, xf, mask, forced_routing=forced, cap=cap, capacity_factor=capf)
+        err = maxabs(got, ref)
+        flips = 0
+        for l in range(dims['NL']):
+            free = cap[f'layer{l}']['routing']['free']
+            flips += int((torch.stack(free['indices'], 1) != forced[l][0]).sum())
+            flips += int((torch.stack(free['keeps'], 1) != forced[l][1]).sum())
+        dropped = sum(int((~forced[l][1]).sum()) for l in range(dims['NL']))
+        print(f'{case} t={t}: |hip - oracle| {err:.2e}, dropped pairs {dropped}, routing flips vs free-running oracle {flips}')
+        assert err <= TOL_STEP and flips == 0
+        if case == 'tiny_capacity':
+            assert dropped > 0.3 * forced[0][1].numel()
+    ctx.close()
+    nm.close()
