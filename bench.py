@@ -205,6 +205,35 @@ def main():
     t_gather = time.perf_counter() - t0
     assert out.shape[0] == GB and bool(torch.isfinite(out).all())
 
+    # ---- dominant kernel on its own: the FiLM out_layers GEMM h += a W^T + b, [2BT, D] x [D, D] (8 launches per step) ----
+    dom = None
+    if rank == 0:
+        import ctypes
+        from motioncraft_amd import lib as mclib
+        lib_ = mclib.load(require_gpu=True)
+        D = DIMS['L'] * DIMS['H']
+        rows = 2 * B * T
+        ga = torch.randn(rows, D, device=dev)
+        gw = torch.randn(D, D, device=dev) / D ** 0.5
+        gb = torch.zeros(D, device=dev)
+        gc = torch.zeros(rows, D, device=dev)
+        P = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        launch = lambda: mclib.check(lib_.mc_op_gemm(P(ga), P(gw), P(gb), P(gc), P(gc), rows, D, D, D, 0, st), 'mc_op_gemm')
+        for _ in range(3):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 16
+        e0.record()
+        for _ in range(nrep):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / nrep * 1e3
+        tf = 2.0 * rows * D * D / (us * 1e-6) / 1e12
+        dom = {'kernel': f'gemm_k<PLAIN> FiLM out_layers GEMM {rows}x{D}x{D} + bias + residual (8 of the ~125 launches, 35 % of a step)',
+               'avg_us': round(us, 1), 'achieved': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,7 +260,7 @@ def main():
                          'traffic_unit': 'GB per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate PMC passes; profiles/r01_pmc_hbm_traffic.txt)',
                          'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_k fp32 MFMA GEMMs)',
                          'algorithmic_gflop_per_sample_step': round(algorithmic_flops_per_sample_step(DIMS, T) / 1e9, 3),
-                         'event_ms_per_step': round(ev_ms, 4)},
+                         'event_ms_per_step': round(ev_ms, 4), 'dominant_kernel': dom},
         }
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
