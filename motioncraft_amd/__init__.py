@@ -6,6 +6,8 @@ from .config import Config, ConfigDict
 from .registry import Registry, build_from_cfg
 from . import models as _models  # registers MotionDiffusion / STMoGenTransformer / STMA / MSELoss
 from .models import ControlT2MHalf
+from .checkpoint import load_checkpoint
 
 __all__ = ['ARCHITECTURES', 'ATTENTIONS', 'LOSSES', 'MODELS', 'SUBMODULES', 'build_architecture',
-           'build_attention', 'build_loss', 'build_submodule', 'Config', 'ConfigDict', 'Registry', 'build_from_cfg', 'ControlT2MHalf']
+           'build_attention', 'build_loss', 'build_submodule', 'Config', 'ConfigDict', 'Registry', 'build_from_cfg', 'ControlT2MHalf',
+           'load_checkpoint']

@@ -238,6 +238,25 @@ def test_skeleton_part_layouts_and_packing():
         synthetic.part_layout('openpose17')
 
 
+def test_checkpoint_formats(tmp_path):
+    """load_checkpoint: mmcv-style {'state_dict', 'meta'} .pth with a DataParallel 'module.' prefix, flat .pth, .npz."""
+    sd = {'model.a.weight': torch.arange(6.).reshape(2, 3), 'model.b': torch.ones(2)}
+
+    class Sink:
+        def load_state_dict(self, state_dict, strict=True):
+            self.sd = state_dict
+    torch.save({'state_dict': {'module.' + k: v for k, v in sd.items()}, 'meta': {'epoch': 3}}, tmp_path / 'a.pth')
+    torch.save(sd, tmp_path / 'b.pth')
+    np.savez(tmp_path / 'c.npz', **{k: v.numpy() for k, v in sd.items()})
+    for name in ('a.pth', 'b.pth', 'c.npz'):
+        m = Sink()
+        ck = mc.load_checkpoint(m, str(tmp_path / name), map_location='cpu')
+        assert set(m.sd) == set(sd) and all(torch.equal(m.sd[k], sd[k]) for k in sd), name
+        assert 'state_dict' in ck
+    with pytest.raises(IOError):
+        mc.load_checkpoint(Sink(), str(tmp_path / 'missing.pth'))
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, 'include', 'motioncraft_amd.h')).read()
     declared = set(re.findall(r'\b(mc_[a-z_0-9]+)\s*\(', hdr))
