@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='samples per GPU (BASELINE configs[1]: 64)')
     ap.add_argument('--frames', type=int, default=196)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the side measurements (dominant-kernel probe, 2 batches in flight)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for plumbing smoke tests")
     a = ap.parse_args()
 
@@ -147,6 +148,7 @@ def main():
     sd = make_state_dict(DIMS, 0)
     nm = NativeModel(DIMS, sd, cfg_scale=DIMS['scale'], device=local_rank)
     del sd
+    side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]      # for the 2-batches-in-flight side measurement
     ctx = nm.context(B, T, max_steps=TOTAL_DDPM_STEPS)
     diff = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
                                 model_var_type='fixed_large'))
@@ -207,7 +209,7 @@ def main():
 
     # ---- dominant kernel on its own: the FiLM out_layers GEMM h += a W^T + b, [2BT, D] x [D, D] (8 launches per step) ----
     dom = None
-    if rank == 0:
+    if rank == 0 and not a.no_extras:
         import ctypes
         from motioncraft_amd import lib as mclib
         lib_ = mclib.load(require_gpu=True)
@@ -234,6 +236,40 @@ def main():
         dom = {'kernel': f'gemm_k<PLAIN> FiLM out_layers GEMM {rows}x{D}x{D} + bias + residual (8 of the ~125 launches, 35 % of a step)',
                'avg_us': round(us, 1), 'achieved': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
+    # ---- side measurement (NOT `value`): two independent batches of B in flight on this GPU, one HIP stream and one
+    # context each -- what a test loop over many batches of 64 can do; each batch keeps its own MoE capacity domain ----
+    inflight2 = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        s2 = side_streams
+        c2, x2, n2 = [], [], []
+        for j in (0, 1):
+            with torch.cuda.stream(s2[j]):
+                cj = nm.context(B, T, max_steps=4)
+                cj.set_timesteps(diff.timestep_map[-4:])
+                cj.set_condition(xf, mask)
+                c2.append(cj)
+                x2.append(torch.randn(B, T, C, device=dev, generator=gen))
+                n2.append(torch.empty(B, T, C, device=dev))
+        e2 = torch.randn(B, T, C, device=dev, generator=gen)
+        torch.cuda.synchronize()
+
+        def both(reps):
+            for _ in range(reps):
+                for j in (0, 1):
+                    with torch.cuda.stream(s2[j]):
+                        c2[j].sample_step(x2[j], 1, coefs[1], e2, x_prev=n2[j])
+        both(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        both(8)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / 8
+        inflight2 = {'frames_per_s': round(2 * B * T / (TOTAL_DDPM_STEPS * dt2), 1), 'ms_per_step_pair': round(dt2 * 1e3, 3),
+                     'note': 'side measurement, not `value`: 2 independent batches of 64 per GPU on 2 HIP streams fill each '
+                             "other's tile-count tails"}
+        c2[0].close()
+        c2[1].close()
+
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,7 +290,8 @@ def main():
                        'batch_per_gpu': B, 'global_batch': GB, 'frames': T, 'parallelism': f'dp{world}',
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
-                       'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)'},
+                       'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
+                       'batches_in_flight': 1, 'two_batches_in_flight': inflight2},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': MEASURED_HBM_GB_PER_STEP_B64 if (B, T) == (64, 196) else None,
                          'traffic_unit': 'GB per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate PMC passes; profiles/r01_pmc_hbm_traffic.txt)',

@@ -19,6 +19,9 @@ SHAPES = [  # name, M, N, K, act, residual
     ('fc1 gelu K=128', 50176, 512, 128, 1, False),
     ('decoder N=322', 25088, 322, 1536, 0, False),
     ('film tables M=1000', 1000, 3072, 2048, 0, False),
+    ('4096^3 (guide reference point)', 4096, 4096, 4096, 0, False),
+    ('film, exact 4 rounds', 21760 - 21760 % 128 + 128 * 0, 1536, 1536, 0, True),
+    ('2048x1536 tiles=192', 2048, 1536, 1536, 0, True),
 ]
 
 
