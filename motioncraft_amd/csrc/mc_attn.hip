@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
 template <int L>
 __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                      const float* __restrict__ mask, float* __restrict__ yt,
-                                                     int B, int T, int Nt, int H) {
+                                                     int b0, int B, int T, int Nt, int H) {
     constexpr int NT = L / 32;           // 32-wide d tiles (= active waves)
     constexpr int LP = L + 4;
     constexpr int C4 = L / 4;            // float4 columns per row
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
     float* Qs = Ks;                      // [32][LP]  phase 3 reuses the K slab (43 KB total -> 3 workgroups per CU)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int b = b0 + blockIdx.x / H, h = blockIdx.x % H;
     const float cnd = b < B ? 1.f : 0.f;             // text-conditioned half first (stmogen.py:736-739)
     const float* mrow = mask + (long)(b % B) * T;
     const int Nseq = Nt + T;
@@ -372,11 +372,12 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 }
 
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int B2, int B, int T, int Nt, int H, int L, hipStream_t s) {
-    dim3 grid(B2 * H), blk(256);
-    if (L == 128) hipLaunchKernelGGL(temporal_k<128>, grid, blk, 0, s, mf, tf, mask, yt, B, T, Nt, H);
-    else if (L == 64) hipLaunchKernelGGL(temporal_k<64>, grid, blk, 0, s, mf, tf, mask, yt, B, T, Nt, H);
-    else if (L == 32) hipLaunchKernelGGL(temporal_k<32>, grid, blk, 0, s, mf, tf, mask, yt, B, T, Nt, H);
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s) {
+    if (nb <= 0) return MC_OK;
+    dim3 grid(nb * H), blk(256);
+    if (L == 128) hipLaunchKernelGGL(temporal_k<128>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H);
+    else if (L == 64) hipLaunchKernelGGL(temporal_k<64>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H);
+    else if (L == 32) hipLaunchKernelGGL(temporal_k<32>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H);
     else { mc_set_error("temporal: latent_dim=%d unsupported (32, 64, 128)", L); return MC_ERR_ARG; }
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -36,7 +36,8 @@ struct GateArgs {
     const float* bp = nullptr;
     const float* sim_n = nullptr;  // [256][E] unit columns
     const float* logit_scale = nullptr;
-    long N = 0;
+    long tok0 = 0, N = 0;          // tokens [tok0, N)
+    int zero_cnt = 1;              // launcher clears cnt first (0: the caller did, several launches accumulate)
     int E = 0, L = 0;
     int* idx = nullptr;            // [N][2]
     float* gate = nullptr;         // [N][2]
@@ -54,7 +55,7 @@ struct RowChainArgs {
     const float* bias = nullptr;
     float* Y = nullptr;            // [N][ldy]
     long ldy = 0;
-    long N = 0;
+    long tok0 = 0, N = 0;          // tokens [tok0, N)
     int L = 0, Nout = 0;
     long twin_from = 0;            // kind 0: tokens >= twin_from (> 0) read the expert outputs of token - twin_from
 };

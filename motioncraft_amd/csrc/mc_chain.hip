@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
     float* s_bp = s_simT + 32 * LDS_SIM;           // projector bias [256]
     s_bp[tid] = g.bp[tid];
     if (tid < 2 * MAXE) s_cnt[tid] = 0;
-    const long tok = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const long tok = g.tok0 + (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool rok = tok < g.N;
     const int hf = lane >> 5, kq = hf * 4;
     // z = LN(x) * gamma + beta + embedding[(t,h)]
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     float* s_bias = smem + 2 * 32 * SP::LDS_LD;      // whole bias vector (Nout <= 4L): a global load per chunk would sit on the critical path
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < g.Nout; i += 256) s_bias[i] = g.bias[i];
-    const long tok = (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const long tok = g.tok0 + (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool rok = tok < g.N;
     const int kq = (lane >> 5) * 4;
     f32x4 xf[NJ];
@@ -430,7 +430,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 23;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 side stream at any batch, 4 CFG twin dedupe in layer 0
+        v = e ? atoi(e) : 55;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams
     }
     return v;
 }
@@ -470,9 +470,9 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
 
 int mc_launch_gate(const GateArgs& g, hipStream_t s) {
     MC_REQUIRE(g.E >= 2 && g.E <= 16, "gate: num_experts=%d unsupported (2..16)", g.E);
-    if (g.N <= 0) return MC_OK;
-    MC_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * 32, s));
-    dim3 grid(cdiv(g.N, 128));
+    if (g.zero_cnt) MC_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * 32, s));
+    if (g.N <= g.tok0) return MC_OK;
+    dim3 grid(cdiv(g.N - g.tok0, 128));
     switch (g.L) {
         case 128: hipLaunchKernelGGL(gate_k<128>, grid, dim3(256), 0, s, g); break;
         case 64: hipLaunchKernelGGL(gate_k<64>, grid, dim3(256), 0, s, g); break;
@@ -485,8 +485,8 @@ int mc_launch_gate(const GateArgs& g, hipStream_t s) {
 
 int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s) {
     MC_REQUIRE(g.Nout % 32 == 0 && g.ldy % 4 == 0, "rowchain: Nout=%d / ldy unsupported", g.Nout);
-    if (g.N <= 0) return MC_OK;
-    dim3 grid(cdiv(g.N, 128));
+    if (g.N <= g.tok0) return MC_OK;
+    dim3 grid(cdiv(g.N - g.tok0, 128));
 #define MC_RC_CASE(LL)                                                                    \
     case LL:                                                                              \
         if (kind == 0) hipLaunchKernelGGL((rowchain_k<LL, 0>), grid, dim3(256), 0, s, g);  \

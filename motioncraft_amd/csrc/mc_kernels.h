@@ -78,5 +78,6 @@ const int* mc_route_num_tiles_ptr(const RouteBufs& rb);
 int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* wsm, float* ys,
                    long frames, int H, int L, int G, hipStream_t s);
 // temporal linear attention over text (+) motion tokens: yt[(b,t)][h*L + c]
+// samples [b0, b0 + nb) of the CFG-doubled batch (B = samples per CFG half)
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int B2, int B, int T, int Nt, int H, int L, hipStream_t s);
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s);

@@ -66,6 +66,10 @@ struct mc_ctx {
     // (LN + qkv -> body attention) of the same layer (fork after the MoE projection, join before proj_out)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // large batches: the batch is cut into `nparts` groups of whole samples, group k > 0 runs on parts[k-1]
+    hipStream_t parts[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
+    int nparts = 2;
     int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
     float* cap_w = nullptr;      // ... and combine weights (0 = dropped) of every layer
 };
@@ -233,6 +237,7 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
         b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
         if ((r = mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s))) return r;
     }
+    if (!out) return MC_OK;                        // the caller launches the projection itself (row ranges)
     if (mc_chain_enabled(2) && mc_mlp_supported(din, 32) && w.dout % 32 == 0) {
         RowChainArgs p;
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.proj_w; p.bias = w.proj_b;
@@ -247,99 +252,187 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     return mc_launch_gemm(GM_COMB, p, 1, 0, s);
 }
 
+// rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
-               const float* ss, const float* out_w, const float* out_b, hipStream_t s) {
+               const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s) {
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
+    const long o = row0 * D;
     int r;
-    if ((r = mc_launch_film_rows(y1, y2, ln_g, ln_b, ss, c->a, c->rows, D, s))) return r;
+    if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s))) return r;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
-    return dense(c->a, D, out_w, D, out_b, hs, D, hs, D, c->rows, D, D, ACT_NONE, s);
+    return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
 }
 
-// One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
-// `i` selects the layer slot (weights, text K/V, FiLM tables): base layers first, control copies after.
-int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, hipStream_t s) {
+// Everything of a DecoderLayer AFTER the expert MLP, restricted to residual-stream rows [row0, row0 + nrows)
+// (whole samples): MoE combine + proj, body LN + q/k/v, body and temporal attention, proj_out FiLM block, SFFN, its
+// FiLM block.  Every kernel here is row-independent, so disjoint row ranges can run on different streams.
+int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st) {
+    const mc_model_config& g = c->m->cfg;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
+    const LayerW& w = c->lw[i];
+    const long tok0 = row0 * H, ntok = nrows * H;
+    int r;
+    // ---- post-score combine + GELU + MOE.proj -> mf [N][4L] ----
+    if (mc_chain_enabled(2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
+        RowChainArgs p;
+        p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.mm.proj_w; p.bias = w.mm.proj_b;
+        p.Y = c->mf; p.ldy = 4 * L; p.tok0 = tok0; p.N = tok0 + ntok; p.L = L; p.Nout = 4 * L;
+        p.twin_from = twin ? c->N / 2 : 0;
+        if ((r = mc_launch_rowchain(0, p, s))) return r;
+    } else {
+        GemmArgs p;
+        p.A = c->y2 + 2 * tok0 * L; p.lda = L; p.comb_w = c->rb.comb_w + 2 * tok0;
+        p.W = w.mm.proj_w; p.ldw = L; p.bias = w.mm.proj_b;
+        p.C = c->mf + tok0 * 4 * L; p.ldc = 4 * L; p.M = (int)ntok; p.N = 4 * L; p.K = L;
+        if ((r = mc_launch_gemm(GM_COMB, p, 1, 0, s))) return r;
+    }
+    // ---- temporal linear attention: needs only mf; on `st` (a second stream for small batches) or inline ----
+    const float* tfl = c->tf + (long)i * c->Ntxt * 2 * L;
+    if (st != s) {
+        MC_HIP(hipEventRecord(c->ev_fork, s));
+        MC_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
+        if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
+                                    g.max_text_len, H, L, st))) return r;
+        MC_HIP(hipEventRecord(c->ev_join, st));
+    }
+    // ---- dynamic body topology: shared LayerNorm + q/k/v ----
+    if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
+        RowChainArgs q;
+        q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
+        q.Y = c->qkv; q.ldy = 3 * L; q.tok0 = tok0; q.N = tok0 + ntok; q.L = L; q.Nout = 3 * L;
+        if ((r = mc_launch_rowchain(1, q, s))) return r;
+    } else {
+        if ((r = mc_launch_ln_rows(c->mf + tok0 * 4 * L, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z + tok0 * L, L, ntok, L, s))) return r;
+        if ((r = dense(c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, s))) return r;
+    }
+    if ((r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, s))) return r;
+    if (st != s) {
+        MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+        return MC_OK;
+    }
+    return mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
+                              g.max_text_len, H, L, s);
+}
+
+int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, long row0, long nrows, hipStream_t s) {
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
     const LayerW& w = c->lw[i];
     int r;
-        // ---- STMA ----
-        const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
-        // The two CFG halves enter base layer 0 with the same residual stream (the pose encoder output is written to
-        // both, stmogen.py:736-740), so gate scores and expert outputs of token i + N/2 equal those of token i:
-        // gate and experts run on the first half only, routing still ranks all N tokens ("twin" mode, mc_route.hip).
-        const bool twin = twin_ok && fused_gate && mc_chain_enabled(2) && mc_chain_enabled(4) && (c->N % 2 == 0);
-        if (fused_gate) {
-            GateArgs ga;
-            ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
-            ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
-            ga.N = twin ? c->N / 2 : c->N; ga.E = g.num_experts; ga.L = L;
-            ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
-            if ((r = mc_launch_gate(ga, s))) return r;
-        } else {
-            if ((r = mc_launch_ln_rows(hs, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
-        }
-        if ((r = run_moe(c, w.mm, c->z, c->N, c->mf, 4 * L, fused_gate, twin, s))) return r;
-        if (c->cap_idx) {
-            if (twin) {     // expert ids exist for the first half only: the twins have the same ones
-                MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
-                MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N + c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
-            } else
-            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
-            MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
-        }
-        // measured: +2.4 % at B=8, nothing at B=64 (both branches fill the CUs on their own) -> small batches only
-        const bool overlap = c->side && (mc_chain_enabled(3) || c->N <= 65536);
-        const float* tfl = c->tf + (long)i * c->Ntxt * 2 * L;
-        if (overlap) {
-            MC_HIP(hipEventRecord(c->ev_fork, s));
-            MC_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, 2 * c->B, c->B, c->T, g.max_text_len, H, L, c->side))) return r;
-            MC_HIP(hipEventRecord(c->ev_join, c->side));
-        }
-        if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
-            RowChainArgs q;
-            q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
-            q.Y = c->qkv; q.ldy = 3 * L; q.N = c->N; q.L = L; q.Nout = 3 * L;
-            if ((r = mc_launch_rowchain(1, q, s))) return r;
-        } else {
-            if ((r = mc_launch_ln_rows(c->mf, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z, L, c->N, L, s))) return r;
-            if ((r = dense(c->z, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv, 3 * L, c->N, 3 * L, L, ACT_NONE, s))) return r;
-        }
-        if ((r = mc_launch_body(c->mf, 4 * L, c->qkv, w.wsm, c->ys, c->rows, H, L, g.dyn_heads, s))) return r;
-        if (overlap) {
-            MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-        } else {
-            if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, 2 * c->B, c->B, c->T, g.max_text_len, H, L, s))) return r;
-        }
-        const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
-        if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, s))) return r;
-        // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
-        if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
-            MlpArgs m;
-            m.X = hs; m.ldx = D; m.x_gstride = L;
-            m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
-            m.Y = c->z2; m.ldy = D; m.y_gstride = L; m.M = (int)c->rows; m.L = L; m.hidden = F;
-            if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
-        } else {
-            GemmArgs f1;
-            f1.A = hs; f1.lda = D; f1.a_gstride = L;
-            f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
-            f1.bias = w.ffn_b1; f1.b_gstride = F; f1.act = ACT_GELU;
-            f1.C = c->fh; f1.ldc = (long)H * F; f1.c_gstride = F;
-            f1.M = (int)c->rows; f1.N = F; f1.K = L;
-            if ((r = mc_launch_gemm(GM_PLAIN, f1, H, 0, s))) return r;
-            GemmArgs f2;
-            f2.A = c->fh; f2.lda = (long)H * F; f2.a_gstride = F;
-            f2.W = w.ffn_w2; f2.ldw = F; f2.w_gstride = (long)L * F;
-            f2.bias = w.ffn_b2; f2.b_gstride = L;
-            f2.C = c->z2; f2.ldc = D; f2.c_gstride = L;
-            f2.M = (int)c->rows; f2.N = L; f2.K = F;
-            if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
-        }
-        const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
-        if ((r = film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, s))) return r;
+    const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
+    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s))) return r;
+    // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
+    const long o = row0 * D;
+    if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
+        MlpArgs m;
+        m.X = hs + o; m.ldx = D; m.x_gstride = L;
+        m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
+        m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;
+        if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
+    } else {
+        GemmArgs f1;
+        f1.A = hs + o; f1.lda = D; f1.a_gstride = L;
+        f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
+        f1.bias = w.ffn_b1; f1.b_gstride = F; f1.act = ACT_GELU;
+        f1.C = c->fh + row0 * H * F; f1.ldc = (long)H * F; f1.c_gstride = F;
+        f1.M = (int)nrows; f1.N = F; f1.K = L;
+        if ((r = mc_launch_gemm(GM_PLAIN, f1, H, 0, s))) return r;
+        GemmArgs f2;
+        f2.A = c->fh + row0 * H * F; f2.lda = (long)H * F; f2.a_gstride = F;
+        f2.W = w.ffn_w2; f2.ldw = F; f2.w_gstride = (long)L * F;
+        f2.bias = w.ffn_b2; f2.b_gstride = L;
+        f2.C = c->z2 + o; f2.ldc = D; f2.c_gstride = L;
+        f2.M = (int)nrows; f2.N = L; f2.K = F;
+        if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
+    }
+    const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
+    return film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, row0, nrows, s);
+}
+
+// One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
+// `i` selects the layer slot (weights, text K/V, FiLM tables): base layers first, control copies after.
+// groups of whole samples for the multi-stream schedule: group k = rows [part_row0(k), part_row0(k + 1))
+long part_row0(const mc_ctx* c, int k) { return ((long)2 * c->B * k / c->nparts) * c->T; }
+hipStream_t part_stream(const mc_ctx* c, int k, hipStream_t s) { return k == 0 ? s : c->parts[k - 1]; }
+int parts_fork(mc_ctx* c, hipStream_t s) {
+    MC_HIP(hipEventRecord(c->ev_fork, s));
+    for (int k = 1; k < c->nparts; ++k) MC_HIP(hipStreamWaitEvent(c->parts[k - 1], c->ev_fork, 0));
     return MC_OK;
+}
+int parts_join(mc_ctx* c, hipStream_t s) {
+    for (int k = 1; k < c->nparts; ++k) {
+        MC_HIP(hipEventRecord(c->ev_parts[k - 1], c->parts[k - 1]));
+        MC_HIP(hipStreamWaitEvent(s, c->ev_parts[k - 1], 0));
+    }
+    return MC_OK;
+}
+
+// `split`: 0 = one stream; 1 = CFG halves on two streams, joined at the end of the layer; 2 = same, but the halves
+// stay apart across layers (the caller joins after the last one) and the gate is split too -- the streams only meet at
+// the routing step, the one place where tokens of the whole batch are ranked against each other.
+int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hipStream_t s) {
+    const mc_model_config& g = c->m->cfg;
+    const int L = g.latent_dim, H = g.num_parts;
+    const LayerW& w = c->lw[i];
+    int r;
+    // ---- STMA: gate + routing + experts (the only part that couples tokens across the batch) ----
+    const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
+    // The two CFG halves enter base layer 0 with the same residual stream (the pose encoder output is written to
+    // both, stmogen.py:736-740), so gate scores and expert outputs of token i + N/2 equal those of token i:
+    // gate and experts run on the first half only, routing still ranks all N tokens ("twin" mode, mc_route.hip).
+    const bool twin = twin_ok && fused_gate && mc_chain_enabled(2) && mc_chain_enabled(4) && (c->N % 2 == 0);
+    if (fused_gate) {
+        GateArgs ga;
+        ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
+        ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
+        ga.E = g.num_experts; ga.L = L;
+        ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
+        if (split == 2 && !twin) {
+            MC_HIP(hipMemsetAsync(ga.cnt, 0, sizeof(int) * 32, s));
+            if ((r = parts_fork(c, s))) return r;
+            ga.zero_cnt = 0;
+            for (int k = 0; k < c->nparts; ++k) {
+                ga.tok0 = part_row0(c, k) * H; ga.N = part_row0(c, k + 1) * H;
+                if ((r = mc_launch_gate(ga, part_stream(c, k, s)))) return r;
+            }
+        } else {
+            ga.N = twin ? c->N / 2 : c->N;
+            if ((r = mc_launch_gate(ga, s))) return r;
+        }
+        if (split == 2 && (r = parts_join(c, s))) return r;      // routing ranks the whole batch: every group must have arrived
+    } else {
+        if ((r = mc_launch_ln_rows(hs, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
+    }
+    if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, s))) return r;       // up to the expert outputs
+    if (c->cap_idx) {
+        if (twin) {     // expert ids exist for the first half only: the twins have the same ones
+            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
+            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N + c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
+        } else {
+            MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * 2 * c->N, hipMemcpyDeviceToDevice, s));
+        }
+        MC_HIP(hipMemcpyAsync(c->cap_w + (long)i * 2 * c->N, c->rb.comb_w, sizeof(float) * 2 * c->N, hipMemcpyDeviceToDevice, s));
+    }
+    // ---- the row-independent rest of the layer ----
+    const long half = (long)c->B * c->T;        // rows of one CFG half
+    if (split) {
+        // Large batches: the two CFG halves go down two streams.  Each kernel of the chain fills 4.59 "waves" of
+        // workgroups at B=64, so ~8 % of every launch is a tail on a partly idle chip; with two independent chains in
+        // flight the next kernel of one half starts inside the tail of the other (same effect as two batches in flight).
+        if ((r = parts_fork(c, s))) return r;
+        for (int k = 0; k < c->nparts; ++k) {
+            hipStream_t sk = part_stream(c, k, s);
+            if ((r = layer_rows(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), sk, sk))) return r;
+        }
+        for (int k = 0; k < c->nparts; ++k)
+            if ((r = layer_rows_tail(c, i, hs, step, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+        if (split == 1 && (r = parts_join(c, s))) return r;
+        return MC_OK;
+    }
+    // Small batches: the temporal branch runs on the side stream beside LN + qkv + body (measured +2.4 % at B=8).
+    const bool side_temporal = c->side && (mc_chain_enabled(3) || c->N <= 65536);
+    if ((r = layer_rows(c, i, hs, step, twin, 0, 2 * half, s, side_temporal ? c->side : s))) return r;
+    return layer_rows_tail(c, i, hs, step, 0, 2 * half, s);
 }
 
 }  // namespace
@@ -428,6 +521,22 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
         mc_ctx_destroy(c);
         return MC_ERR_HIP;
     }
+    {
+        const char* e = getenv("MC_SPLIT");
+        c->nparts = e ? atoi(e) : 2;
+        if (c->nparts < 2) c->nparts = 2;
+        if (c->nparts > 4) c->nparts = 4;
+        if (c->nparts > 2 * batch) c->nparts = 2 * batch;
+        c->parts[0] = c->side;
+        for (int k = 0; k < c->nparts - 1; ++k) {
+            if ((k > 0 && hipStreamCreateWithFlags(&c->parts[k], hipStreamNonBlocking) != hipSuccess) ||
+                hipEventCreateWithFlags(&c->ev_parts[k], hipEventDisableTiming) != hipSuccess) {
+                mc_set_error("could not create the part streams / events");
+                mc_ctx_destroy(c);
+                return MC_ERR_HIP;
+            }
+        }
+    }
     const long Nmax = c->N > c->Ntxt ? c->N : c->Ntxt;
     const size_t zsz = (size_t)(c->N * L > c->Ntxt * Dt ? c->N * L : c->Ntxt * Dt);
     const size_t hsz = (size_t)(2 * c->N * 4 * L > 2 * c->Ntxt * 4 * Dt ? 2 * c->N * 4 * L : 2 * c->Ntxt * 4 * Dt);
@@ -477,6 +586,10 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
 void mc_ctx_destroy(mc_ctx* c) {
     if (!c) return;
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    for (int k = 1; k < 3; ++k)
+        if (c->parts[k]) { (void)hipStreamSynchronize(c->parts[k]); (void)hipStreamDestroy(c->parts[k]); }
+    for (int k = 0; k < 3; ++k)
+        if (c->ev_parts[k]) (void)hipEventDestroy(c->ev_parts[k]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (void* p : c->allocs) (void)hipFree(p);
@@ -597,6 +710,10 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
     const int NC = c->have_ctrl ? g.num_ctrl_layers : 0;
+    // large batches: the CFG halves run on two streams (see run_layer); with a control branch the extra whole-batch
+    // ops between layers need both halves, so the halves re-join after every layer
+    const bool fused = mc_chain_enabled(1) && mc_chain_enabled(2) && mc_mlp_supported(L, 32);
+    const int split = (c->side && mc_chain_enabled(5) && c->N > 65536 && fused) ? (NC > 0 ? 1 : 2) : 0;
     for (int i = 0; i < nl; ++i) {
         // ControlT2MHalf.forward_test (controlnet.py:372-413): base block 0, then for index 1..copy:
         //   c, c_skip = controlnet[index-1](x=h, c=c);  h = base[index](h + c_skip)
@@ -605,12 +722,13 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
             if (j == 0) {
                 if ((r = mc_launch_add_rows(c->hc, c->h, c->cb, nullptr, c->rows, D, s))) return r;   // x + before_proj(c)
             }
-            if ((r = run_layer(c, slot, c->hc, step, false, s))) return r;                                     // copied_block
+            if ((r = run_layer(c, slot, c->hc, step, false, split ? 1 : 0, s))) return r;                        // copied_block
             const LayerW& cw = c->lw[slot];
             if ((r = dense(c->hc, D, cw.after_w, D, cw.after_b, c->h, D, c->h, D, c->rows, D, D, ACT_NONE, s))) return r;  // h += after_proj(c)
         }
-        if ((r = run_layer(c, i, c->h, step, i == 0, s))) return r;
+        if ((r = run_layer(c, i, c->h, step, i == 0, split, s))) return r;
     }
+    if (split == 2 && (r = parts_join(c, s))) return r;      // the groups meet again before the pose decoder
     if (stop_after >= 0) return MC_OK;
     // PoseDecoder as one dense [D -> C] GEMM (stmogen.py:505-544), /2 folded into the packed weight
     float* o = out2_dev ? out2_dev : c->out2;
