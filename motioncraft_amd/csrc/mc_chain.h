@@ -34,7 +34,7 @@ struct GateArgs {
     float* Z = nullptr;            // [N][L]  LN(x)+embedding (expert input)
     const float* Wp = nullptr;     // cosine projector [256][L]
     const float* bp = nullptr;
-    const float* sim_n = nullptr;  // [256][E] unit columns
+    const float* sim_nT = nullptr; // [32][256]: unit columns of sim_matrix, transposed, rows >= E zero
     const float* logit_scale = nullptr;
     long tok0 = 0, N = 0;          // tokens [tok0, N)
     int zero_cnt = 1;              // launcher clears cnt first (0: the caller did, several launches accumulate)

@@ -241,9 +241,9 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
     auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
     float* s_simT = smem + 2 * 32 * SP::LDS_LD;    // [32 expert rows (>= E zero)][256 + 4]: sim_n^T as an MFMA "A" operand
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 32 * 256; i += 256) {
-        const int e = i >> 8, j = i & 255;
-        s_simT[e * LDS_SIM + j] = e < g.E ? g.sim_n[j * g.E + e] : 0.f;
+    for (int i = tid; i < 32 * 64; i += 256) {         // 32 rows x 64 float4 (pre-transposed at pack time: coalesced)
+        const int e = i >> 6, j4 = (i & 63) * 4;
+        *reinterpret_cast<f32x4*>(s_simT + e * LDS_SIM + j4) = *reinterpret_cast<const f32x4*>(g.sim_nT + e * 256 + j4);
     }
     float* s_bp = s_simT + 32 * LDS_SIM;           // projector bias [256]
     s_bp[tid] = g.bp[tid];

@@ -27,7 +27,7 @@ struct mc_model {
 };
 
 struct MoeW {
-    const float *emb, *gate_w, *gate_b, *sim_n, *scale, *fc1_w, *fc1_b, *fc2_wt, *fc2_b, *proj_w, *proj_b;
+    const float *emb, *gate_w, *gate_b, *sim_n, *sim_nT, *scale, *fc1_w, *fc1_b, *fc2_wt, *fc2_b, *proj_w, *proj_b;
     int din, dout;
 };
 
@@ -116,6 +116,7 @@ int bind_moe(mc_model* m, const std::string& pre, int din, int dout, int seq_row
     GP(w->gate_w, pre + "gate_w", 256 * din);
     GP(w->gate_b, pre + "gate_b", 256);
     GP(w->sim_n, pre + "sim_n", 256 * E);
+    GP(w->sim_nT, pre + "sim_nT", 32 * 256);
     GP(w->scale, pre + "scale", 1);
     GP(w->fc1_w, pre + "fc1_w", (int64_t)E * 4 * din * din);
     GP(w->fc1_b, pre + "fc1_b", (int64_t)E * 4 * din);
@@ -384,7 +385,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     if (fused_gate) {
         GateArgs ga;
         ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
-        ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_n = w.mm.sim_n; ga.logit_scale = w.mm.scale;
+        ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_nT = w.mm.sim_nT; ga.logit_scale = w.mm.scale;
         ga.E = g.num_experts; ga.L = L;
         ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
         if (split == 2 && !twin) {

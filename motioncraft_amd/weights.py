@@ -41,7 +41,11 @@ def pack_moe(sd, pre, out, key):
     out[key + 'gate_w'] = _f(sd[m + 'gates.0.cosine_projector.weight'])   # [256, Din]
     out[key + 'gate_b'] = _f(sd[m + 'gates.0.cosine_projector.bias'])
     sim = sd[m + 'gates.0.sim_matrix'].float()
-    out[key + 'sim_n'] = _f(torch.nn.functional.normalize(sim, dim=0))     # [256, E], unit columns
+    sim_n = torch.nn.functional.normalize(sim, dim=0)
+    out[key + 'sim_n'] = _f(sim_n)                                         # [256, E], unit columns
+    simT = torch.zeros(32, 256)                                            # transposed + zero rows: MFMA "A" operand of gate_k
+    simT[:sim_n.shape[1]] = sim_n.T
+    out[key + 'sim_nT'] = _f(simT)
     temp = sd[m + 'gates.0.temperature'].float()
     out[key + 'scale'] = _f(torch.clamp(temp, max=math.log(1.0 / 0.01)).exp().reshape(1))
     out[key + 'fc1_w'] = _f(sd[m + 'experts.batched_fc1_w'])               # [E, 4Din, Din]  (N, K)
