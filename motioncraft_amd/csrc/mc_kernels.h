@@ -61,7 +61,7 @@ struct RouteBufs {
     int* src_row;      // [2N]   slot -> token
     int* dst_row;      // [2N]   slot -> 2*token + choice
     // tile map
-    int* tile_group; int* tile_row0; int* tile_nrows;
+    int* tile_group; int* tile_row0; int* tile_nrows;   // [2][max_tiles] (one map per slot group)
     int* state;        // small int block, layout in mc_route.hip
     int max_tiles;
 };
@@ -70,8 +70,9 @@ size_t mc_route_state_ints(int E);
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
                           RouteBufs rb, hipStream_t s);
 // capacity/BPR drop decision + slot compaction + tile map (tile rows = 128)
-int mc_launch_route(long N, long Nsrc, int E, int capacity, RouteBufs rb, hipStream_t s);   // Nsrc = N, or N/2 (twin mode)
-const int* mc_route_num_tiles_ptr(const RouteBufs& rb);
+// Nsrc = N, or N/2 (twin mode); tokens >= gsplit get their own slot group (tile map at [max_tiles, 2 max_tiles))
+int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBufs rb, hipStream_t s);
+const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group = 0);
 
 // ---- mc_attn.hip ----------------------------------------------------------------------
 // static + dynamic body topology: ys[(b,t)][h*L + c]

@@ -202,9 +202,45 @@ int dense(const float* A, long lda, const float* W, long ldw, const float* bias,
 // One tutel MoE layer + GELU + proj (class MOE, st_attention.py:49-56) over Ntok tokens whose
 // gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
 // `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
-int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, bool gated, bool twin, hipStream_t s) {
+// expert FFN over the slots of one slot group (mc_route.hip): y2[dst_row] = FC2(gelu(FC1(z[src_row])))
+int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, hipStream_t s) {
+    const int E = c->m->cfg.num_experts, din = w.din, hid = 4 * w.din;
+    const int max_tiles = cdiv(2 * Ntok, 128) + E;
+    const long to = (long)group * c->rb.max_tiles;
+    int r;
+    if (mc_chain_enabled(0) && mc_mlp_supported(din, hid)) {
+        // fused expert FFN: hidden activations stay on chip (mc_chain.hip)
+        MlpArgs m;
+        m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
+        m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
+        m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
+        m.num_tiles = mc_route_num_tiles_ptr(c->rb, group); m.src_row = c->rb.src_row; m.dst_row = c->rb.dst_row;
+        return mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s);
+    }
+    GemmArgs a;
+    a.A = z; a.lda = din; a.src_row = c->rb.src_row;
+    a.W = w.fc1_w; a.ldw = din; a.w_gstride = (long)hid * din;
+    a.bias = w.fc1_b; a.b_gstride = hid; a.act = ACT_GELU;
+    a.C = c->hbuf; a.ldc = hid; a.N = hid; a.K = din;
+    a.tile_group = c->rb.tile_group + to; a.tile_row0 = c->rb.tile_row0 + to; a.tile_nrows = c->rb.tile_nrows + to;
+    a.num_tiles = mc_route_num_tiles_ptr(c->rb, group);
+    if ((r = mc_launch_gemm(GM_EXP1, a, 1, max_tiles, s))) return r;
+    GemmArgs b;
+    b.A = c->hbuf; b.lda = hid; b.W = w.fc2_wt; b.ldw = hid; b.w_gstride = (long)din * hid;
+    b.bias = w.fc2_b; b.b_gstride = din; b.dst_row = c->rb.dst_row;
+    b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
+    b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
+    return mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s);
+}
+
+// One tutel MoE layer + GELU + proj (class MOE, st_attention.py:49-56) over Ntok tokens whose
+// gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
+// `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
+// `gsplit` < Ntok: two slot groups; then only the routing runs here and the caller launches moe_experts per group.
+int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, bool gated, bool twin, long gsplit,
+            hipStream_t s) {
     const mc_model_config& g = c->m->cfg;
-    const int E = g.num_experts, din = w.din, hid = 4 * w.din;
+    const int E = g.num_experts, din = w.din;
     int r;
     if (!gated) {
         // cosine projector (tutel/gates/cosine_top.py): proj = z Wp^T + bp
@@ -212,32 +248,9 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
         if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
     }
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
-    if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, E, capacity, c->rb, s))) return r;
-    const int max_tiles = cdiv(2 * Ntok, 128) + E;
-    if (mc_chain_enabled(0) && mc_mlp_supported(din, hid)) {
-        // fused expert FFN: hidden activations stay on chip (mc_mlp.hip)
-        MlpArgs m;
-        m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
-        m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
-        m.tile_group = c->rb.tile_group; m.tile_row0 = c->rb.tile_row0; m.tile_nrows = c->rb.tile_nrows;
-        m.num_tiles = mc_route_num_tiles_ptr(c->rb); m.src_row = c->rb.src_row; m.dst_row = c->rb.dst_row;
-        if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
-    } else {
-        GemmArgs a;
-        a.A = z; a.lda = din; a.src_row = c->rb.src_row;
-        a.W = w.fc1_w; a.ldw = din; a.w_gstride = (long)hid * din;
-        a.bias = w.fc1_b; a.b_gstride = hid; a.act = ACT_GELU;
-        a.C = c->hbuf; a.ldc = hid; a.N = hid; a.K = din;
-        a.tile_group = c->rb.tile_group; a.tile_row0 = c->rb.tile_row0; a.tile_nrows = c->rb.tile_nrows;
-        a.num_tiles = mc_route_num_tiles_ptr(c->rb);
-        if ((r = mc_launch_gemm(GM_EXP1, a, 1, max_tiles, s))) return r;
-        GemmArgs b;
-        b.A = c->hbuf; b.lda = hid; b.W = w.fc2_wt; b.ldw = hid; b.w_gstride = (long)din * hid;
-        b.bias = w.fc2_b; b.b_gstride = din; b.dst_row = c->rb.dst_row;
-        b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
-        b.tile_group = a.tile_group; b.tile_row0 = a.tile_row0; b.tile_nrows = a.tile_nrows; b.num_tiles = a.num_tiles;
-        if ((r = mc_launch_gemm(GM_EXP2, b, 1, max_tiles, s))) return r;
-    }
+    if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, gsplit, E, capacity, c->rb, s))) return r;
+    if (gsplit < Ntok) return MC_OK;
+    if ((r = moe_experts(c, w, z, Ntok, 0, s))) return r;
     if (!out) return MC_OK;                        // the caller launches the projection itself (row ranges)
     if (mc_chain_enabled(2) && mc_mlp_supported(din, 32) && w.dout % 32 == 0) {
         RowChainArgs p;
@@ -404,7 +417,10 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     } else {
         if ((r = mc_launch_ln_rows(hs, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
     }
-    if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, s))) return r;       // up to the expert outputs
+    // two slot groups when the two sample groups run on two streams: each group's expert MLP joins its own chain
+    const bool grouped = split == 2 && c->nparts == 2 && mc_chain_enabled(6);
+    const long gsplit = grouped ? part_row0(c, 1) * H : c->N;
+    if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, gsplit, s))) return r;   // routing (+ experts if one group)
     if (c->cap_idx) {
         if (twin) {     // expert ids exist for the first half only: the twins have the same ones
             MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
@@ -420,7 +436,16 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         // Large batches: the two CFG halves go down two streams.  Each kernel of the chain fills 4.59 "waves" of
         // workgroups at B=64, so ~8 % of every launch is a tail on a partly idle chip; with two independent chains in
         // flight the next kernel of one half starts inside the tail of the other (same effect as two batches in flight).
-        if ((r = parts_fork(c, s))) return r;
+        if (grouped && twin) {         // group 1 combines group 0's expert rows (its own tokens have no slots): fork after them
+            if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s))) return r;
+            if ((r = parts_fork(c, s))) return r;
+        } else {
+            if ((r = parts_fork(c, s))) return r;
+            if (grouped) {
+                if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s))) return r;
+                if ((r = moe_experts(c, w.mm, c->z, c->N, 1, c->parts[0]))) return r;
+            }
+        }
         for (int k = 0; k < c->nparts; ++k) {
             hipStream_t sk = part_stream(c, k, s);
             if ((r = layer_rows(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), sk, sk))) return r;
@@ -575,9 +600,9 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->rb.src_row, 2 * Nmax);
     WS(c->rb.dst_row, 2 * Nmax);
     c->rb.max_tiles = cdiv(2 * Nmax, 128) + g.num_experts;
-    WS(c->rb.tile_group, c->rb.max_tiles);
-    WS(c->rb.tile_row0, c->rb.max_tiles);
-    WS(c->rb.tile_nrows, c->rb.max_tiles);
+    WS(c->rb.tile_group, 2 * c->rb.max_tiles);
+    WS(c->rb.tile_row0, 2 * c->rb.max_tiles);
+    WS(c->rb.tile_nrows, 2 * c->rb.max_tiles);
     WS(c->rb.state, mc_route_state_ints(g.num_experts));
 #undef WS
     *out = c;
@@ -648,7 +673,7 @@ int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_d
         const LayerW& w = c->lw[i];
         if ((r = mc_launch_ln_rows(xf_out_dev, Dt, 0, w.tnorm_g, w.tnorm_b, w.tm.emb, Nt, c->xfn, Dt, half, Dt, s))) return r;
         MC_HIP(hipMemcpyAsync(c->xfn + half * Dt, c->xfn, sizeof(float) * half * Dt, hipMemcpyDeviceToDevice, s));
-        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, false, false, s))) return r;
+        if ((r = run_moe(c, w.tm, c->xfn, c->Ntxt, c->tf + (long)i * c->Ntxt * 2 * L, 2 * L, false, false, c->Ntxt, s))) return r;
     }
     c->have_cond = true;
     return MC_OK;

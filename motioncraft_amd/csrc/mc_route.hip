@@ -25,14 +25,16 @@ constexpr int TILE_ROWS = 128;
 // int state block layout
 enum {
     ST_CNT = 0,                   // [2][MAXE]   tokens per (choice, expert)
-    ST_KEPT = ST_CNT + MAXP,      // [MAXE]      kept pairs per expert
-    ST_FILL = ST_KEPT + MAXE,     // [MAXE]      compaction cursors
-    ST_OFF = ST_FILL + MAXE,      // [MAXE+1]    slot range starts
-    ST_ACTIVE = ST_OFF + MAXE + 1,  // [MAXP]    1: overflowed, needs selection; 0: keep all; -1: keep none
+    // slots are laid out per (slot group g, expert e), g = 0/1 = token below / at-or-above `gsplit`: the expert MLP of
+    // each sample group can then be launched on its own stream (mc_model.hip); one group when gsplit >= N
+    ST_KEPT = ST_CNT + MAXP,      // [2][MAXE]   kept pairs per (slot group, expert)
+    ST_FILL = ST_KEPT + 2 * MAXE, // [2][MAXE]   compaction cursors
+    ST_OFF = ST_FILL + 2 * MAXE,  // [2*MAXE+1]  slot range starts
+    ST_ACTIVE = ST_OFF + 2 * MAXE + 1,  // [MAXP] 1: overflowed, needs selection; 0: keep all; -1: keep none
     ST_RANK = ST_ACTIVE + MAXP,   // [MAXP]      remaining rank during selection
     ST_ANY = ST_RANK + MAXP,      // [1]         any problem active
-    ST_NTILES = ST_ANY + 1,       // [1]
-    ST_PREFIX = ST_NTILES + 1,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
+    ST_NTILES = ST_ANY + 1,       // [2]         tiles per slot group
+    ST_PREFIX = ST_NTILES + 2,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
     ST_HIST = ST_PREFIX + 2 * MAXP,  // [MAXP][256]
     ST_TOTAL = ST_HIST + MAXP * 256
 };
@@ -119,7 +121,7 @@ __global__ void route_init_k(int* __restrict__ state, int E, int capacity, int c
         if (act == 1) atomicOr(&any, 1);
     }
     for (int i = threadIdx.x; i < MAXP * 256; i += blockDim.x) state[ST_HIST + i] = 0;
-    if (threadIdx.x < MAXE) { state[ST_KEPT + threadIdx.x] = 0; state[ST_FILL + threadIdx.x] = 0; }
+    if (threadIdx.x < 2 * MAXE) { state[ST_KEPT + threadIdx.x] = 0; state[ST_FILL + threadIdx.x] = 0; }
     __syncthreads();
     if (p == 0) state[ST_ANY] = any;
 }
@@ -188,17 +190,17 @@ __global__ __launch_bounds__(256) void route_pick_k(int* __restrict__ state) {
 
 // keep/drop + combine weights + per-expert kept counts
 __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx, const float* __restrict__ gate,
-                                                    const uint32_t* __restrict__ key, long N, long Nsrc,
+                                                    const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
                                                     float* __restrict__ comb_w, int* __restrict__ state) {
     __shared__ int s_act[MAXP];
     __shared__ unsigned long long s_thr[MAXP];
-    __shared__ int s_kept[MAXE];
+    __shared__ int s_kept[2 * MAXE];
     if (threadIdx.x < MAXP) {
         s_act[threadIdx.x] = state[ST_ACTIVE + threadIdx.x];
         s_thr[threadIdx.x] = ((unsigned long long)(uint32_t)state[ST_PREFIX + 2 * threadIdx.x] << 32) |
                              (uint32_t)state[ST_PREFIX + 2 * threadIdx.x + 1];
     }
-    if (threadIdx.x < MAXE) s_kept[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * MAXE) s_kept[threadIdx.x] = 0;
     __syncthreads();
     for (long a = (long)blockIdx.x * 256 + threadIdx.x; a < 2 * N; a += (long)gridDim.x * 256) {
         const long tok = a >> 1;
@@ -210,51 +212,58 @@ __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx,
         if (s_act[p] == -1) keep = false;
         else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok) >= s_thr[p];
         comb_w[a] = keep ? gate[as] : 0.f;
-        if (keep && tok < Nsrc) atomicAdd(&s_kept[e], 1);      // expert slots exist for the first Nsrc tokens only
+        if (keep && tok < Nsrc) atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + e], 1);   // expert slots exist for the first Nsrc tokens only
     }
     __syncthreads();
-    if (threadIdx.x < MAXE && s_kept[threadIdx.x]) atomicAdd(&state[ST_KEPT + threadIdx.x], s_kept[threadIdx.x]);
+    if (threadIdx.x < 2 * MAXE && s_kept[threadIdx.x]) atomicAdd(&state[ST_KEPT + threadIdx.x], s_kept[threadIdx.x]);
 }
 
-// slot ranges + 128-row tile map
+// slot ranges + 128-row tile maps: slot group g's tiles are written at [g * max_tiles, ...), its count at ST_NTILES + g
 __global__ void route_plan_k(int* __restrict__ state, int E, int* __restrict__ tile_group,
                              int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
-    __shared__ int s_off[MAXE + 1], s_t0[MAXE + 1];
+    __shared__ int s_off[2 * MAXE + 1], s_t0[2][MAXE + 1];
     if (threadIdx.x == 0) {
-        int off = 0, nt = 0;
-        for (int e = 0; e < E; ++e) {
-            s_off[e] = off;
-            s_t0[e] = nt;
-            state[ST_OFF + e] = off;
-            const int cnt = state[ST_KEPT + e];
-            off += cnt;
-            nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+        int off = 0;
+        for (int g = 0; g < 2; ++g) {
+            int nt = 0;
+            for (int e = 0; e < E; ++e) {
+                s_off[g * MAXE + e] = off;
+                s_t0[g][e] = nt;
+                state[ST_OFF + g * MAXE + e] = off;
+                const int cnt = state[ST_KEPT + g * MAXE + e];
+                off += cnt;
+                nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+            }
+            for (int e = E; e < MAXE; ++e) { s_off[g * MAXE + e] = off; state[ST_OFF + g * MAXE + e] = off; }
+            s_t0[g][E] = nt;
+            state[ST_NTILES + g] = min(nt, max_tiles);
         }
-        s_off[E] = off;
-        s_t0[E] = nt;
-        state[ST_OFF + E] = off;
-        state[ST_NTILES] = min(nt, max_tiles);
+        s_off[2 * MAXE] = off;
+        state[ST_OFF + 2 * MAXE] = off;
     }
     __syncthreads();
-    const int nt = min(s_t0[E], max_tiles);
-    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-        int e = 0;
-        while (e + 1 < E && s_t0[e + 1] <= t) ++e;
-        const int r = (t - s_t0[e]) * TILE_ROWS;
-        tile_group[t] = e;
-        tile_row0[t] = s_off[e] + r;
-        tile_nrows[t] = min(TILE_ROWS, s_off[e + 1] - s_off[e] - r);
+    for (int g = 0; g < 2; ++g) {
+        const int nt = min(s_t0[g][E], max_tiles);
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            int e = 0;
+            while (e + 1 < E && s_t0[g][e + 1] <= t) ++e;
+            const int r = (t - s_t0[g][e]) * TILE_ROWS;
+            const int ve = g * MAXE + e;
+            tile_group[g * max_tiles + t] = e;
+            tile_row0[g * max_tiles + t] = s_off[ve] + r;
+            tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+        }
     }
 }
 
 // compaction: workgroup-local cursors in LDS, one global reservation per (workgroup, expert)
 __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx, const float* __restrict__ comb_w,
-                                                    long N, int* __restrict__ state, int* __restrict__ src_row,
+                                                    long N, long gsplit, int* __restrict__ state, int* __restrict__ src_row,
                                                     int* __restrict__ dst_row) {
     constexpr int PER = 8;  // pairs per thread
-    __shared__ int s_cnt[MAXE];
-    __shared__ int s_base[MAXE];
-    if (threadIdx.x < MAXE) s_cnt[threadIdx.x] = 0;
+    __shared__ int s_cnt[2 * MAXE];
+    __shared__ int s_base[2 * MAXE];
+    if (threadIdx.x < 2 * MAXE) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const long a0 = ((long)blockIdx.x * 256 + threadIdx.x) * PER;
     int le[PER], lp[PER];
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx,
         const long a = a0 + i;
         le[i] = -1;
         if (a < 2 * N && comb_w[a] != 0.f) {
-            le[i] = idx[a];
+            le[i] = ((a >> 1) >= gsplit ? MAXE : 0) + idx[a];
             lp[i] = atomicAdd(&s_cnt[le[i]], 1);
         }
     }
     __syncthreads();
-    if (threadIdx.x < MAXE && s_cnt[threadIdx.x])
+    if (threadIdx.x < 2 * MAXE && s_cnt[threadIdx.x])
         s_base[threadIdx.x] = state[ST_OFF + threadIdx.x] + atomicAdd(&state[ST_FILL + threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
 #pragma unroll
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx,
 }  // namespace
 
 size_t mc_route_state_ints(int) { return ST_TOTAL; }
-const int* mc_route_num_tiles_ptr(const RouteBufs& rb) { return rb.state + ST_NTILES; }
+const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
 
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
                           RouteBufs rb, hipStream_t s) {
@@ -303,7 +312,8 @@ int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* lo
 // halves enter the first decoder layer with the same residual stream), gate outputs exist for the first half only;
 // the capacity test still ranks all N tokens (a twin ranks right behind its original: same score, larger index, so
 // "twin kept => original kept"), combine weights are produced for all N, expert slots only for the first half.
-int mc_launch_route(long N, long Nsrc, int E, int capacity, RouteBufs rb, hipStream_t s) {
+// gsplit: tokens >= gsplit form slot group 1 (own slot ranges and tile map at [max_tiles, 2 max_tiles)); >= N: one group.
+int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBufs rb, hipStream_t s) {
     MC_REQUIRE(Nsrc == N || 2 * Nsrc == N, "route: Nsrc=%ld must be N or N/2 (N=%ld)", Nsrc, N);
     hipLaunchKernelGGL(route_init_k, dim3(1), dim3(256), 0, s, rb.state, E, capacity, (int)(N / Nsrc));
     int blocks = cdiv(2 * N, 256 * 8);
@@ -313,10 +323,10 @@ int mc_launch_route(long N, long Nsrc, int E, int capacity, RouteBufs rb, hipStr
         hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, Nsrc, rb.state, pass);
         hipLaunchKernelGGL(route_pick_k, dim3(MAXP), dim3(256), 0, s, rb.state);
     }
-    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, rb.comb_w, rb.state);
+    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state);
     hipLaunchKernelGGL(route_plan_k, dim3(1), dim3(256), 0, s, rb.state, E, rb.tile_group, rb.tile_row0, rb.tile_nrows,
                        rb.max_tiles);
-    hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * Nsrc, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, Nsrc, rb.state,
+    hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * Nsrc, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, Nsrc, gsplit, rb.state,
                        rb.src_row, rb.dst_row);
     MC_LAUNCH_CHECK();
     return MC_OK;
