@@ -44,7 +44,7 @@ extern "C" {
 typedef struct mc_model mc_model;
 typedef struct mc_ctx mc_ctx;
 
-/* configs/stmogen/*.py: model=dict(type='STMoGenTransformer', ...) */
+/* the configs under configs/stmogen: model=dict(type='STMoGenTransformer', ...) */
 typedef struct mc_model_config {
     int32_t input_feats;      /* 322 (SMPL-X motionx layout)                       */
     int32_t max_seq_len;      /* 196                                               */

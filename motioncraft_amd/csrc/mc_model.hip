@@ -282,7 +282,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
 // FiLM block.  Every kernel here is row-independent, so disjoint row ranges can run on different streams.
 int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st) {
     const mc_model_config& g = c->m->cfg;
-    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H;
     const LayerW& w = c->lw[i];
     const long tok0 = row0 * H, ntok = nrows * H;
     int r;
@@ -720,7 +720,7 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     MC_REQUIRE(step >= 0 && step < c->S, "step_index %d outside the %d-step schedule", step, c->S);
     hipStream_t s = (hipStream_t)stream;
     const mc_model_config& g = c->m->cfg;
-    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim, C = g.input_feats;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, C = g.input_feats;
     const long BT = (long)c->B * c->T;
     int r;
     // PoseEncoder as one dense [C -> D] GEMM with the scattered weight, + sequence_embedding[:T],
