@@ -34,7 +34,8 @@ enum {
     ST_RANK = ST_ACTIVE + MAXP,   // [MAXP]      remaining rank during selection
     ST_ANY = ST_RANK + MAXP,      // [1]         any problem active
     ST_NTILES = ST_ANY + 1,       // [2]         tiles per slot group
-    ST_PREFIX = ST_NTILES + 2,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
+    ST_DONE = ST_NTILES + 2,      // [2]         finished-workgroup counters (hist pass, keep pass): the last one continues
+    ST_PREFIX = ST_DONE + 2,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
     ST_HIST = ST_PREFIX + 2 * MAXP,  // [MAXP][256]
     ST_TOTAL = ST_HIST + MAXP * 256
 };
@@ -122,6 +123,7 @@ __global__ void route_init_k(int* __restrict__ state, int E, int capacity, int c
     }
     for (int i = threadIdx.x; i < MAXP * 256; i += blockDim.x) state[ST_HIST + i] = 0;
     if (threadIdx.x < 2 * MAXE) { state[ST_KEPT + threadIdx.x] = 0; state[ST_FILL + threadIdx.x] = 0; }
+    if (threadIdx.x < 2) state[ST_DONE + threadIdx.x] = 0;
     __syncthreads();
     if (p == 0) state[ST_ANY] = any;
 }
@@ -154,44 +156,97 @@ __global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx,
     __syncthreads();
     for (int i = threadIdx.x; i < MAXP * 256; i += 256)
         if (h[i]) atomicAdd(&state[ST_HIST + i], h[i]);
+    // ---- the last workgroup to get here picks, per active problem, the bin holding the rank-th largest element ----
+    __threadfence();
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&state[ST_DONE], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = wave; p < MAXP; p += 4) {                       // one wavefront per problem, 4 bins per lane
+        if (s_act[p] != 1) continue;
+        int cb[4], t = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int* hp = &state[ST_HIST + p * 256 + 4 * lane + j];
+            cb[j] = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // other CUs' atomics live in L2
+            *hp = 0;
+            t += cb[j];
+        }
+        int suf = t;                                             // inclusive suffix sum over lanes (bins descending)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += v;
+        }
+        const int rank = state[ST_RANK + p];
+        int above = suf - t;                                     // elements in bins above this lane's 4
+        int found = -1, above_found = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const int incl = above + cb[j];                      // suffix count including bin 4*lane+j
+            if (found < 0 && incl >= rank && above < rank) { found = 4 * lane + j; above_found = above; }
+            above = incl;
+        }
+        if (found >= 0) {
+            unsigned long long pre = s_pre[p];
+            pre = (pre << 8) | (unsigned long long)found;
+            state[ST_PREFIX + 2 * p] = (int)(uint32_t)(pre >> 32);
+            state[ST_PREFIX + 2 * p + 1] = (int)(uint32_t)pre;
+            state[ST_RANK + p] = rank - above_found;
+        }
+    }
+    if (threadIdx.x == 0) state[ST_DONE] = 0;
 }
 
-// pick the bin holding the rank-th largest element; one workgroup per problem
-__global__ __launch_bounds__(256) void route_pick_k(int* __restrict__ state) {
-    if (state[ST_ANY] == 0) return;
-    const int p = blockIdx.x;
-    if (state[ST_ACTIVE + p] != 1) return;
-    __shared__ int suf[257];
-    const int b = threadIdx.x;
-    const int c = state[ST_HIST + p * 256 + b];
-    suf[b] = c;
-    if (b == 0) suf[256] = 0;
+// slot ranges + 128-row tile maps: slot group g's tiles are written at [g * max_tiles, ...), its count at ST_NTILES + g
+__device__ __forceinline__ void plan_tiles(int* __restrict__ state, int E, int* __restrict__ tile_group,
+                                           int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
+    __shared__ int s_off[2 * MAXE + 1], s_t0[2][MAXE + 1], s_cnt2[2 * MAXE];
+    if (threadIdx.x < 2 * MAXE)      // the other workgroups' atomics live in L2: 32 parallel agent-scope loads, not 32 serial ones
+        s_cnt2[threadIdx.x] = __hip_atomic_load(&state[ST_KEPT + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    // suffix sums (inclusive): suf[b] = sum_{j >= b} hist[j]
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = (b + o < 256) ? suf[b + o] : 0;
-        __syncthreads();
-        suf[b] += v;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int g = 0; g < 2; ++g) {
+            int nt = 0;
+            for (int e = 0; e < E; ++e) {
+                s_off[g * MAXE + e] = off;
+                s_t0[g][e] = nt;
+                state[ST_OFF + g * MAXE + e] = off;
+                const int cnt = s_cnt2[g * MAXE + e];
+                off += cnt;
+                nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+            }
+            for (int e = E; e < MAXE; ++e) { s_off[g * MAXE + e] = off; state[ST_OFF + g * MAXE + e] = off; }
+            s_t0[g][E] = nt;
+            state[ST_NTILES + g] = min(nt, max_tiles);
+        }
+        s_off[2 * MAXE] = off;
+        state[ST_OFF + 2 * MAXE] = off;
     }
-    const int rank = state[ST_RANK + p];
-    // the chosen bin is the largest b with suf[b] >= rank  (suf is non-increasing in b)
-    const bool here = suf[b] >= rank && suf[b + 1] < rank;
-    state[ST_HIST + p * 256 + b] = 0;
-    if (here) {
-        unsigned long long pre = ((unsigned long long)(uint32_t)state[ST_PREFIX + 2 * p] << 32) |
-                                 (uint32_t)state[ST_PREFIX + 2 * p + 1];
-        pre = (pre << 8) | (unsigned long long)b;
-        state[ST_PREFIX + 2 * p] = (int)(uint32_t)(pre >> 32);
-        state[ST_PREFIX + 2 * p + 1] = (int)(uint32_t)pre;
-        state[ST_RANK + p] = rank - suf[b + 1];
+    __syncthreads();
+    for (int g = 0; g < 2; ++g) {
+        const int nt = min(s_t0[g][E], max_tiles);
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            int e = 0;
+            while (e + 1 < E && s_t0[g][e + 1] <= t) ++e;
+            const int r = (t - s_t0[g][e]) * TILE_ROWS;
+            const int ve = g * MAXE + e;
+            tile_group[g * max_tiles + t] = e;
+            tile_row0[g * max_tiles + t] = s_off[ve] + r;
+            tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+        }
     }
 }
 
 // keep/drop + combine weights + per-expert kept counts
 __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                     const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
-                                                    float* __restrict__ comb_w, int* __restrict__ state) {
+                                                    float* __restrict__ comb_w, int* __restrict__ state, int E,
+                                                    int* __restrict__ tile_group, int* __restrict__ tile_row0,
+                                                    int* __restrict__ tile_nrows, int max_tiles) {
     __shared__ int s_act[MAXP];
     __shared__ unsigned long long s_thr[MAXP];
     __shared__ int s_kept[2 * MAXE];
@@ -216,44 +271,15 @@ __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx,
     }
     __syncthreads();
     if (threadIdx.x < 2 * MAXE && s_kept[threadIdx.x]) atomicAdd(&state[ST_KEPT + threadIdx.x], s_kept[threadIdx.x]);
-}
-
-// slot ranges + 128-row tile maps: slot group g's tiles are written at [g * max_tiles, ...), its count at ST_NTILES + g
-__global__ void route_plan_k(int* __restrict__ state, int E, int* __restrict__ tile_group,
-                             int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
-    __shared__ int s_off[2 * MAXE + 1], s_t0[2][MAXE + 1];
-    if (threadIdx.x == 0) {
-        int off = 0;
-        for (int g = 0; g < 2; ++g) {
-            int nt = 0;
-            for (int e = 0; e < E; ++e) {
-                s_off[g * MAXE + e] = off;
-                s_t0[g][e] = nt;
-                state[ST_OFF + g * MAXE + e] = off;
-                const int cnt = state[ST_KEPT + g * MAXE + e];
-                off += cnt;
-                nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
-            }
-            for (int e = E; e < MAXE; ++e) { s_off[g * MAXE + e] = off; state[ST_OFF + g * MAXE + e] = off; }
-            s_t0[g][E] = nt;
-            state[ST_NTILES + g] = min(nt, max_tiles);
-        }
-        s_off[2 * MAXE] = off;
-        state[ST_OFF + 2 * MAXE] = off;
-    }
+    // the last workgroup to finish turns the kept counts into slot ranges + tile maps
+    __threadfence();
+    __shared__ int s_last;
     __syncthreads();
-    for (int g = 0; g < 2; ++g) {
-        const int nt = min(s_t0[g][E], max_tiles);
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-            int e = 0;
-            while (e + 1 < E && s_t0[g][e + 1] <= t) ++e;
-            const int r = (t - s_t0[g][e]) * TILE_ROWS;
-            const int ve = g * MAXE + e;
-            tile_group[g * max_tiles + t] = e;
-            tile_row0[g * max_tiles + t] = s_off[ve] + r;
-            tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
-        }
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd(&state[ST_DONE + 1], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    plan_tiles(state, E, tile_group, tile_row0, tile_nrows, max_tiles);
+    if (threadIdx.x == 0) state[ST_DONE + 1] = 0;
 }
 
 // compaction: workgroup-local cursors in LDS, one global reservation per (workgroup, expert)
@@ -321,11 +347,9 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
     if (blocks < 1) blocks = 1;
     for (int pass = 0; pass < 8; ++pass) {
         hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, Nsrc, rb.state, pass);
-        hipLaunchKernelGGL(route_pick_k, dim3(MAXP), dim3(256), 0, s, rb.state);
     }
-    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state);
-    hipLaunchKernelGGL(route_plan_k, dim3(1), dim3(256), 0, s, rb.state, E, rb.tile_group, rb.tile_row0, rb.tile_nrows,
-                       rb.max_tiles);
+    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state,
+                       E, rb.tile_group, rb.tile_row0, rb.tile_nrows, rb.max_tiles);
     hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * Nsrc, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, Nsrc, gsplit, rb.state,
                        rb.src_row, rb.dst_row);
     MC_LAUNCH_CHECK();
