@@ -632,3 +632,49 @@ def test_edge_cases_vs_oracle(case):
             assert dropped > 0.3 * forced[0][1].numel()
     ctx.close()
     nm.close()
+
+
+def test_long_sequence_windows_repaint_vs_oracle(small_model):
+    """Caller side of the RePaint mode (tools/m2d_test.py:139-232 window loop): 3 windows of 24 frames advancing by
+    18, each later window keeping its first 6 frames equal to the previous window's last 6; the HIP windows are
+    checked against the CPU oracle run with the same draws and the same window plumbing."""
+    import types
+    import motioncraft_amd as mc
+    from motioncraft_amd import longform
+    from oracle import stmogen_oracle as O, weights as W
+    sd, _ = small_model
+    opt = types.SimpleNamespace(same_overlap_noisy=False, no_repaint=False, addBlend=True, overlap_len=6, no_resample=True,
+                                jump_length=3, jump_n_sample=5, timestep_respacing='ddim50')
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    cfg.model['opt'] = opt
+    arch = mc.build_architecture(cfg.model)
+    arch.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    g = torch.Generator().manual_seed(123)
+    xf = torch.nn.functional.layer_norm(torch.randn(1, SMALL['Nt'], SMALL['Dt'], generator=g), (SMALL['Dt'],))
+    first_gt = torch.randn(6, 322, generator=g)
+    x_Ts = [torch.randn(1, 24, 322, generator=g) for _ in range(3)]
+    total, L, pre = 60, 24, 6
+    assert longform.window_starts(total, L, pre) == (3, 18)
+
+    def draws(seed):
+        gen = torch.Generator().manual_seed(seed)
+        return (torch.randn(1, 24, 322, generator=gen) for _ in range(10 ** 6))
+    rec, wins = longform.sample_long(arch, total, L, pre, repaint=True, overlap_len=6, first_gt=first_gt,
+                                     condition_kwargs=dict(xf_out=xf.cuda()),
+                                     inference_kwargs=lambda i: dict(noise=x_Ts[i], step_noise=draws(50 + i)))
+    assert rec.shape == (18 + 18 + 24, 322) and len(wins) == 3
+    # the same loop on the oracle
+    sched, mask, prev, ref_parts = O.Schedule(1000, '15,15,8,6,6'), torch.ones(1, 24), None, []
+    keep = torch.zeros(1, 24, 322, dtype=torch.bool)
+    keep[:, :6] = True
+    for i in range(3):
+        gt = torch.zeros(1, 24, 322)
+        gt[:, :6] = first_gt if i == 0 else prev[:, -6:]
+        prev = O.sample_loop_repaint(sd, SMALL, sched, x_Ts[i], xf, mask, keep, gt, draws(50 + i), 6, 50, no_resample=True)
+        ref_parts.append(prev[0] if i == 2 else prev[0, :18])
+        err = maxabs(T_(wins[i]), prev[0])
+        print(f'long-form window {i}: |hip - oracle| {err:.2e}')
+        assert err <= TOL_FINAL
+    assert maxabs(T_(rec), torch.cat(ref_parts)) <= TOL_FINAL
+    assert np.abs(wins[1][0] - wins[0][-6]).max() <= 1e-6          # frame 0 of a later window IS the previous frame -6
+    arch.model.release()
