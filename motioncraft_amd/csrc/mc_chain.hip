@@ -258,13 +258,13 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
         const long tk = rok ? tok : g.N - 1;
         const float* xp = g.X + tk * g.ldx + kq;
         const float* ep = g.emb + (tk % g.emb_mod) * L + kq;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) zf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+        frag_layernorm<NJ>(zf, g.gamma, g.beta, kq);
+        // embedding rows: one batch of NJ unconditional loads after the LayerNorm (holding them across it spills)
         f32x4 ef[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            zf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
-            ef[j] = *reinterpret_cast<const f32x4*>(ep + 8 * j);
-        }
-        frag_layernorm<NJ>(zf, g.gamma, g.beta, kq);
+        for (int j = 0; j < NJ; ++j) ef[j] = *reinterpret_cast<const f32x4*>(ep + 8 * j);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) zf[j] += ef[j];
         if (rok) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
     // (the C^T fragment of a chunk is the B operand of the [32 -> experts] product)
     float ss = 0.f;
     f32x16 lacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    SP sp;
+    SP sp;                                 // (requesting this chunk before the row loads spills in this kernel: 256 VGPRs)
     sp.fetch(g.Wp, L, 0, 0, tid);
     sp.commit(Ws(0), tid);
     sp.fetch(g.Wp, L, 32, 0, tid);
@@ -372,6 +372,8 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     const long tok = g.tok0 + (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool rok = tok < g.N;
     const int kq = (lane >> 5) * 4;
+    SP sp;
+    sp.fetch(g.W, L, 0, 0, tid);          // first weight chunk requested before the row loads: its latency hides behind them
     f32x4 xf[NJ];
     if constexpr (KIND == 0) {
         const long tk = rok ? tok : 0;
@@ -400,8 +402,6 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
         frag_layernorm<NJ>(xf, g.gamma, g.beta, kq);
     }
     const int nc = g.Nout / 32;
-    SP sp;
-    sp.fetch(g.W, L, 0, 0, tid);
     sp.commit(Ws(0), tid);
     if (nc > 1) sp.fetch(g.W, L, 32, 0, tid);
     __syncthreads();
