@@ -678,3 +678,38 @@ def test_long_sequence_windows_repaint_vs_oracle(small_model):
     assert maxabs(T_(rec), torch.cat(ref_parts)) <= TOL_FINAL
     assert np.abs(wins[1][0] - wins[0][-6]).max() <= 1e-6          # frame 0 of a later window IS the previous frame -6
     arch.model.release()
+
+
+@pytest.mark.parametrize('case', ['s2g_025b', 'm2d_finedance'])
+def test_baseline_control_configs_at_full_architecture_vs_oracle(case):
+    """BASELINE configs[2] / [3] architectures at their real widths, one denoiser call at B=1 vs the CPU oracle:
+    S2G (configs/stmogen/S2G_Beats2_no_face_loss_025b.py: L=128, 8 layers, copy_blocks_num=2, T=64... here 196 frames,
+    pre-encoded audio condition of width D) and M2D (M2D_finedance_no_face_loss.py: L=64, 4 layers, copy_blocks_num=3,
+    35-d music features, 120-frame windows)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    if case == 's2g_025b':
+        dims, copy, feats, T, Tc = W.default_dims(NL=8), 2, 1536, 196, 150
+    else:
+        dims, copy, feats, T, Tc = W.default_dims(L=64, F=256), 3, 35, 120, 120
+    sd = W.make_state_dict(dims, 0, shapes=W.control_param_shapes(dims, copy, feats))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    assert nm.copy_blocks_num == copy and nm.control_cond_feats == feats
+    x, xf, mask = synth_inputs(dims, 1, T, seed=71, lengths=[T - 9])
+    g = torch.Generator().manual_seed(72)
+    c = torch.randn(1, Tc, feats, generator=g)
+    ctx = nm.context(1, T, max_steps=1)
+    ctx.enable_capture()
+    ctx.set_timesteps([480])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    ctx.set_control(c.cuda())
+    out2 = ctx.denoise(x.cuda(), 0)
+    w = (1 - (1000 - 480) / 1000) * dims['scale'] + 1
+    got = out2[:1] * w + out2[1:] * (1 - w)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    ref = O.denoise_control(sd, dims, x, 480, xf, mask, c, copy)
+    err = maxabs(got, ref)
+    print(f'{case}: NL={dims["NL"]} L={dims["L"]} copy={copy}: |hip - oracle| {err:.2e} (|ref| max {float(ref.abs().max()):.2f})')
+    assert err <= TOL_STEP
+    ctx.close()
+    nm.close()
