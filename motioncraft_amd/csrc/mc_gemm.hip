@@ -22,7 +22,7 @@
 //   GM_EXP2   expert FC2: A row = slot, C row = dst_row[slot]  (= 2*token + choice)
 //   GM_COMB   A[r][k] = gelu(w0[r]*Y[2r][k] + w1[r]*Y[2r+1][k]) (post-score combine of the two
 //             expert outputs of a token, dropped choices have w = 0), then dense GEMM
-//   GM_ENC    pose encoder: unaligned K=322 rows (scalar loads), + row-periodic add table
+//   GM_ENC    pose encoder / first conv layer: rows may be unaligned (scalar loads on the guarded path), + row-periodic add table
 //             (positional embedding) and duplicate-row write (the two CFG halves share h0)
 #include "mc_common.h"
 #include "mc_gemm.h"
@@ -52,7 +52,7 @@ __device__ __forceinline__ void load_tile(const GemmArgs& g, const float* __rest
                 if (st.cw1[i] != 0.f) y1 = *reinterpret_cast<const f32x4*>(Ab + st.aoff[i] + g.lda + k);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = gelu_exact(st.cw0[i] * y0[j] + st.cw1[i] * y1[j]);
-            } else if constexpr (MODE == GM_ENC) {
+            } else if constexpr (MODE == GM_ENC && GUARD) {      // unaligned rows (K or lda not a multiple of 4): scalar loads
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (k + j < g.K) v[j] = Ab[st.aoff[i] + k + j];
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const bool full = nrows == BM && (tn + 1) * BN <= g.N && (g.K % BK) == 0 && MODE != GM_ENC;
+    const bool full = nrows == BM && (tn + 1) * BN <= g.N && (g.K % BK) == 0 &&
+                      (MODE != GM_ENC || (g.lda % 4 == 0 && g.a_gstride % 4 == 0));
     if (full) {
         if (g.tune & 1) mainloop<MODE, false, true>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);
         else mainloop<MODE, false, false>(g, Ab, Wb, st, As, Bs, sr, sk, wm, wn, lane, acc);

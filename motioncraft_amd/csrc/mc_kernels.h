@@ -42,6 +42,8 @@ struct InpaintArgs {
 };
 int mc_launch_sampler_inpaint(const float* x_t, const float* out_text, const float* out_none, const float* noise,
                               InpaintArgs ip, float* x_prev, float* x0_out, long n, SamplerCoefs c, hipStream_t s);
+// Y[r][0:Cp] = X[r][0:C], zero padded (aligned rows for the pose-encoder GEMM)
+int mc_launch_pad_rows(const float* X, float* Y, long rows, int C, int Cp, hipStream_t s);
 int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s);
 
 // ---- mc_post.hip ----------------------------------------------------------------------

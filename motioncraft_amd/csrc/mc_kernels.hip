@@ -221,6 +221,17 @@ __global__ __launch_bounds__(256) void sampler_inpaint_k(const float* __restrict
     }
 }
 
+// Y[r][0:Cp] = X[r][0:C] zero-extended: the pose rows (322 / 263 / 251 floats, 8-byte aligned at best) become
+// 16-byte aligned rows of the encoder GEMM's k-step multiple, so that GEMM takes its vector-load fast path
+__global__ __launch_bounds__(256) void pad_rows_k(const float* __restrict__ X, float* __restrict__ Y, long rows, int C, int Cp) {
+    const long n = rows * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / Cp;
+        const int c = (int)(i % Cp);
+        Y[i] = c < C ? X[r * C + c] : 0.f;
+    }
+}
+
 // out = a x + b noise  (the forward "undo" step of the resampling schedule, gaussian_diffusion.py:429-435)
 __global__ __launch_bounds__(256) void axpby_k(const float* __restrict__ x, const float* __restrict__ y, float a, float b,
                                                float* __restrict__ out, long n) {
@@ -308,6 +319,15 @@ int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out
     int blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(axpby_k, dim3(blocks), dim3(256), 0, s, x, y, a, b, out, n);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_pad_rows(const float* X, float* Y, long rows, int C, int Cp, hipStream_t s) {
+    if (rows <= 0) return MC_OK;
+    int blocks = cdiv(rows * Cp, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pad_rows_k, dim3(blocks), dim3(256), 0, s, X, Y, rows, C, Cp);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

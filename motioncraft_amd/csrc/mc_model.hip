@@ -23,7 +23,7 @@ struct mc_model {
     mc_model_config cfg;
     std::map<std::string, std::pair<float*, int64_t>> params;
     bool finalized = false;
-    int Cp = 0;  // input_feats padded to a multiple of 4 (row stride of enc.w)
+    int Cp = 0;  // input_feats padded to a multiple of 32 (row stride of enc.w and of the padded pose rows)
 };
 
 struct MoeW {
@@ -55,7 +55,7 @@ struct mc_ctx {
     // workspace
     std::vector<void*> allocs;
     int64_t bytes = 0;
-    float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2;
+    float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2, *xpad;
     float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
     const float* mask = nullptr;
     int* t_orig;
@@ -490,7 +490,7 @@ int mc_model_create(const mc_model_config* cfg, mc_model** out) {
     }
     mc_model* m = new mc_model();
     m->cfg = *cfg;
-    m->Cp = (cfg->input_feats + 3) / 4 * 4;
+    m->Cp = (cfg->input_feats + 31) / 32 * 32;
     *out = m;
     return MC_OK;
 }
@@ -580,6 +580,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->z2, c->rows * D);
     WS(c->fh, c->rows * H * F);
     WS(c->out2, c->rows * g.input_feats);
+    WS(c->xpad, (long)batch * frames * m->Cp);
     WS(c->xfn, c->Ntxt * Dt);
     WS(c->tf, (long)c->NLA * c->Ntxt * 2 * L);
     WS(c->t_orig, max_steps);
@@ -726,12 +727,13 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     // PoseEncoder as one dense [C -> D] GEMM with the scattered weight, + sequence_embedding[:T],
     // written to both CFG halves (stmogen.py:336-353; diffusion_transformer.py:215-218; stmogen.py:740)
     {
+        if ((r = mc_launch_pad_rows(x_t, c->xpad, BT, C, c->m->Cp, s))) return r;
         GemmArgs e;
-        e.A = x_t; e.lda = C;
+        e.A = c->xpad; e.lda = c->m->Cp;
         e.W = c->enc_w; e.ldw = c->m->Cp; e.bias = c->enc_b;
         e.add = c->seq_emb; e.add_mod = c->T; e.ld_add = D;
         e.C = c->h; e.ldc = D; e.dup_rows = BT;
-        e.M = (int)BT; e.N = D; e.K = C;
+        e.M = (int)BT; e.N = D; e.K = c->m->Cp;
         if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;

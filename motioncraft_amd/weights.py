@@ -94,7 +94,7 @@ def pack_state_dict(state_dict, dims):
     sd = strip_prefix(state_dict)
     L, H, NL, C = dims['L'], dims['H'], dims['NL'], dims['input_feats']
     D = L * H
-    Cp = (C + 3) // 4 * 4
+    Cp = (C + 31) // 32 * 32        # pose channels padded to the GEMM's k-step: the library pads x_t rows to match
     names, sl, body = part_layout(dims.get('dataset', 'motionx'))
     assert H == len(names) + 1 and len(body) == C, 'num_heads / input_feats do not match the dataset part layout'
     out = OrderedDict()

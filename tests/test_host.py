@@ -186,7 +186,7 @@ def test_weight_packing_layouts():
     sd = synthetic.make_state_dict(SMALL, 0)
     p = weights.pack_state_dict({'model.' + k: v for k, v in sd.items()}, SMALL)   # checkpoint prefix stripped
     L, H, C = SMALL['L'], SMALL['H'], 322
-    assert p['enc.w'].shape == (L * H, 324) and p['dec.w'].shape == (C, L * H)
+    assert p['enc.w'].shape == (L * H, 352) and p['dec.w'].shape == (C, L * H)
     sl = synthetic.smplx_part_slices()
     x = torch.randn(3, C)
     # dense encoder == per-part linears (reference stmogen.py:336-353)
@@ -223,7 +223,7 @@ def test_skeleton_part_layouts_and_packing():
         sd = synthetic.make_state_dict(dims, 0)
         p = weights.pack_state_dict(sd, dims)
         L, H = 32, 8
-        assert p['enc.w'].shape == (L * H, (C + 3) // 4 * 4) and p['dec.w'].shape == (C, L * H)
+        assert p['enc.w'].shape == (L * H, (C + 31) // 32 * 32) and p['dec.w'].shape == (C, L * H)
         x = torch.randn(3, C)
         feats = [x[:, sl[n]] @ sd[f'joint_embed.{n}_embed.weight'].T + sd[f'joint_embed.{n}_embed.bias'] for n in names]
         feats.append(x[:, body] @ sd['joint_embed.body_embed.weight'].T + sd['joint_embed.body_embed.bias'])
