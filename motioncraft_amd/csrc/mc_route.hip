@@ -34,7 +34,7 @@ enum {
     ST_RANK = ST_ACTIVE + MAXP,   // [MAXP]      remaining rank during selection
     ST_ANY = ST_RANK + MAXP,      // [1]         any problem active
     ST_NTILES = ST_ANY + 1,       // [2]         tiles per slot group
-    ST_DONE = ST_NTILES + 2,      // [2]         finished-workgroup counters (hist pass, keep pass): the last one continues
+    ST_DONE = ST_NTILES + 2,      // [2]         finished-workgroup counter of the histogram pass: the last one picks the bin
     ST_PREFIX = ST_DONE + 2,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
     ST_HIST = ST_PREFIX + 2 * MAXP,  // [MAXP][256]
     ST_TOTAL = ST_HIST + MAXP * 256
@@ -201,11 +201,10 @@ __global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx,
 }
 
 // slot ranges + 128-row tile maps: slot group g's tiles are written at [g * max_tiles, ...), its count at ST_NTILES + g
-__device__ __forceinline__ void plan_tiles(int* __restrict__ state, int E, int* __restrict__ tile_group,
-                                           int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
+__global__ void route_plan_k(int* __restrict__ state, int E, int* __restrict__ tile_group,
+                             int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
     __shared__ int s_off[2 * MAXE + 1], s_t0[2][MAXE + 1], s_cnt2[2 * MAXE];
-    if (threadIdx.x < 2 * MAXE)      // the other workgroups' atomics live in L2: 32 parallel agent-scope loads, not 32 serial ones
-        s_cnt2[threadIdx.x] = __hip_atomic_load(&state[ST_KEPT + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 2 * MAXE) s_cnt2[threadIdx.x] = state[ST_KEPT + threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
         int off = 0;
@@ -227,26 +226,22 @@ __device__ __forceinline__ void plan_tiles(int* __restrict__ state, int E, int* 
         state[ST_OFF + 2 * MAXE] = off;
     }
     __syncthreads();
-    for (int g = 0; g < 2; ++g) {
-        const int nt = min(s_t0[g][E], max_tiles);
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-            int e = 0;
-            while (e + 1 < E && s_t0[g][e + 1] <= t) ++e;
-            const int r = (t - s_t0[g][e]) * TILE_ROWS;
-            const int ve = g * MAXE + e;
-            tile_group[g * max_tiles + t] = e;
-            tile_row0[g * max_tiles + t] = s_off[ve] + r;
-            tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+    for (int g = 0; g < 2; ++g)
+        for (int e = 0; e < E; ++e) {                              // expert by expert: no per-tile search for its expert
+            const int ve = g * MAXE + e, t1 = min(s_t0[g][e + 1], max_tiles);
+            for (int t = s_t0[g][e] + threadIdx.x; t < t1; t += blockDim.x) {
+                const int r = (t - s_t0[g][e]) * TILE_ROWS;
+                tile_group[g * max_tiles + t] = e;
+                tile_row0[g * max_tiles + t] = s_off[ve] + r;
+                tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+            }
         }
-    }
 }
 
 // keep/drop + combine weights + per-expert kept counts
 __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                     const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
-                                                    float* __restrict__ comb_w, int* __restrict__ state, int E,
-                                                    int* __restrict__ tile_group, int* __restrict__ tile_row0,
-                                                    int* __restrict__ tile_nrows, int max_tiles) {
+                                                    float* __restrict__ comb_w, int* __restrict__ state) {
     __shared__ int s_act[MAXP];
     __shared__ unsigned long long s_thr[MAXP];
     __shared__ int s_kept[2 * MAXE];
@@ -271,15 +266,6 @@ __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx,
     }
     __syncthreads();
     if (threadIdx.x < 2 * MAXE && s_kept[threadIdx.x]) atomicAdd(&state[ST_KEPT + threadIdx.x], s_kept[threadIdx.x]);
-    // the last workgroup to finish turns the kept counts into slot ranges + tile maps
-    __threadfence();
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&state[ST_DONE + 1], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    plan_tiles(state, E, tile_group, tile_row0, tile_nrows, max_tiles);
-    if (threadIdx.x == 0) state[ST_DONE + 1] = 0;
 }
 
 // compaction: workgroup-local cursors in LDS, one global reservation per (workgroup, expert)
@@ -348,8 +334,10 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
     for (int pass = 0; pass < 8; ++pass) {
         hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, Nsrc, rb.state, pass);
     }
-    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state,
-                       E, rb.tile_group, rb.tile_row0, rb.tile_nrows, rb.max_tiles);
+    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state);
+    // (planning inside the keep kernel's last workgroup was measured slower: 39 us vs 10 + 14 for the two launches)
+    hipLaunchKernelGGL(route_plan_k, dim3(1), dim3(256), 0, s, rb.state, E, rb.tile_group, rb.tile_row0, rb.tile_nrows,
+                       rb.max_tiles);
     hipLaunchKernelGGL(route_fill_k, dim3(cdiv(2 * Nsrc, 256 * 8)), dim3(256), 0, s, rb.idx, rb.comb_w, Nsrc, gsplit, rb.state,
                        rb.src_row, rb.dst_row);
     MC_LAUNCH_CHECK();
