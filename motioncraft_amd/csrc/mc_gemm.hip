@@ -317,13 +317,103 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-DMA variant of the plain GEMM for launches made of full tiles only (M % 128 == N % 128 == K % 32 == 0):
+// `global_load_lds_dwordx4` writes each lane's 16 bytes straight into LDS (lane-linear, 1 KiB per wave-instruction),
+// so there is no register staging and no ds_write in the k-loop.  The LDS image is the unpadded [128][32] tile; the
+// 16-byte chunk a lane fetches is XOR-swizzled with its row (chunk c of row r sits at position c ^ (r & 7)) so the
+// b128 fragment reads of 8 consecutive rows hit 8 different bank groups (rows r and r+8 still share one: 2-way).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_dma_k(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BK];
+    float* As = smem;                  // [2][BM][BK]
+    float* Bs = smem + 2 * BM * BK;    // [2][BN][BK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = g.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * BM;
+    const float* __restrict__ Ab = g.A + g.a_col;
+    const float* __restrict__ Wb = g.W;
+    // DMA assignment: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per instruction;
+    // lane l -> row 8q + (l >> 3), LDS position l & 7, global chunk (l & 7) ^ (l >> 3)
+    const int dr = lane >> 3, dc = ((lane & 7) ^ dr) * 4;
+    const float* ga = Ab + (long)(row0 + 32 * wave + dr) * g.lda + dc;
+    const float* gw = Wb + (long)(tn * BN + 32 * wave + dr) * g.ldw + dc;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);    // the LDS destination goes to M0: must be provably uniform
+    auto issue = [&](int kt, int buf) {
+        float* la = As + buf * BM * BK + 32 * wave_u * BK;
+        float* lw = Bs + buf * BN * BK + 32 * wave_u * BK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds(ga + (long)8 * q * g.lda + kt * BK, la + 8 * q * BK, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gw + (long)8 * q * g.ldw + kt * BK, lw + 8 * q * BK, 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int frow = lane & 31, hf = lane >> 5, sw = frow & 7;
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto ld_frag = [&](const float* At, const float* Bt, int j) {
+        const int pos = ((2 * j + hf) ^ sw) * 4;          // rows frow and frow + 32 share frow & 7
+        Frag f;
+        f.a0 = *reinterpret_cast<const f32x4*>(At + pos);
+        f.a1 = *reinterpret_cast<const f32x4*>(At + 32 * BK + pos);
+        f.b0 = *reinterpret_cast<const f32x4*>(Bt + pos);
+        f.b1 = *reinterpret_cast<const f32x4*>(Bt + 32 * BK + pos);
+        return f;
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a0[i], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a0[i], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a1[i], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a1[i], acc[1][1], 0, 0, 0);
+        }
+    };
+    const int nk = g.K / BK;
+    issue(0, 0);
+    __syncthreads();                                      // (its fence waits vmcnt(0): the DMA has landed)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);          // in flight during the 64 MFMAs below
+        const float* At = As + buf * BM * BK + (wm * 64 + frow) * BK;
+        const float* Bt = Bs + buf * BN * BK + (wn * 64 + frow) * BK;
+        // fragments of k-group j+1 are requested BEFORE the 16 MFMAs of group j (sched_barrier: the scheduler otherwise
+        // sinks the reads to their use and exposes the LDS latency four times per k-tile)
+        Frag f0 = ld_frag(At, Bt, 0);
+        Frag f1 = ld_frag(At, Bt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        f0 = ld_frag(At, Bt, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1);
+        f1 = ld_frag(At, Bt, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0);
+        mma(f1);
+        __syncthreads();
+    }
+    if (g.act == ACT_GELU) epilogue_vec<GM_PLAIN, false, ACT_GELU>(g, 0, row0, BM, tn, wm, wn, lane, acc);
+    else if (g.act == ACT_SILU) epilogue_vec<GM_PLAIN, false, ACT_SILU>(g, 0, row0, BM, tn, wm, wn, lane, acc);
+    else if (g.act == ACT_NONE) epilogue_vec<GM_PLAIN, false, ACT_NONE>(g, 0, row0, BM, tn, wm, wn, lane, acc);
+    else epilogue_vec<GM_PLAIN, false, ACT_LRELU>(g, 0, row0, BM, tn, wm, wn, lane, acc);
+}
+
 }  // namespace
 
 static int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_GEMM_TUNE");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 17;
     }
     return v;
 }
@@ -336,6 +426,13 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
     if (ntm <= 0 || ntn <= 0) return MC_OK;
     if (mode != GM_ENC) MC_REQUIRE(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
     dim3 grid(ntm * ntn, groups > 0 ? groups : 1, 1);
+    const bool vec_out = (g.ldc % 4 == 0) && (g.c_col % 4 == 0) && (!g.R || g.ldr % 4 == 0);
+    if ((g.tune & 16) && mode == GM_PLAIN && groups <= 1 && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
+        g.lda % 4 == 0 && g.ldw % 4 == 0 && g.a_col % 4 == 0 && vec_out && g.act != ACT_QUICKGELU && !g.act_after_res) {
+        hipLaunchKernelGGL(gemm_dma_k, grid, dim3(256), 0, stream, g);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
     switch (mode) {
         case GM_PLAIN: hipLaunchKernelGGL(gemm_k<GM_PLAIN>, grid, dim3(256), 0, stream, g); break;
         case GM_EXP1: hipLaunchKernelGGL(gemm_k<GM_EXP1>, grid, dim3(256), 0, stream, g); break;
