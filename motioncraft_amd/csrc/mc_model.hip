@@ -771,19 +771,44 @@ static SamplerCoefs to_coefs(const mc_step_coefs* k) {
     return c;
 }
 
+// The pose decoder is affine, so  w dec(h_text) + (1 - w) dec(h_none) = dec(w h_text + (1 - w) h_none):  the sampler
+// entry points combine the two CFG halves of the residual stream first and decode B*T rows instead of 2*B*T
+// (mc_denoise, which hands out both decoded halves, keeps the reference's order).
+static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, void* stream, const float** x0c) {
+    const mc_model_config& g = c->m->cfg;
+    int r = mc_denoise(c, x_t, step, nullptr, g.num_layers, stream);          // all layers, no decoder
+    if (r != MC_OK) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = g.latent_dim * g.num_parts, C = g.input_feats;
+    const long BT = (long)c->B * c->T;
+    if ((r = mc_launch_axpby(c->h, c->h + BT * D, k->text_coef, k->none_coef, c->a, BT * D, s))) return r;
+    if ((r = dense(c->a, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+    *x0c = c->out2;
+    return MC_OK;
+}
+
+static SamplerCoefs combined_coefs(const mc_step_coefs* k) {
+    SamplerCoefs sc = to_coefs(k);
+    sc.text_coef = 1.f;                  // x0 is already the CFG-combined prediction
+    sc.none_coef = 0.f;
+    return sc;
+}
+
 int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
                    float* x_prev, float* x0, void* stream) {
     MC_REQUIRE(c && x_t && k && noise && x_prev, "null argument");
-    int r = mc_denoise(c, x_t, step, nullptr, -1, stream);
+    const float* x0c = nullptr;
+    int r = denoise_combined(c, x_t, step, k, stream, &x0c);
     if (r != MC_OK) return r;
     const long n = (long)c->B * c->T * c->m->cfg.input_feats;
-    return mc_launch_sampler_update(x_t, c->out2, c->out2 + n, noise, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
+    return mc_launch_sampler_update(x_t, x0c, x0c, noise, x_prev, x0, n, combined_coefs(k), (hipStream_t)stream);
 }
 
 int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
                            const mc_inpaint* ip, float* x_prev, float* x0, void* stream) {
     MC_REQUIRE(c && x_t && k && noise && x_prev && ip, "null argument");
-    int r = mc_denoise(c, x_t, step, nullptr, -1, stream);
+    const float* x0c = nullptr;
+    int r = denoise_combined(c, x_t, step, k, stream, &x0c);
     if (r != MC_OK) return r;
     const int C = c->m->cfg.input_feats;
     const long n = (long)c->B * c->T * C;
@@ -791,7 +816,7 @@ int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_s
     a.gt = ip->gt_dev; a.keep = ip->keep_dev; a.gt_noise = ip->gt_noise_dev; a.blend_w = ip->blend_w_dev;
     a.blend_len = ip->blend_len; a.T = c->T; a.C = C;
     MC_REQUIRE(a.blend_len >= 0 && a.blend_len <= c->T, "blend_len %d outside the %d-frame window", a.blend_len, c->T);
-    return mc_launch_sampler_inpaint(x_t, c->out2, c->out2 + n, noise, a, x_prev, x0, n, to_coefs(k), (hipStream_t)stream);
+    return mc_launch_sampler_inpaint(x_t, x0c, x0c, noise, a, x_prev, x0, n, combined_coefs(k), (hipStream_t)stream);
 }
 
 int mc_postprocess_smplx(const float* pred, const int32_t* lengths, const double* mean, const double* stdv,
