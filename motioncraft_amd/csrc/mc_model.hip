@@ -67,6 +67,7 @@ struct mc_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // large batches: the batch is cut into `nparts` groups of whole samples, group k > 0 runs on parts[k-1]
+    bool defer_last_gemm = false;   // sampler entry points: the last FiLM GEMM runs on the CFG-combined rows (see denoise_combined)
     hipStream_t parts[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
     int nparts = 2;
@@ -268,11 +269,13 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
 
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
-               const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s) {
+               const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
+               bool prologue_only = false) {
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     const long o = row0 * D;
     int r;
     if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s))) return r;
+    if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
     return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
 }
@@ -360,7 +363,8 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, long row0, long nrows
         if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
     }
     const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
-    return film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, row0, nrows, s);
+    return film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, row0, nrows, s,
+                      c->defer_last_gemm && i == g.num_layers - 1);
 }
 
 // One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
@@ -776,13 +780,23 @@ static SamplerCoefs to_coefs(const mc_step_coefs* k) {
 // (mc_denoise, which hands out both decoded halves, keeps the reference's order).
 static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, void* stream, const float** x0c) {
     const mc_model_config& g = c->m->cfg;
-    int r = mc_denoise(c, x_t, step, nullptr, g.num_layers, stream);          // all layers, no decoder
+    // ... and so is the Linear of the very last StylizationBlock (h += a W^T + b): it, too, runs once on the combined
+    // rows  h_c = comb(h) + comb(a) W^T + b  instead of on both halves.
+    const bool defer = mc_chain_enabled(7);
+    c->defer_last_gemm = defer;
+    int r = mc_denoise(c, x_t, step, nullptr, g.num_layers, stream);          // all layers (minus that GEMM), no decoder
+    c->defer_last_gemm = false;
     if (r != MC_OK) return r;
     hipStream_t s = (hipStream_t)stream;
     const int D = g.latent_dim * g.num_parts, C = g.input_feats;
     const long BT = (long)c->B * c->T;
-    if ((r = mc_launch_axpby(c->h, c->h + BT * D, k->text_coef, k->none_coef, c->a, BT * D, s))) return r;
-    if ((r = dense(c->a, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+    const LayerW& w = c->lw[g.num_layers - 1];
+    if ((r = mc_launch_axpby(c->h, c->h + BT * D, k->text_coef, k->none_coef, c->z2, BT * D, s))) return r;     // h_c
+    if (defer) {
+        if ((r = mc_launch_axpby(c->a, c->a + BT * D, k->text_coef, k->none_coef, c->a, BT * D, s))) return r;      // a_c
+        if ((r = dense(c->a, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
+    }
+    if ((r = dense(c->z2, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
     *x0c = c->out2;
     return MC_OK;
 }
