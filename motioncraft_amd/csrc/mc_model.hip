@@ -48,6 +48,7 @@ struct mc_ctx {
     long N = 0, rows = 0, Ntxt = 0;
     std::vector<LayerW> lw;
     const float *enc_w, *enc_b, *seq_emb, *time_w0, *time_b0, *time_w2, *time_b2, *dec_w, *dec_b;
+    const float *dec_wf = nullptr, *dec_bf = nullptr;   // decoder folded with the last StylizationBlock Linear (optional)
     const float *ctrl_in_w = nullptr, *ctrl_in_b = nullptr;
     int NLA = 0;                 // base + control layers (weights, text K/V and FiLM tables are per layer slot)
     float *hc = nullptr, *cb = nullptr, *cenc = nullptr;   // control stream, before_proj(c) [rows,D], forward_c(c) [B*T,D]
@@ -141,6 +142,10 @@ int bind_weights(mc_ctx* c) {
     GP(c->time_b2, "time.b2", Te);
     GP(c->dec_w, "dec.w", (int64_t)g.input_feats * D);
     GP(c->dec_b, "dec.b", g.input_feats);
+    if (m->params.count("dec.wf") && m->params.count("dec.bf")) {
+        GP(c->dec_wf, "dec.wf", (int64_t)g.input_feats * D);
+        GP(c->dec_bf, "dec.bf", g.input_feats);
+    }
     c->NLA = g.num_layers + g.num_ctrl_layers;
     c->lw.resize(c->NLA);
     if (g.num_ctrl_layers > 0) {
@@ -794,6 +799,14 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
     if ((r = mc_launch_axpby(c->h, c->h + BT * D, k->text_coef, k->none_coef, c->z2, BT * D, s))) return r;     // h_c
     if (defer) {
         if ((r = mc_launch_axpby(c->a, c->a + BT * D, k->text_coef, k->none_coef, c->a, BT * D, s))) return r;      // a_c
+        if (c->dec_wf) {
+            // ... and that Linear composed with the decoder is one [C, D] matrix (folded at pack time):
+            // x0 = dec(h_c) + a_c (Wd W)^T + Wd b  -- two skinny GEMMs instead of a 1536^2 one plus the decoder
+            if ((r = dense(c->z2, D, c->dec_w, D, c->dec_bf, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+            if ((r = dense(c->a, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+            *x0c = c->out2;
+            return MC_OK;
+        }
         if ((r = dense(c->a, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
     }
     if ((r = dense(c->z2, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;

@@ -121,6 +121,12 @@ def pack_state_dict(state_dict, dims):
     dec_w[:, (H - 1) * L:] = 0.5 * sd['out.body_out.weight'].float()
     dec_b += 0.5 * sd['out.body_out.bias'].float()
     out['dec.w'], out['dec.b'] = _f(dec_w), _f(dec_b)
+    # the Linear of the LAST StylizationBlock (h += a W^T + b) followed by the affine decoder, folded (in fp64) into one
+    # [C, D] matrix for the sampler entry points:  dec(h + a W^T + b) = dec(h) + a (Wd W)^T + Wd b
+    lastp = f'temporal_decoder_blocks.{NL - 1}.ffn.proj_out.out_layers.2.'
+    Wl, bl = sd[lastp + 'weight'].double(), sd[lastp + 'bias'].double()
+    out['dec.wf'] = _f((dec_w.double() @ Wl).float())
+    out['dec.bf'] = _f((dec_b.double() + dec_w.double() @ bl).float())
 
     for i in range(NL):
         pack_layer(sd, f'temporal_decoder_blocks.{i}.', out, f'l{i}.', H)
