@@ -713,3 +713,32 @@ def test_baseline_control_configs_at_full_architecture_vs_oracle(case):
     assert err <= TOL_STEP
     ctx.close()
     nm.close()
+
+
+def test_control_branch_through_the_sampler_step():
+    """The sampler entry point (CFG-combined, folded tail) with the control branch active: 12 DDIM steps of the small
+    control config against the oracle's denoise_control + ddim_step, including the end of the schedule (i = 0)."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    g = load('control_small.npz')
+    sd = W.make_state_dict(CTRL, SMALL_SEED, shapes=W.control_param_shapes(CTRL, CTRL_COPY, CTRL_FEATS))
+    nm = NativeModel(CTRL, sd, cfg_scale=CTRL['scale'])
+    x, xf, mask, c = (T_(g[k]) for k in ('x_t', 'xf_out', 'motion_mask', 'c'))
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    sched = O.Schedule(1000, '15,15,8,6,6')
+    ctx = nm.context(2, 24, max_steps=50)
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    ctx.set_control(c.cuda())
+    noises = step_noise_from_seed(4, tuple(x.shape), 12)
+    xg, xo = x.cuda(), x
+    for n, i in enumerate([49, 48, 47, 30, 29, 11, 10, 4, 3, 2, 1, 0]):
+        xg_in = xg.cpu()
+        xg = ctx.sample_step(xg, i, d.step_coefs(i, 'ddim', CTRL['scale']), noises[n].cuda())
+        x0 = O.denoise_control(sd, CTRL, xg_in, sched.timestep_map[i], xf, mask, c, CTRL_COPY)
+        ref = O.ddim_step(sched, i, xg_in, x0, noises[n])
+        assert maxabs(xg, ref) <= TOL_STEP, i
+    ctx.close()
+    nm.close()
