@@ -372,8 +372,6 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, long row0, long nrows
                       c->defer_last_gemm && i == g.num_layers - 1);
 }
 
-// One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
-// `i` selects the layer slot (weights, text K/V, FiLM tables): base layers first, control copies after.
 // groups of whole samples for the multi-stream schedule: group k = rows [part_row0(k), part_row0(k + 1))
 long part_row0(const mc_ctx* c, int k) { return ((long)2 * c->B * k / c->nparts) * c->T; }
 hipStream_t part_stream(const mc_ctx* c, int k, hipStream_t s) { return k == 0 ? s : c->parts[k - 1]; }
@@ -390,6 +388,8 @@ int parts_join(mc_ctx* c, hipStream_t s) {
     return MC_OK;
 }
 
+// One DecoderLayer (STMA + SFFN, stmogen.py:610-623) in place on the residual stream `hs` [rows, D];
+// `i` selects the layer slot (weights, text K/V, FiLM tables): base layers first, control copies after.
 // `split`: 0 = one stream; 1 = CFG halves on two streams, joined at the end of the layer; 2 = same, but the halves
 // stay apart across layers (the caller joins after the last one) and the gate is split too -- the streams only meet at
 // the routing step, the one place where tokens of the whole batch are ranked against each other.
