@@ -742,3 +742,46 @@ def test_control_branch_through_the_sampler_step():
         assert maxabs(xg, ref) <= TOL_STEP, i
     ctx.close()
     nm.close()
+
+
+@pytest.mark.parametrize('which', ['all_layers', 'layer0_only'])
+def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
+    """Degenerate gate (cosine projector with zero weight, so its output is the bias for every token): all tokens
+    have the SAME score vector, pick the same two experts with exactly tied importance, batch-prioritised routing falls
+    back to token order, those two experts overflow massively and the capacity cut lands BETWEEN a first-CFG-half
+    token and its identical second-half twin.  Exercises the stable tie order of the radix select and the twin-dedupe
+    bookkeeping of base layer 0 when twins end up with different keep flags; routing must equal the free-running oracle
+    exactly.  (Ties BETWEEN experts inside one token's top-2 are left out: torch.topk's tie order is
+    implementation-defined, i.e. the reference itself has no single answer there.)"""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    dims = SMALL
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    layers = range(dims['NL']) if which == 'all_layers' else [0]
+    for l in layers:
+        pre = f'temporal_decoder_blocks.{l}.ca_block.motion_moe.model.gates.0.cosine_projector.'
+        sd[pre + 'weight'] = torch.zeros_like(sd[pre + 'weight'])
+        sd[pre + 'bias'] = torch.randn(sd[pre + 'bias'].shape, generator=torch.Generator().manual_seed(11 + l))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    x, xf, mask = synth_inputs(dims, 2, 24, seed=97, lengths=[24, 20])
+    ctx = nm.context(2, 24, max_steps=1)
+    ctx.enable_capture()
+    ctx.set_timesteps([333])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    out2 = ctx.denoise(x.cuda(), 0)
+    w = (1 - (1000 - 333) / 1000) * dims['scale'] + 1
+    got = out2[:2] * w + out2[2:] * (1 - w)
+    cap = {}
+    ref = O.denoise(sd, dims, x, 333, xf, mask, cap=cap)                 # free-running oracle: no teacher forcing
+    N = 2 * 2 * 24 * dims['H']
+    for l in layers:
+        idx, keep = ctx.routing(l)
+        free = cap[f'layer{l}']['routing']['free']
+        assert torch.equal(idx, torch.stack(free['indices'], 1)) and torch.equal(keep, torch.stack(free['keeps'], 1)), l
+        assert bool((idx[:, 0] == idx[0, 0]).all()) and bool((idx[:, 1] == idx[0, 1]).all())
+        assert bool(keep[:N // 2, 0].any()) and not bool(keep[N // 2:, 0].any())     # twins split by the capacity cut
+    err = maxabs(got, ref)
+    print(f'exact ties ({which}): |hip - oracle| {err:.2e}')
+    assert err <= TOL_STEP
+    ctx.close()
+    nm.close()
