@@ -31,7 +31,8 @@ __device__ __forceinline__ void static_for_16(F&& f) {
 
 template <int HD, int H>
 __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, long ldmf, const float* __restrict__ qkv,
-                                                   const float* __restrict__ wsm, float* __restrict__ ys, long frames) {
+                                                   const float* __restrict__ wsm, float* __restrict__ ys, long frames,
+                                                   TwinAlias alias, long frame0) {
     constexpr int G = 8, L = G * HD;
     constexpr int GPW = 64 / HD;                 // (frame, head) groups per wave
     __shared__ float s_w[H * H];
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
     const long frame = grp / G;
     const int gh = (int)(grp % G), l = lane % HD;
     if (frame >= frames) return;                 // whole HD-lane groups leave together
+    if (alias.split_flag && frame0 + frame >= alias.from && *alias.split_flag == 0) return;   // identical to the twin frame: not produced
     const int c = gh * HD + l;
     const long tok0 = frame * H;
     float bv[H], q[H], k[H], v[H];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
 template <int L>
 __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                      const float* __restrict__ mask, float* __restrict__ yt,
-                                                     int b0, int B, int T, int Nt, int H) {
+                                                     int b0, int B, int T, int Nt, int H, const int* twin_flag) {
     constexpr int NT = L / 32;           // 32-wide d tiles (= active waves)
     constexpr int LP = L + 4;
     constexpr int C4 = L / 4;            // float4 columns per row
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = b0 + blockIdx.x / H, h = blockIdx.x % H;
     const float cnd = b < B ? 1.f : 0.f;             // text-conditioned half first (stmogen.py:736-739)
+    // CFG twin aliasing (base layer 0): the motion rows of sample b >= B were not produced, they equal sample b - B's
+    const int bm = (twin_flag && b >= B && *twin_flag == 0) ? b - B : b;
     const float* mrow = mask + (long)(b % B) * T;
     const int Nseq = Nt + T;
     const float NEG = -1000000.f;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
         const bool txt = nc < Nt;
         t = txt ? 0 : nc - Nt;
         const float* rt = tf + ((long)b * Nt + (txt ? nc : 0)) * 2 * L + c4;            // [key | value]
-        const float* rm = mf + (((long)b * T + t) * H + h) * D4 + L + c4;               // [.. | key | value | ..]
+        const float* rm = mf + (((long)bm * T + t) * H + h) * D4 + L + c4;              // [.. | key | value | ..]
         return txt ? rt : rm;
     };
     auto issue_kv = [&](int n, int c4, f32x4& kk, f32x4& vv, float& mv) {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
     auto prefetch_q = [&](int tc) {
         const int t = tc * 32 + qrow;
         if (t < T) {
-            const float* r = mf + (((long)b * T + t) * H + h) * D4 + 3 * L + qsub * SEG;
+            const float* r = mf + (((long)bm * T + t) * H + h) * D4 + 3 * L + qsub * SEG;
 #pragma unroll
             for (int j = 0; j < SEG; j += 4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(r + j);
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
 }  // namespace
 
 int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* wsm, float* ys,
-                   long frames, int H, int L, int G, hipStream_t s) {
+                   long frames, int H, int L, int G, hipStream_t s, TwinAlias alias, long frame0) {
     MC_REQUIRE(G == 8 && (H == 12 || H == 8) && (L == 32 || L == 64 || L == 128), "body: H=%d L=%d G=%d unsupported", H, L, G);
     if (frames <= 0) return MC_OK;
     const int hd = L / G;
@@ -362,9 +366,9 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
     const long waves = (groups * hd + 63) / 64;
     dim3 grid((unsigned)((waves + 3) / 4));
 #define MC_BODY_CASE(HH)                                                                                          \
-    if (hd == 16) hipLaunchKernelGGL((body_reg_k<16, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);    \
-    else if (hd == 8) hipLaunchKernelGGL((body_reg_k<8, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames); \
-    else hipLaunchKernelGGL((body_reg_k<4, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames);
+    if (hd == 16) hipLaunchKernelGGL((body_reg_k<16, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames, alias, frame0);    \
+    else if (hd == 8) hipLaunchKernelGGL((body_reg_k<8, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames, alias, frame0); \
+    else hipLaunchKernelGGL((body_reg_k<4, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames, alias, frame0);
     if (H == 12) { MC_BODY_CASE(12) } else { MC_BODY_CASE(8) }   // motionx: 12 parts; human_ml3d / kit_ml: 8
 #undef MC_BODY_CASE
     MC_LAUNCH_CHECK();
@@ -372,12 +376,12 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 }
 
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s) {
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag) {
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
-    if (L == 128) hipLaunchKernelGGL(temporal_k<128>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H);
-    else if (L == 64) hipLaunchKernelGGL(temporal_k<64>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H);
-    else if (L == 32) hipLaunchKernelGGL(temporal_k<32>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H);
+    if (L == 128) hipLaunchKernelGGL(temporal_k<128>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    else if (L == 64) hipLaunchKernelGGL(temporal_k<64>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    else if (L == 32) hipLaunchKernelGGL(temporal_k<32>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
     else { mc_set_error("temporal: latent_dim=%d unsupported (32, 64, 128)", L); return MC_ERR_ARG; }
     MC_LAUNCH_CHECK();
     return MC_OK;

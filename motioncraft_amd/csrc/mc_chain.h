@@ -1,6 +1,7 @@
 // Register-chained row-panel kernels (mc_chain.hip): fused MLP, gate, combine+proj+LN+qkv.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "mc_kernels.h"
 #include <stdint.h>
 
 enum { MLP_EXPERT = 0, MLP_PARTS = 1 };
@@ -58,6 +59,7 @@ struct RowChainArgs {
     long tok0 = 0, N = 0;          // tokens [tok0, N)
     int L = 0, Nout = 0;
     long twin_from = 0;            // kind 0: tokens >= twin_from (> 0) read the expert outputs of token - twin_from
+    TwinAlias alias;               // tokens >= alias.from are neither computed nor stored while *alias.split_flag == 0
 };
 
 bool mc_chain_enabled(int which);   // 0: fused mlp, 1: gate, 2: rowchain (proj, qkv)   (env MC_CHAIN bitmask, default all)

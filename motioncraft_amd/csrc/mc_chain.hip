@@ -370,13 +370,16 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < g.Nout; i += 256) s_bias[i] = g.bias[i];
     const long tok = g.tok0 + (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
-    const bool rok = tok < g.N;
+    // CFG twin aliasing (base layer 0): rows identical to their twin's are not produced at all
+    const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
+    if (aliasing && g.tok0 + (long)blockIdx.x * 128 >= g.alias.from) return;
+    const bool rok = tok < g.N && !(aliasing && tok >= g.alias.from);
     const int kq = (lane >> 5) * 4;
     SP sp;
     sp.fetch(g.W, L, 0, 0, tid);          // first weight chunk requested before the row loads: its latency hides behind them
     f32x4 xf[NJ];
     if constexpr (KIND == 0) {
-        const long tk = rok ? tok : 0;
+        const long tk = tok < g.N ? tok : 0;
         const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
         const long ty = (g.twin_from > 0 && tk >= g.twin_from) ? tk - g.twin_from : tk;    // CFG twin: same expert outputs
         const float* y0 = g.X + 2 * ty * L + kq;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
             for (int i = 0; i < 4; ++i) xf[j][i] = gelu_exact((k0 ? w0 * ya[j][i] : 0.f) + (k1 ? w1 * yb[j][i] : 0.f));
     } else {
         // rows past N read row N-1 instead (never stored): a load under `if (rok)` costs one exposed latency per j
-        const float* xp = g.X + (rok ? tok : g.N - 1) * g.ldx + kq;
+        const float* xp = g.X + (tok < g.N ? tok : g.N - 1) * g.ldx + kq;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
         frag_layernorm<NJ>(xf, g.gamma, g.beta, kq);
@@ -430,7 +433,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 247;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded)
+        v = e ? atoi(e) : 503;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0
     }
     return v;
 }

@@ -3,13 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// CFG twin aliasing in base layer 0: while *split_flag == 0 the rows >= `from` of mf / qkv / ys are bit-identical to
+// rows (r - from); producers neither compute nor store them, consumers read the twin's.  flag == nullptr: off.
+struct TwinAlias {
+    const int* split_flag = nullptr;
+    long from = 0;
+};
+
 // ---- mc_kernels.hip -------------------------------------------------------------------
 // Y[r][0:L] = LN_L(X[r*ldx + x_col : +L]) * gamma + beta (+ add[(r % add_mod)*L + c])
 int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, const float* beta,
                       const float* add, int add_mod, float* Y, long ldy, long rows, int L, hipStream_t s);
 // A[r][0:D] = silu( LN_D(Y1[r] (+ Y2[r])) * gamma + beta ) * (1 + ss[0:D]) + ss[D:2D] ) -- StylizationBlock prologue
+// y1_alias: Y1 rows (global row index row0 + r) >= from are read from row - from while the flag is clear
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
-                        const float* ss, float* A, long rows, int D, hipStream_t s);
+                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias = TwinAlias(), long row0 = 0);
 // te[s][0:D] = cat(cos(t_s f), sin(t_s f))
 int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s);
 int mc_launch_silu(const float* X, float* Y, long n, hipStream_t s);
@@ -75,12 +83,14 @@ int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* lo
 // Nsrc = N, or N/2 (twin mode); tokens >= gsplit get their own slot group (tile map at [max_tiles, 2 max_tiles))
 int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBufs rb, hipStream_t s);
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group = 0);
+// twin mode: 1 after routing iff some second-half token was kept/dropped differently from its first-half twin
+const int* mc_route_split_flag_ptr(const RouteBufs& rb);
 
 // ---- mc_attn.hip ----------------------------------------------------------------------
 // static + dynamic body topology: ys[(b,t)][h*L + c]
 int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* wsm, float* ys,
-                   long frames, int H, int L, int G, hipStream_t s);
+                   long frames, int H, int L, int G, hipStream_t s, TwinAlias alias = TwinAlias(), long frame0 = 0);
 // temporal linear attention over text (+) motion tokens: yt[(b,t)][h*L + c]
 // samples [b0, b0 + nb) of the CFG-doubled batch (B = samples per CFG half)
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s);
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag = nullptr);

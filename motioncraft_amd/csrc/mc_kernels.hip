@@ -51,10 +51,13 @@ constexpr int FILM_MAXC = 8;  // 8 float4 chunks x 64 lanes = 2048 channels
 __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ Y1, const float* __restrict__ Y2,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ ss, float* __restrict__ A,
-                                                   long rows, int D) {
+                                                   long rows, int D, TwinAlias y1_alias, long row0) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
+    // CFG twin aliasing (base layer 0): Y1 rows that were not produced are read from their twin
+    long r1 = r;
+    if (y1_alias.split_flag && row0 + r >= y1_alias.from && *y1_alias.split_flag == 0) r1 = r - y1_alias.from;
     const int nch = D >> 2;
     f32x4 v[FILM_MAXC];
     float s = 0.f;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
         const int ch = c * 64 + lane;
         v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ch < nch) {
-            v[c] = *reinterpret_cast<const f32x4*>(Y1 + r * D + ch * 4);
+            v[c] = *reinterpret_cast<const f32x4*>(Y1 + r1 * D + ch * 4);
             if (Y2) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(Y2 + r * D + ch * 4);
                 v[c] += w;
@@ -254,10 +257,10 @@ int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, c
 }
 
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
-                        const float* ss, float* A, long rows, int D, hipStream_t s) {
+                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0) {
     MC_REQUIRE(D % 4 == 0 && D <= FILM_MAXC * 256, "film_rows: unsupported D=%d", D);
     if (rows <= 0) return MC_OK;
-    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D);
+    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -68,6 +68,7 @@ struct mc_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // large batches: the batch is cut into `nparts` groups of whole samples, group k > 0 runs on parts[k-1]
+    bool no_alias = false;          // introspection runs (stop_after_layers < num_layers): every intermediate row is materialised
     bool defer_last_gemm = false;   // sampler entry points: the last FiLM GEMM runs on the CFG-combined rows (see denoise_combined)
     hipStream_t parts[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
@@ -275,11 +276,11 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
-               bool prologue_only = false) {
+               bool prologue_only = false, TwinAlias y1_alias = TwinAlias()) {
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     const long o = row0 * D;
     int r;
-    if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s))) return r;
+    if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
     return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
@@ -289,6 +290,15 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
 // (whole samples): MoE combine + proj, body LN + q/k/v, body and temporal attention, proj_out FiLM block, SFFN, its
 // FiLM block.  Every kernel here is row-independent, so disjoint row ranges can run on different streams.
 int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st) {
+    // twin layer: rows of the second CFG half whose routing equals their twin's are aliased, not recomputed
+    TwinAlias tok_alias, frame_alias;
+    const int* twin_flag = nullptr;
+    if (twin && mc_chain_enabled(8) && !c->no_alias) {
+        twin_flag = mc_route_split_flag_ptr(c->rb);
+        tok_alias.split_flag = frame_alias.split_flag = twin_flag;
+        tok_alias.from = c->N / 2;
+        frame_alias.from = c->rows / 2;
+    }
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, H = g.num_parts, D = L * H;
     const LayerW& w = c->lw[i];
@@ -300,6 +310,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.mm.proj_w; p.bias = w.mm.proj_b;
         p.Y = c->mf; p.ldy = 4 * L; p.tok0 = tok0; p.N = tok0 + ntok; p.L = L; p.Nout = 4 * L;
         p.twin_from = twin ? c->N / 2 : 0;
+        p.alias = tok_alias;
         if ((r = mc_launch_rowchain(0, p, s))) return r;
     } else {
         GemmArgs p;
@@ -314,7 +325,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         MC_HIP(hipEventRecord(c->ev_fork, s));
         MC_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
         if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
-                                    g.max_text_len, H, L, st))) return r;
+                                    g.max_text_len, H, L, st, twin_flag))) return r;
         MC_HIP(hipEventRecord(c->ev_join, st));
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
@@ -322,27 +333,31 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         RowChainArgs q;
         q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
         q.Y = c->qkv; q.ldy = 3 * L; q.tok0 = tok0; q.N = tok0 + ntok; q.L = L; q.Nout = 3 * L;
+        q.alias = tok_alias;
         if ((r = mc_launch_rowchain(1, q, s))) return r;
     } else {
         if ((r = mc_launch_ln_rows(c->mf + tok0 * 4 * L, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z + tok0 * L, L, ntok, L, s))) return r;
         if ((r = dense(c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, s))) return r;
     }
-    if ((r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, s))) return r;
+    if ((r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, s,
+                            frame_alias, row0))) return r;
     if (st != s) {
         MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
         return MC_OK;
     }
     return mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
-                              g.max_text_len, H, L, s);
+                              g.max_text_len, H, L, s, twin_flag);
 }
 
-int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, long row0, long nrows, hipStream_t s) {
+int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s) {
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
     const LayerW& w = c->lw[i];
     int r;
     const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
-    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s))) return r;
+    TwinAlias ys_alias;
+    if (twin && mc_chain_enabled(8) && !c->no_alias) { ys_alias.split_flag = mc_route_split_flag_ptr(c->rb); ys_alias.from = c->rows / 2; }
+    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias))) return r;
     // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
     const long o = row0 * D;
     if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
@@ -458,16 +473,21 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         for (int k = 0; k < c->nparts; ++k) {
             hipStream_t sk = part_stream(c, k, s);
             if ((r = layer_rows(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), sk, sk))) return r;
+            if (k == 0 && twin && mc_chain_enabled(8) && !c->no_alias) {
+                // twin aliasing: the other groups read group 0's mf / ys instead of producing their own
+                MC_HIP(hipEventRecord(c->ev_join, s));
+                for (int j = 1; j < c->nparts; ++j) MC_HIP(hipStreamWaitEvent(c->parts[j - 1], c->ev_join, 0));
+            }
         }
         for (int k = 0; k < c->nparts; ++k)
-            if ((r = layer_rows_tail(c, i, hs, step, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+            if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
         if (split == 1 && (r = parts_join(c, s))) return r;
         return MC_OK;
     }
     // Small batches: the temporal branch runs on the side stream beside LN + qkv + body (measured +2.4 % at B=8).
     const bool side_temporal = c->side && (mc_chain_enabled(3) || c->N <= 65536);
     if ((r = layer_rows(c, i, hs, step, twin, 0, 2 * half, s, side_temporal ? c->side : s))) return r;
-    return layer_rows_tail(c, i, hs, step, 0, 2 * half, s);
+    return layer_rows_tail(c, i, hs, step, twin, 0, 2 * half, s);
 }
 
 }  // namespace
@@ -746,6 +766,7 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
         if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
+    c->no_alias = stop_after >= 0 && stop_after < g.num_layers;
     const int NC = c->have_ctrl ? g.num_ctrl_layers : 0;
     // large batches: the CFG halves run on two streams (see run_layer); with a control branch the extra whole-batch
     // ops between layers need both halves, so the halves re-join after every layer

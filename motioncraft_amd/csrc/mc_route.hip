@@ -34,7 +34,9 @@ enum {
     ST_RANK = ST_ACTIVE + MAXP,   // [MAXP]      remaining rank during selection
     ST_ANY = ST_RANK + MAXP,      // [1]         any problem active
     ST_NTILES = ST_ANY + 1,       // [2]         tiles per slot group
-    ST_DONE = ST_NTILES + 2,      // [2]         finished-workgroup counter of the histogram pass: the last one picks the bin
+    ST_DONE = ST_NTILES + 2,      // [1]         finished-workgroup counter of the histogram pass: the last one picks the bin
+                                  // [1]  (ST_DONE + 1 = ST_SPLIT) twin mode: some token and its twin got different keep flags
+    ST_SPLIT = ST_DONE + 1,
     ST_PREFIX = ST_DONE + 2,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
     ST_HIST = ST_PREFIX + 2 * MAXP,  // [MAXP][256]
     ST_TOTAL = ST_HIST + MAXP * 256
@@ -262,6 +264,10 @@ __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx,
         if (s_act[p] == -1) keep = false;
         else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok) >= s_thr[p];
         comb_w[a] = keep ? gate[as] : 0.f;
+        if (tok >= Nsrc && s_act[p] == 1) {          // twin mode: would the original (same key, smaller index) decide differently?
+            const bool keep_orig = composite(key[ts], (uint32_t)ts) >= s_thr[p];
+            if (keep_orig != keep) state[ST_SPLIT] = 1;
+        }
         if (keep && tok < Nsrc) atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + e], 1);   // expert slots exist for the first Nsrc tokens only
     }
     __syncthreads();
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx,
 
 size_t mc_route_state_ints(int) { return ST_TOTAL; }
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
+const int* mc_route_split_flag_ptr(const RouteBufs& rb) { return rb.state + ST_SPLIT; }
 
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
                           RouteBufs rb, hipStream_t s) {
