@@ -291,7 +291,11 @@ def main():
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
-                       'batches_in_flight': 1, 'two_batches_in_flight': inflight2},
+                       'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
+                       'exact_reductions': 'results equal the unreduced computation (tests/test_gpu_parity.py): CFG twins of base layer 0 '
+                                           'share gate / expert / proj / qkv / body work (identical inputs); the last StylizationBlock '
+                                           'Linear + affine pose decoder run once on the CFG-combined rows; FLOPs in `roofline` are '
+                                           'counted as the reference performs them (DESIGN.md section 4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': MEASURED_HBM_GB_PER_STEP_B64 if (B, T) == (64, 196) else None,
                          'traffic_unit': 'GB per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate PMC passes; profiles/r01_pmc_hbm_traffic.txt)',
