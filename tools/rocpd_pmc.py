@@ -29,10 +29,11 @@ def main(path, filt=''):
         print(f'{key[0]} grid=({key[1]},{key[2]}) x{n}  avg {d:9.1f} us')
         for k in sorted(c):
             print(f'     {k:34s} {c[k]:18.1f}')
+        # GRBM_GUI_ACTIVE is reported once per XCD (8 on MI355X) and summed over them by the query above
         if 'GRBM_GUI_ACTIVE' in c and d > 0:
-            print(f'     -> effective clock {c["GRBM_GUI_ACTIVE"]/d/1e3:.3f} GHz')
+            print(f'     -> effective clock {c["GRBM_GUI_ACTIVE"]/8/d/1e3:.3f} GHz  (gui_active / 8 XCDs / duration)')
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
-            print(f'     -> MfmaUtil {c["SQ_VALU_MFMA_BUSY_CYCLES"]/(c["GRBM_GUI_ACTIVE"]*1024)*100:.1f} % (busy / (gui_active * 1024 SIMDs))')
+            print(f'     -> MfmaUtil {c["SQ_VALU_MFMA_BUSY_CYCLES"]/(c["GRBM_GUI_ACTIVE"]/8*1024)*100:.1f} %  (busy cycles summed over SIMDs / (cycles * 1024 SIMDs))')
 
 
 if __name__ == '__main__':
