@@ -785,3 +785,29 @@ def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
     assert err <= TOL_STEP
     ctx.close()
     nm.close()
+
+
+def test_control_branch_without_condition_cfg_vs_oracle():
+    """condition_encode_cfg.condition_cfg=False: the control condition also drives the unconditional CFG half
+    (controlnet.py forward_test: `c * cond_type` only when condition_cfg)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    g = load('control_small.npz')
+    sd = W.make_state_dict(CTRL, SMALL_SEED, shapes=W.control_param_shapes(CTRL, CTRL_COPY, CTRL_FEATS))
+    x, xf, mask, c = (T_(g[k]) for k in ('x_t', 'xf_out', 'motion_mask', 'c'))
+    outs = {}
+    for ccfg in (True, False):
+        nm = NativeModel(CTRL, sd, cfg_scale=CTRL['scale'], condition_cfg=ccfg)
+        ctx = nm.context(2, 24, max_steps=1)
+        ctx.set_timesteps([640])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        ctx.set_control(c.cuda())
+        out2 = ctx.denoise(x.cuda(), 0)
+        w = (1 - (1000 - 640) / 1000) * CTRL['scale'] + 1
+        outs[ccfg] = (out2[:2] * w + out2[2:] * (1 - w)).cpu()
+        ref = O.denoise_control(sd, CTRL, x, 640, xf, mask, c, CTRL_COPY, condition_cfg=ccfg)
+        assert maxabs(outs[ccfg], ref) <= TOL_STEP, ccfg
+        ctx.close()
+        nm.close()
+    assert maxabs(outs[True], T_(g['x0_t640'])) <= TOL_STEP
+    assert maxabs(outs[True], outs[False]) > 1e-3          # the flag matters
