@@ -52,6 +52,9 @@ int mc_launch_sampler_inpaint(const float* x_t, const float* out_text, const flo
                               InpaintArgs ip, float* x_prev, float* x0_out, long n, SamplerCoefs c, hipStream_t s);
 // Y[r][0:Cp] = X[r][0:C], zero padded (aligned rows for the pose-encoder GEMM)
 int mc_launch_pad_rows(const float* X, float* Y, long rows, int C, int Cp, hipStream_t s);
+// out[M][N] (contiguous) = sum_s part[s][M][N] + bias[N] + res[M][N]
+int mc_launch_splitk_reduce(const float* part, int S, long M, int N, const float* bias, const float* res, float* out,
+                            hipStream_t s);
 int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s);
 
 // ---- mc_post.hip ----------------------------------------------------------------------

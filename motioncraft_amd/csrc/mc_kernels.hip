@@ -235,6 +235,20 @@ __global__ __launch_bounds__(256) void pad_rows_k(const float* __restrict__ X, f
     }
 }
 
+// split-K reduction: out[r][n] = sum_s part[s][r][n] (s ascending: deterministic) + bias[n] + res[r][n]
+__global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ part, int S, long MN, int N,
+                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                      float* __restrict__ out) {
+    const long n4 = MN >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * i);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + (long)s * MN + 4 * i);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + (4 * i) % N);
+        if (res) v += *reinterpret_cast<const f32x4*>(res + 4 * i);
+        *reinterpret_cast<f32x4*>(out + 4 * i) = v;
+    }
+}
+
 // out = a x + b noise  (the forward "undo" step of the resampling schedule, gaussian_diffusion.py:429-435)
 __global__ __launch_bounds__(256) void axpby_k(const float* __restrict__ x, const float* __restrict__ y, float a, float b,
                                                float* __restrict__ out, long n) {
@@ -331,6 +345,18 @@ int mc_launch_pad_rows(const float* X, float* Y, long rows, int C, int Cp, hipSt
     int blocks = cdiv(rows * Cp, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pad_rows_k, dim3(blocks), dim3(256), 0, s, X, Y, rows, C, Cp);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_splitk_reduce(const float* part, int S, long M, int N, const float* bias, const float* res, float* out,
+                            hipStream_t s) {
+    MC_REQUIRE(N % 4 == 0 && S >= 1, "split-K reduce: N=%d S=%d", N, S);
+    const long MN = M * N;
+    if (MN <= 0) return MC_OK;
+    int blocks = cdiv(MN / 4, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, s, part, S, MN, N, bias, res, out);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -57,6 +57,7 @@ struct mc_ctx {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2, *xpad;
+    size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
     float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
     const float* mask = nullptr;
     int* t_orig;
@@ -206,6 +207,25 @@ int dense(const float* A, long lda, const float* W, long ldw, const float* bias,
     return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
 }
 
+// Small batches: a [M x K] x [K x N] GEMM with fewer than ~128 output tiles leaves most of the 256 CUs idle while each
+// tile walks the whole K serially.  Split K across workgroups (the grouped launch with column offsets as "group"
+// strides), partial sums in `ws`, reduced in a fixed order: C = sum_s A[:, s] W[:, s]^T + bias + R.
+int dense_splitk(const float* A, const float* W, const float* bias, const float* R, float* C, long M, int N, int K,
+                 float* ws, size_t ws_floats, hipStream_t s) {
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    int S = 1;
+    while (S < 8 && tiles * (S * 2) <= 512 && K % (S * 2 * 32) == 0 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
+    if (S == 1) return dense(A, K, W, K, bias, R, N, C, N, M, N, K, ACT_NONE, s);
+    GemmArgs g;
+    g.A = A; g.lda = K; g.a_gstride = K / S;          // split s reads columns [s K/S, (s+1) K/S) of A and of W
+    g.W = W; g.ldw = K; g.w_gstride = K / S;
+    g.C = ws; g.ldc = N; g.c_gstride = M * N;
+    g.M = (int)M; g.N = N; g.K = K / S;
+    int r = mc_launch_gemm(GM_PLAIN, g, S, 0, s);
+    if (r != MC_OK) return r;
+    return mc_launch_splitk_reduce(ws, S, M, N, bias, R, C, s);
+}
+
 // One tutel MoE layer + GELU + proj (class MOE, st_attention.py:49-56) over Ntok tokens whose
 // gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
 // `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
@@ -283,6 +303,8 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
+    if (nrows <= 2048 && c->hbuf_floats)       // few output tiles: split K (hbuf is free scratch on the fused path)
+        return dense_splitk(c->a + o, out_w, out_b, hs + o, hs + o, nrows, D, D, c->hbuf, c->hbuf_floats, s);
     return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
 }
 
@@ -600,6 +622,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->z, zsz);
     WS(c->proj, Nmax * 256);
     WS(c->hbuf, hsz);
+    if (mc_chain_enabled(0) && mc_mlp_supported(L, 4 * L)) c->hbuf_floats = hsz;   // (the text MoE only touches hbuf in set_condition)
     WS(c->y2, 2 * zsz);
     WS(c->mf, c->N * 4 * L);
     WS(c->qkv, c->N * 3 * L);
