@@ -23,6 +23,10 @@ struct MlpArgs {
     const int* num_tiles = nullptr;
     const int* src_row = nullptr;
     const int* dst_row = nullptr;
+    // small batches: the hidden dimension is split over gridDim.z workgroups; split z writes its partial FC2 sums to
+    // Y + z * y_sstride (b2 added by split 0 only); the caller reduces the partials in a fixed order
+    int nsplit = 1;
+    long y_sstride = 0;
 };
 
 struct GateArgs {

@@ -168,19 +168,21 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc2[t][q] = 0.f;
 
-    const int nch = g.hidden / HC;
+    // hidden chunks [hc0, nch) of this workgroup (all of them unless the hidden dimension is split over blockIdx.z)
+    const int nch_all = g.hidden / HC;
+    const int hc0 = (int)((long)nch_all * blockIdx.z / g.nsplit), nch = (int)((long)nch_all * (blockIdx.z + 1) / g.nsplit);
     S1 s1;
     S2 s2;
-    s1.fetch(W1, L, 0, 0, tid);
-    s2.fetch(W2t, g.hidden, 0, 0, tid);
-    s1.commit(W1s(0), tid);
-    s2.commit(W2s(0), tid);
-    if (nch > 1) {
-        s1.fetch(W1, L, HC, 0, tid);
-        s2.fetch(W2t, g.hidden, 0, HC, tid);
+    s1.fetch(W1, L, hc0 * HC, 0, tid);
+    s2.fetch(W2t, g.hidden, 0, hc0 * HC, tid);
+    s1.commit(W1s(hc0 & 1), tid);
+    s2.commit(W2s(hc0 & 1), tid);
+    if (hc0 + 1 < nch) {
+        s1.fetch(W1, L, (hc0 + 1) * HC, 0, tid);
+        s2.fetch(W2t, g.hidden, 0, (hc0 + 1) * HC, tid);
     }
     __syncthreads();
-    for (int hc = 0; hc < nch; ++hc) {
+    for (int hc = hc0; hc < nch; ++hc) {
         const int buf = hc & 1;
         if (hc + 1 < nch) {
             s1.commit(W1s(buf ^ 1), tid);
@@ -216,13 +218,14 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
     if (!rok) return;
     long drow = row0 + r;
     if constexpr (MODE == MLP_EXPERT) drow = g.dst_row[row0 + r];
-    float* yrow = g.Y + (long)grp * g.y_gstride + drow * g.ldy;
+    float* yrow = g.Y + (long)blockIdx.z * g.y_sstride + (long)grp * g.y_gstride + drow * g.ldy;
+    const bool add_b2 = blockIdx.z == 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = t * 32 + 8 * q + kq;
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + n);
+            const f32x4 bb = add_b2 ? *reinterpret_cast<const f32x4*>(b2 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 v = {acc2[t][4 * q] + bb[0], acc2[t][4 * q + 1] + bb[1], acc2[t][4 * q + 2] + bb[2], acc2[t][4 * q + 3] + bb[3]};
             *reinterpret_cast<f32x4*>(yrow + n) = v;
         }
@@ -448,12 +451,13 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
     MC_REQUIRE(mc_mlp_supported(g.L, g.hidden), "fused mlp: L=%d hidden=%d unsupported", g.L, g.hidden);
     MC_REQUIRE(g.ldx % 4 == 0 && g.ldy % 4 == 0 && g.x_gstride % 4 == 0 && g.y_gstride % 4 == 0, "fused mlp: unaligned strides");
     dim3 grid;
+    MC_REQUIRE(g.nsplit >= 1 && (g.hidden / 32) % g.nsplit == 0, "fused mlp: %d hidden chunks cannot be split %d ways", g.hidden / 32, g.nsplit);
     if (mode == MLP_EXPERT) {
         if (max_tiles <= 0) return MC_OK;
-        grid = dim3(max_tiles);
+        grid = dim3(max_tiles, 1, g.nsplit);
     } else {
         if (g.M <= 0) return MC_OK;
-        grid = dim3(cdiv(g.M, 128), groups);
+        grid = dim3(cdiv(g.M, 128), groups, g.nsplit);
     }
 #define MC_MLP_CASE(LL)                                                                              \
     case LL:                                                                                         \

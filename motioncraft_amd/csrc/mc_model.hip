@@ -242,6 +242,14 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
         m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
         m.num_tiles = mc_route_num_tiles_ptr(c->rb, group); m.src_row = c->rb.src_row; m.dst_row = c->rb.dst_row;
+        // small batches (a few dozen tiles, each walking all hidden chunks serially): split the hidden dimension 4 ways,
+        // partial FC2 sums in hbuf, reduced in a fixed order (rows of dropped pairs stay unwritten garbage: never read)
+        const int S = 4;
+        if (z == c->z && c->rows <= 2048 && (hid / 32) % S == 0 && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
+            m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
+            if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
+            return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s);
+        }
         return mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s);
     }
     GemmArgs a;
@@ -387,7 +395,12 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         m.X = hs + o; m.ldx = D; m.x_gstride = L;
         m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
         m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;
-        if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
+        const int S = 4;
+        if (nrows <= 2048 && (F / 32) % S == 0 && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
+            m.Y = c->hbuf; m.nsplit = S; m.y_sstride = nrows * D;
+            if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
+            if ((r = mc_launch_splitk_reduce(c->hbuf, S, nrows, D, nullptr, nullptr, c->z2 + o, s))) return r;
+        } else if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
     } else {
         GemmArgs f1;
         f1.A = hs + o; f1.lda = D; f1.a_gstride = L;
