@@ -17,6 +17,8 @@
  *   mc_sample_step_inpaint  the same with y = {gt, outpainting_mask}   gaussian_diffusion.py:492-501, 855-877
  *   mc_textenc_*          DiffusionTransformer.encode_text (CLIP text tower, text_pre_proj, textTransEncoder, text_ln)
  *                                                                      mogen/models/transformers/diffusion_transformer.py:109-172
+ *   mc_evalenc_*          T2MContrastiveModel_SMPLX.encode_motion / encode_text (evaluation embeddings)
+ *                                                                      mogen/models/rnns/t2m_bigru_smplx.py:66-437
  *   mc_wavenc_*           WavEncoder (audio condition pre-encoder)     mogen/models/utils/blocks.py:11-71; controlnet.py:90-105,187
  *   mc_postprocess_smplx  de-normalise + SMPL-X re-pack + temporal filter  tools/visualize.py:39-44,217-246; tools/s2g_test.py:289-297
  *   mc_op_renoise         GaussianDiffusion._undo (resampling jumps)   gaussian_diffusion.py:429-435, 1113-1118
@@ -179,6 +181,39 @@ int mc_textenc_forward_feat(mc_textenc* e, const float* clip_feat_dev, int32_t B
 /* tokens_dev int32 [B, max_len] (clip.tokenize ids) -> xf_out_dev; clip_feat_out_dev may be NULL */
 int mc_textenc_forward_tokens(mc_textenc* e, const int32_t* tokens_dev, int32_t B, float* clip_feat_out_dev,
                               float* xf_out_dev, void* stream);
+
+/* ---- Evaluation embedding model (T2MContrastiveModel_SMPLX; mogen/models/rnns/t2m_bigru_smplx.py:396-437) --------
+ * motion side: ActorAgnosticEncoder (:66-195); text side: DistilbertActorAgnosticEncoder after tokenisation (:198-394).
+ * The embeddings feed FID / R-precision / matching score / diversity / multimodality (mogen/core/evaluation/). */
+typedef struct mc_evalenc mc_evalenc;
+typedef struct mc_evalenc_config {
+    int32_t nfeats;           /* motion_encoder.nfeats (322)                                                  */
+    int32_t latent_dim;       /* 256                                                                          */
+    int32_t ff_size;          /* 1024                                                                         */
+    int32_t num_layers;       /* 4 layers of nn.TransformerEncoder (post-LN, GELU)                            */
+    int32_t num_heads;        /* 4; head_dim must be 64                                                       */
+    int32_t pe_len;           /* rows of sequence_pos_encoding.pe (5000)                                      */
+    int32_t bert_dim;         /* DistilBERT hidden size (768); 0 = motion side only                           */
+    int32_t bert_layers;      /* 6                                                                            */
+    int32_t bert_heads;       /* 12; head_dim must be 64                                                      */
+    int32_t bert_ff;          /* 3072                                                                         */
+    int32_t bert_vocab;       /* 30522                                                                        */
+    int32_t bert_max_pos;     /* 512                                                                          */
+} mc_evalenc_config;
+int mc_evalenc_create(const mc_evalenc_config* cfg, mc_evalenc** out);
+void mc_evalenc_destroy(mc_evalenc* e);
+/* fp32 parameters from host memory under the evaluator checkpoint's own keys ("motionencoder.skel_embedding.weight",
+ * "motionencoder.mu_token", "motionencoder.sequence_pos_encoding.pe", "motionencoder.seqTransEncoder.layers.{i}.*",
+ * "textencoder.text_model.embeddings.*", "textencoder.text_model.transformer.layer.{i}.*", "textencoder.projection.1.*",
+ * "textencoder.mu_token", ... as split by load_pretrained, t2m_bigru_smplx.py:417-435) */
+int mc_evalenc_set_param(mc_evalenc* e, const char* name, const float* host, int64_t numel);
+int mc_evalenc_finalize(mc_evalenc* e);
+/* encode_motion(motion, motion_length).loc: motion_dev [B, T, nfeats], lengths_dev int32 [B] -> mu_out_dev [B, latent_dim] */
+int mc_evalenc_encode_motion(mc_evalenc* e, const float* motion_dev, const int32_t* lengths_dev, int32_t B, int32_t T,
+                             float* mu_out_dev, void* stream);
+/* encode_text(...).loc after the tokenizer: ids_dev int32 [B, S], mask_dev uint8 [B, S] (attention_mask) -> mu_out_dev */
+int mc_evalenc_encode_text(mc_evalenc* e, const int32_t* ids_dev, const uint8_t* mask_dev, int32_t B, int32_t S,
+                           float* mu_out_dev, void* stream);
 
 /* ---- WavEncoder: step-invariant audio condition encoder of the speech-to-gesture configs ------------------ */
 typedef struct mc_wavenc mc_wavenc;

@@ -10,6 +10,7 @@
 #include "mc_common.h"
 #include "mc_gemm.h"
 #include "mc_kernels.h"
+#include "mc_enc.h"
 #include "../../include/motioncraft_amd.h"
 #include <map>
 #include <string>
@@ -19,7 +20,8 @@ namespace {
 
 // LayerNorm over rows of L floats (L % 4 == 0, L <= 4096): one wavefront per row, two-pass variance.
 __global__ __launch_bounds__(256) void ln_wide_k(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, float* __restrict__ Y, long rows, int L) {
+                                                 const float* __restrict__ beta, float* __restrict__ Y, long rows, int L,
+                                                 float eps, int relu) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -37,14 +39,17 @@ __global__ __launch_bounds__(256) void ln_wide_k(const float* __restrict__ X, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) q += (v[j] - mean) * (v[j] - mean);
     }
-    const float rstd = rsqrtf(group_sum(q, 64) / (float)L + 1e-5f);
+    const float rstd = rsqrtf(group_sum(q, 64) / (float)L + eps);
     for (int i = lane; i < n4; i += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * i);
         const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * i);
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * g[j] + b[j];
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (v[j] - mean) * rstd * g[j] + b[j];
+            if (relu) o[j] = fmaxf(o[j], 0.f);
+        }
         *reinterpret_cast<f32x4*>(Y + r * L + 4 * i) = o;
     }
 }
@@ -113,31 +118,125 @@ __global__ __launch_bounds__(256) void mha_small_k(const float* __restrict__ qkv
     }
 }
 
-struct LayerP {
-    const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_g, *n1_b, *n2_g, *n2_b;
-};
+// General form: any S, optional key mask, optional causal mask.  One workgroup per (sample, head, block of 16 queries);
+// keys are streamed through LDS 64 at a time with the running-max ("online") softmax, so that LDS use is independent of
+// S.  Wave w owns queries 4w .. 4w+3 of the block; lane = key within the chunk for the scores, lane = channel for P V.
+constexpr int MHA_QB = 16;
+__global__ __launch_bounds__(256) void mha_masked_k(const float* __restrict__ qkv, const uint8_t* __restrict__ valid,
+                                                    float* __restrict__ out, int S, int d, int heads, int causal) {
+    __shared__ float Ks[64 * (MHA_HD + 1)];
+    __shared__ float Vs[64 * MHA_HD];
+    __shared__ float Qs[MHA_QB][MHA_HD];
+    __shared__ float Ps[4][64];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, q0 = blockIdx.y * MHA_QB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* base = qkv + (long)b * S * 3 * d + h * MHA_HD;
+    for (int i = tid; i < MHA_QB * MHA_HD; i += 256) {
+        const int qi = i / MHA_HD, c = i % MHA_HD, q = q0 + qi;
+        Qs[qi][c] = q < S ? base[(long)q * 3 * d + c] * 0.125f : 0.f;
+    }
+    float m[4], l[4], o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { m[u] = -INFINITY; l[u] = 0.f; o[u] = 0.f; }
+    for (int k0 = 0; k0 < S; k0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * MHA_HD; i += 256) {
+            const int j = i / MHA_HD, c = i % MHA_HD, key = k0 + j;
+            const bool in = key < S;
+            const long off = (long)(in ? key : 0) * 3 * d + c;
+            const float kv = base[off + d], vv = base[off + 2 * d];
+            Ks[j * (MHA_HD + 1) + c] = in ? kv : 0.f;
+            Vs[j * MHA_HD + c] = in ? vv : 0.f;
+        }
+        __syncthreads();
+        const int key = k0 + lane;
+        const bool ok = key < S && (valid == nullptr || valid[(long)b * S + (key < S ? key : 0)] != 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int qi = wave * 4 + u, q = q0 + qi;
+            float a = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < MHA_HD; ++c) a += Qs[qi][c] * Ks[lane * (MHA_HD + 1) + c];
+            const bool use = ok && !(causal && key > q);
+            a = use ? a : -INFINITY;
+            const float mn = fmaxf(m[u], group_max(a, 64));
+            const float p = use ? expf(a - mn) : 0.f;
+            const float alpha = m[u] == -INFINITY ? 0.f : expf(m[u] - mn);
+            l[u] = l[u] * alpha + group_sum(p, 64);
+            Ps[wave][lane] = p;
+            __builtin_amdgcn_wave_barrier();
+            float acc = 0.f;
+#pragma unroll 16
+            for (int j = 0; j < 64; ++j) acc += Ps[wave][j] * Vs[j * MHA_HD + lane];
+            o[u] = o[u] * alpha + acc;
+            m[u] = mn;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = q0 + wave * 4 + u;
+        if (q < S) out[((long)b * S + q) * d + h * MHA_HD + lane] = l[u] > 0.f ? o[u] / l[u] : 0.f;
+    }
+}
 
-int dense(const float* A, long lda, const float* W, long ldw, const float* bias, const float* R, long ldr, float* C, long ldc,
-          long M, int N, int K, int act, hipStream_t s) {
+}  // namespace
+
+int mc_enc_dense(const float* A, long lda, const float* W, long ldw, const float* bias, const float* R, long ldr, float* C, long ldc,
+                 long M, int N, int K, int act, hipStream_t s) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R = R; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
     return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
 }
 
-int ln_wide(const float* X, const float* g, const float* b, float* Y, long rows, int L, hipStream_t s) {
+int mc_enc_ln(const float* X, const float* g, const float* b, float* Y, long rows, int L, float eps, int relu, hipStream_t s) {
     MC_REQUIRE(L % 4 == 0, "layer norm width %d", L);
-    hipLaunchKernelGGL(ln_wide_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, X, g, b, Y, rows, L);
+    hipLaunchKernelGGL(ln_wide_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, X, g, b, Y, rows, L, eps, relu);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
 
-}  // namespace
+int mc_enc_embed_tokens(const int* ids, const float* emb, const float* pos, float* X, long rows, int S, int d, int vocab,
+                        hipStream_t s) {
+    MC_REQUIRE(d % 4 == 0, "embedding width %d", d);
+    hipLaunchKernelGGL(embed_tokens_k, dim3(cdiv(rows * (d / 4), 256)), dim3(256), 0, s, ids, emb, pos, X, rows, S, d, vocab);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_enc_layer(const EncLayer& p, float* x, float* qkv, float* att, float* y, float* hid, long rows, int B, int S, int d,
+                 int heads, int ff, bool pre_ln, int act, int causal, const uint8_t* valid, float eps, hipStream_t s) {
+    MC_REQUIRE(d == heads * MHA_HD, "encoder layer: width %d with %d heads (head_dim must be %d)", d, heads, MHA_HD);
+    int r;
+    const float* src = x;
+    if (pre_ln) {
+        if ((r = mc_enc_ln(x, p.n1_g, p.n1_b, y, rows, d, eps, 0, s))) return r;
+        src = y;
+    }
+    if ((r = mc_enc_dense(src, d, p.in_w, d, p.in_b, nullptr, 0, qkv, 3 * d, rows, 3 * d, d, ACT_NONE, s))) return r;
+    if (valid == nullptr && S <= MHA_S)
+        hipLaunchKernelGGL(mha_small_k, dim3(B * heads), dim3(256), 0, s, qkv, att, S, d, heads, causal);
+    else
+        hipLaunchKernelGGL(mha_masked_k, dim3(B * heads, cdiv(S, MHA_QB)), dim3(256), 0, s, qkv, valid, att, S, d, heads, causal);
+    MC_LAUNCH_CHECK();
+    if (pre_ln) {
+        if ((r = mc_enc_dense(att, d, p.out_w, d, p.out_b, x, d, x, d, rows, d, d, ACT_NONE, s))) return r;   // x += out_proj(att)
+        if ((r = mc_enc_ln(x, p.n2_g, p.n2_b, y, rows, d, eps, 0, s))) return r;
+        if ((r = mc_enc_dense(y, d, p.l1_w, d, p.l1_b, nullptr, 0, hid, ff, rows, ff, d, act, s))) return r;
+        return mc_enc_dense(hid, ff, p.l2_w, ff, p.l2_b, x, d, x, d, rows, d, ff, ACT_NONE, s);                // x += c_proj(...)
+    }
+    if ((r = mc_enc_dense(att, d, p.out_w, d, p.out_b, x, d, y, d, rows, d, d, ACT_NONE, s))) return r;       // y = x + out_proj(att)
+    if ((r = mc_enc_ln(y, p.n1_g, p.n1_b, x, rows, d, eps, 0, s))) return r;
+    if ((r = mc_enc_dense(x, d, p.l1_w, d, p.l1_b, nullptr, 0, hid, ff, rows, ff, d, act, s))) return r;
+    if ((r = mc_enc_dense(hid, ff, p.l2_w, ff, p.l2_b, x, d, y, d, rows, d, ff, ACT_NONE, s))) return r;      // y = x + linear2(...)
+    return mc_enc_ln(y, p.n2_g, p.n2_b, x, rows, d, eps, 0, s);
+}
 
 struct mc_textenc {
     mc_textenc_config cfg;
     std::map<std::string, std::pair<float*, int64_t>> params;
-    std::vector<LayerP> ft, clip;
+    std::vector<EncLayer> ft, clip;
     const float *pre_w = nullptr, *pre_b = nullptr, *ln_g = nullptr, *ln_b = nullptr;
     const float *tok = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
     bool finalized = false, has_clip = false;
@@ -156,33 +255,6 @@ int getp(mc_textenc* e, const std::string& name, int64_t numel, const float** ou
     }
     *out = it->second.first;
     return MC_OK;
-}
-
-// one encoder layer over x [rows][d] in place; scratch: qkv [rows][3d], att [rows][d], y [rows][d], hid [rows][ff]
-//   post-LN (nn.TransformerEncoderLayer, norm_first=False): x = LN1(x + SA(x)); x = LN2(x + FF(x))
-//   pre-LN  (CLIP ResidualAttentionBlock):                  x = x + SA(LN1(x)); x = x + MLP(LN2(x))
-int run_layer(const LayerP& p, float* x, float* qkv, float* att, float* y, float* hid, long rows, int B, int S, int d, int heads,
-              int ff, bool pre_ln, int act, int causal, hipStream_t s) {
-    int r;
-    const float* src = x;
-    if (pre_ln) {
-        if ((r = ln_wide(x, p.n1_g, p.n1_b, y, rows, d, s))) return r;
-        src = y;
-    }
-    if ((r = dense(src, d, p.in_w, d, p.in_b, nullptr, 0, qkv, 3 * d, rows, 3 * d, d, ACT_NONE, s))) return r;
-    hipLaunchKernelGGL(mha_small_k, dim3(B * heads), dim3(256), 0, s, qkv, att, S, d, heads, causal);
-    MC_LAUNCH_CHECK();
-    if (pre_ln) {
-        if ((r = dense(att, d, p.out_w, d, p.out_b, x, d, x, d, rows, d, d, ACT_NONE, s))) return r;          // x += out_proj(att)
-        if ((r = ln_wide(x, p.n2_g, p.n2_b, y, rows, d, s))) return r;
-        if ((r = dense(y, d, p.l1_w, d, p.l1_b, nullptr, 0, hid, ff, rows, ff, d, act, s))) return r;
-        return dense(hid, ff, p.l2_w, ff, p.l2_b, x, d, x, d, rows, d, ff, ACT_NONE, s);                       // x += c_proj(...)
-    }
-    if ((r = dense(att, d, p.out_w, d, p.out_b, x, d, y, d, rows, d, d, ACT_NONE, s))) return r;              // y = x + out_proj(att)
-    if ((r = ln_wide(y, p.n1_g, p.n1_b, x, rows, d, s))) return r;
-    if ((r = dense(x, d, p.l1_w, d, p.l1_b, nullptr, 0, hid, ff, rows, ff, d, act, s))) return r;
-    if ((r = dense(hid, ff, p.l2_w, ff, p.l2_b, x, d, y, d, rows, d, ff, ACT_NONE, s))) return r;             // y = x + linear2(...)
-    return ln_wide(y, p.n2_g, p.n2_b, x, rows, d, s);
 }
 
 int ensure_ws(mc_textenc* e, size_t floats, hipStream_t s) {
@@ -240,10 +312,10 @@ int mc_textenc_finalize(mc_textenc* e) {
         TP(e->pre_w, "text_pre_proj.weight", (int64_t)d * c.clip_dim);
         TP(e->pre_b, "text_pre_proj.bias", d);
     }
-    e->ft.assign(c.num_layers, LayerP());
+    e->ft.assign(c.num_layers, EncLayer());
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "textTransEncoder.layers." + std::to_string(i) + ".";
-        LayerP& L = e->ft[i];
+        EncLayer& L = e->ft[i];
         TP(L.in_w, p + "self_attn.in_proj_weight", (int64_t)3 * d * d);  TP(L.in_b, p + "self_attn.in_proj_bias", 3 * d);
         TP(L.out_w, p + "self_attn.out_proj.weight", (int64_t)d * d);    TP(L.out_b, p + "self_attn.out_proj.bias", d);
         TP(L.l1_w, p + "linear1.weight", (int64_t)ff * d);               TP(L.l1_b, p + "linear1.bias", ff);
@@ -260,10 +332,10 @@ int mc_textenc_finalize(mc_textenc* e) {
         TP(e->pos, "clip.positional_embedding", (int64_t)c.max_len * w);
         TP(e->lnf_g, "clip.ln_final.weight", w);
         TP(e->lnf_b, "clip.ln_final.bias", w);
-        e->clip.assign(c.clip_layers, LayerP());
+        e->clip.assign(c.clip_layers, EncLayer());
         for (int i = 0; i < c.clip_layers; ++i) {
             const std::string p = "clip.transformer.resblocks." + std::to_string(i) + ".";
-            LayerP& L = e->clip[i];
+            EncLayer& L = e->clip[i];
             TP(L.in_w, p + "attn.in_proj_weight", (int64_t)3 * w * w);  TP(L.in_b, p + "attn.in_proj_bias", 3 * w);
             TP(L.out_w, p + "attn.out_proj.weight", (int64_t)w * w);    TP(L.out_b, p + "attn.out_proj.bias", w);
             TP(L.l1_w, p + "mlp.c_fc.weight", (int64_t)cf * w);         TP(L.l1_b, p + "mlp.c_fc.bias", cf);
@@ -294,13 +366,13 @@ int mc_textenc_forward_feat(mc_textenc* e, const float* clip_feat, int32_t B, fl
     float* y = att + rows * d;
     float* hid = y + rows * d;
     if (e->pre_w) {
-        if ((r = dense(clip_feat, c.clip_dim, e->pre_w, c.clip_dim, e->pre_b, nullptr, 0, x, d, rows, d, c.clip_dim, ACT_NONE, s))) return r;
+        if ((r = mc_enc_dense(clip_feat, c.clip_dim, e->pre_w, c.clip_dim, e->pre_b, nullptr, 0, x, d, rows, d, c.clip_dim, ACT_NONE, s))) return r;
     } else {
         MC_HIP(hipMemcpyAsync(x, clip_feat, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     for (int i = 0; i < c.num_layers; ++i)
-        if ((r = run_layer(e->ft[i], x, qkv, att, y, hid, rows, B, S, d, c.num_heads, ff, false, ACT_GELU, 0, s))) return r;
-    return ln_wide(x, e->ln_g, e->ln_b, xf_out, rows, d, s);
+        if ((r = mc_enc_layer(e->ft[i], x, qkv, att, y, hid, rows, B, S, d, c.num_heads, ff, false, ACT_GELU, 0, nullptr, 1e-5f, s))) return r;
+    return mc_enc_ln(x, e->ln_g, e->ln_b, xf_out, rows, d, 1e-5f, 0, s);
 }
 
 // tokens_dev int32 [B, max_len] (clip.tokenize output) -> clip_feat_out_dev (optional) and xf_out_dev
@@ -322,12 +394,11 @@ int mc_textenc_forward_tokens(mc_textenc* e, const int32_t* tokens, int32_t B, f
     float* y = att + rows * w;
     float* hid = y + rows * w;
     float* feat = hid + rows * cf;
-    hipLaunchKernelGGL(embed_tokens_k, dim3(cdiv(rows * (w / 4), 256)), dim3(256), 0, s, tokens, e->tok, e->pos, x, rows, S, w, c.vocab);
-    MC_LAUNCH_CHECK();
+    if ((r = mc_enc_embed_tokens(tokens, e->tok, e->pos, x, rows, S, w, c.vocab, s))) return r;
     for (int i = 0; i < c.clip_layers; ++i)
-        if ((r = run_layer(e->clip[i], x, qkv, att, y, hid, rows, B, S, w, c.clip_heads, cf, true, ACT_QUICKGELU, 1, s))) return r;
+        if ((r = mc_enc_layer(e->clip[i], x, qkv, att, y, hid, rows, B, S, w, c.clip_heads, cf, true, ACT_QUICKGELU, 1, nullptr, 1e-5f, s))) return r;
     float* f = clip_feat_out ? clip_feat_out : feat;
-    if ((r = ln_wide(x, e->lnf_g, e->lnf_b, f, rows, w, s))) return r;
+    if ((r = mc_enc_ln(x, e->lnf_g, e->lnf_b, f, rows, w, 1e-5f, 0, s))) return r;
     return mc_textenc_forward_feat(e, f, B, xf_out, stream);
 }
 

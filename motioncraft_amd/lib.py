@@ -35,6 +35,11 @@ class Inpaint(ctypes.Structure):
                 ('blend_w_dev', ctypes.c_void_p), ('blend_len', ctypes.c_int32)]
 
 
+class EvalEncConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('nfeats', 'latent_dim', 'ff_size', 'num_layers', 'num_heads', 'pe_len', 'bert_dim',
+                                              'bert_layers', 'bert_heads', 'bert_ff', 'bert_vocab', 'bert_max_pos')]
+
+
 class TextEncConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('clip_dim', 'text_latent_dim', 'num_layers', 'ff_size', 'num_heads', 'max_len',
                                               'clip_layers', 'clip_heads', 'clip_ff', 'vocab')]
@@ -74,6 +79,12 @@ _SIGNATURES = {
     'mc_textenc_finalize': (ctypes.c_int, [_P]),
     'mc_textenc_forward_feat': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, _P]),
     'mc_textenc_forward_tokens': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, _P, _P]),
+    'mc_evalenc_create': (ctypes.c_int, [ctypes.POINTER(EvalEncConfig), ctypes.POINTER(_P)]),
+    'mc_evalenc_destroy': (None, [_P]),
+    'mc_evalenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),
+    'mc_evalenc_finalize': (ctypes.c_int, [_P]),
+    'mc_evalenc_encode_motion': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    'mc_evalenc_encode_text': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
     'mc_wavenc_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     'mc_wavenc_destroy': (None, [_P]),
     'mc_wavenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),

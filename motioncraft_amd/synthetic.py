@@ -279,6 +279,76 @@ def make_text_encoder_state(shapes, seed=0):
     return sd
 
 
+def _vae_transformer_shapes(s, pre, d, ff, num_layers, max_len=5000):
+    s[pre + 'mu_token'], s[pre + 'logvar_token'] = (d,), (d,)
+    s[pre + 'sequence_pos_encoding.pe'] = (max_len, 1, d)
+    for i in range(num_layers):
+        p = f'{pre}seqTransEncoder.layers.{i}.'
+        s[p + 'self_attn.in_proj_weight'], s[p + 'self_attn.in_proj_bias'] = (3 * d, d), (3 * d,)
+        s[p + 'self_attn.out_proj.weight'], s[p + 'self_attn.out_proj.bias'] = (d, d), (d,)
+        s[p + 'linear1.weight'], s[p + 'linear1.bias'] = (ff, d), (ff,)
+        s[p + 'linear2.weight'], s[p + 'linear2.bias'] = (d, ff), (d,)
+        for n in ('norm1', 'norm2'):
+            s[p + n + '.weight'], s[p + n + '.bias'] = (d,), (d,)
+
+
+def eval_encoder_param_shapes(nfeats=322, latent_dim=256, ff_size=1024, num_layers=4, bert=None, **unused):
+    """Keys of the evaluation embedding model's checkpoint as T2MContrastiveModel_SMPLX.load_pretrained reads them
+    (``motionencoder.*`` / ``textencoder.*``, t2m_bigru_smplx.py:417-435).  ``bert``: dict(dim, n_layers, hidden_dim,
+    vocab_size, max_position_embeddings) of the DistilBERT text model, or None for the motion side only."""
+    s = OrderedDict()
+    m = 'motionencoder.'
+    s[m + 'skel_embedding.weight'], s[m + 'skel_embedding.bias'] = (latent_dim, nfeats), (latent_dim,)
+    _vae_transformer_shapes(s, m, latent_dim, ff_size, num_layers)
+    if bert is not None:
+        t, w = 'textencoder.', bert['dim']
+        e = t + 'text_model.embeddings.'
+        s[e + 'word_embeddings.weight'] = (bert['vocab_size'], w)
+        s[e + 'position_embeddings.weight'] = (bert['max_position_embeddings'], w)
+        s[e + 'LayerNorm.weight'], s[e + 'LayerNorm.bias'] = (w,), (w,)
+        for i in range(bert['n_layers']):
+            p = f'{t}text_model.transformer.layer.{i}.'
+            for n in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
+                s[p + f'attention.{n}.weight'], s[p + f'attention.{n}.bias'] = (w, w), (w,)
+            s[p + 'sa_layer_norm.weight'], s[p + 'sa_layer_norm.bias'] = (w,), (w,)
+            s[p + 'ffn.lin1.weight'], s[p + 'ffn.lin1.bias'] = (bert['hidden_dim'], w), (bert['hidden_dim'],)
+            s[p + 'ffn.lin2.weight'], s[p + 'ffn.lin2.bias'] = (w, bert['hidden_dim']), (w,)
+            s[p + 'output_layer_norm.weight'], s[p + 'output_layer_norm.bias'] = (w,), (w,)
+        s[t + 'projection.1.weight'], s[t + 'projection.1.bias'] = (latent_dim, w), (latent_dim,)
+        _vae_transformer_shapes(s, t, latent_dim, ff_size, num_layers)
+    return s
+
+
+def sinusoid_table(max_len, d):
+    """PositionalEncoding.pe (t2m_bigru_smplx.py:24-32), fp32 torch arithmetic: [max_len, 1, d]."""
+    pe = torch.zeros(max_len, d)
+    pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2).float() * (-math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(1)
+
+
+def make_eval_encoder_state(shapes, seed=0):
+    sd = OrderedDict()
+    for k, shape in shapes.items():
+        if k.endswith('sequence_pos_encoding.pe'):
+            sd[k] = sinusoid_table(shape[0], shape[2])
+            continue
+        r = _randn(seed, 'eval.' + k, shape)
+        if k.endswith('.bias') or k.endswith('_bias'):
+            sd[k] = (0.1 if 'norm' in k.lower() else 0.02) * r
+        elif 'norm' in k.lower():
+            sd[k] = 1.0 + 0.1 * r
+        elif k.endswith('_token'):
+            sd[k] = r
+        elif 'embeddings.' in k:
+            sd[k] = 0.5 * r
+        else:
+            sd[k] = r / math.sqrt(shape[-1])
+    return sd
+
+
 def make_wav_encoder_state(out_dim, audio_in, seed=0):
     """Deterministic non-trivial WavEncoder weights (BatchNorm running stats included) keyed like the reference."""
     from .wav_encoder import wav_encoder_param_shapes

@@ -133,6 +133,30 @@ def load():
     return ns
 
 
+def _shell(name, path):
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m.__package__ = name
+        sys.modules[name] = m
+
+
+def load_evaluation():
+    """The reference's evaluation side: the embedding model module (needs the ``transformers``
+    package, present in this image) and mogen/core/evaluation's metric functions + evaluators."""
+    install()
+    _shell('mogen.models.rnns', REF + '/mogen/models/rnns')
+    _shell('mogen.core', REF + '/mogen/core')
+    _shell('mogen.core.evaluation', REF + '/mogen/core/evaluation')
+    _shell('mogen.core.evaluation.evaluators', REF + '/mogen/core/evaluation/evaluators')
+    ns = types.SimpleNamespace()
+    ns.rnns = importlib.import_module('mogen.models.rnns.t2m_bigru_smplx')
+    ns.utils = importlib.import_module('mogen.core.evaluation.utils')
+    for n in ('precision', 'matching_score', 'fid', 'diversity', 'multimodality'):
+        setattr(ns, n, importlib.import_module(f'mogen.core.evaluation.evaluators.{n}_evaluator'))
+    return ns
+
+
 def build_reference_denoiser(model_cfg):
     """STMoGenTransformer(**cfg) with text_encoder=None (SURVEY.md section 8c recipe)."""
     ref = load()

@@ -28,6 +28,9 @@ Fixtures
   skeleton_parts.npz    8-part layouts: human_ml3d (263-d) and kit_ml (251-d) reduced configs (x0 at two t + 50-step
                         DDIM final), and the shipped T2M_humanml3d.py architecture (L=64, H=8) x0 at t=500
   control_wav_small.npz ControlT2MHalf S2G form: condition_pre_encode='wav' (WavEncoder on 9000 x 2 raw audio -> 17 frames)
+  evaluator.npz         evaluation embedding model (ActorAgnosticEncoder + DistilbertActorAgnosticEncoder over a reduced
+                        DistilBERT), the transformers WordPiece tokenizer on tricky sentences, mogen/core/evaluation
+                        metric functions and the five evaluators driven by a stub embedding model
   full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
   full_ddim.npz         0.125b config, B=1: final sample of the 50-step DDIM loop
 """
@@ -422,6 +425,105 @@ def control_wav():
                         motion_mask=mask.numpy(), audio=audio.numpy(), x0_t420=ref.numpy())
 
 
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import EVAL_BERT, EVAL_DIMS  # noqa: E402
+EVAL_WORDS = ['a', 'person', 'walk', '##s', '##ing', 'forward', 'and', 'then', 'jump', 'run', '##ning', 'the', 'left', 'right',
+              'hand', 'wave', '.', ',', '!', '-', "'", 'cafe', 'un', '##believ', '##able', '##ly', 'slow', '2', '##0', 'step',
+              'turn', '##ed', 'man', 'wo', '##man', 'is', 'arm', 'both', 'up', 'down']
+EVAL_TEXTS = ['A person walks forward.', 'jumping and then waves the left hand, running!',
+              "The man's Caf\u00e9 unbelievably slow-walking 20 steps", 'xyzzy turned  \t right\n and then up', '']
+
+
+def eval_vocab():
+    base = ['[PAD]', '[UNK]', '[CLS]', '[SEP]', '[MASK]'] + list('bcdefghijklmnopqrstuvwxyz') + ['##' + c for c in 'abcdefghijklmnopqrstuvwxyz']
+    return list(dict.fromkeys(base + EVAL_WORDS))
+
+
+def evaluator():
+    """T2MContrastiveModel_SMPLX's two encoders, the tokenizer, the metrics, the evaluators."""
+    import tempfile
+    from transformers import DistilBertConfig, DistilBertModel, DistilBertTokenizer
+    from oracle import eval_encoder_oracle as EO
+    from motioncraft_amd.wordpiece import WordPieceTokenizer
+    ev = ref_shim.load_evaluation()
+    vocab = eval_vocab()
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, 'vocab.txt'), 'w') as f:
+        f.write('\n'.join(vocab) + '\n')
+    DistilBertModel(DistilBertConfig(vocab_size=len(vocab), **EVAL_BERT)).save_pretrained(d)
+    DistilBertTokenizer(os.path.join(d, 'vocab.txt')).save_pretrained(d)
+    kw = {k: v for k, v in EVAL_DIMS.items() if k != 'nfeats'}
+    menc = ev.rnns.ActorAgnosticEncoder(nfeats=EVAL_DIMS['nfeats'], vae=True, **kw).eval()
+    tenc = ev.rnns.DistilbertActorAgnosticEncoder(modelpath=d, vae=True, **kw).eval()
+    shapes = W.eval_encoder_param_shapes(bert=dict(EVAL_BERT, vocab_size=len(vocab)), **EVAL_DIMS)
+    ref_keys = {'motionencoder.' + k: v for k, v in menc.state_dict().items()}
+    ref_keys.update({'textencoder.' + k: v for k, v in tenc.state_dict().items()})
+    assert set(ref_keys) == set(shapes), sorted(set(ref_keys) ^ set(shapes))[:8]
+    for k, v in ref_keys.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sd = W.make_eval_encoder_state(shapes, seed=6)
+    assert maxabs(sd['motionencoder.sequence_pos_encoding.pe'], menc.state_dict()['sequence_pos_encoding.pe']) == 0
+    menc.load_state_dict({k[len('motionencoder.'):]: v for k, v in sd.items() if k.startswith('motionencoder.')}, strict=True)
+    tenc.load_state_dict({k[len('textencoder.'):]: v for k, v in sd.items() if k.startswith('textencoder.')}, strict=True)
+
+    g = torch.Generator().manual_seed(71)
+    motion = torch.randn(3, 24, EVAL_DIMS['nfeats'], generator=g)
+    lengths = [24, 17, 9]
+    with torch.no_grad():
+        ref_m = menc(motion, torch.tensor(lengths), None).loc
+        ref_t = tenc(EVAL_TEXTS, None, 'cpu').loc
+    tok = tenc.tokenizer(EVAL_TEXTS, return_tensors='pt', padding=True)
+    ids, mask = tok['input_ids'], tok['attention_mask']
+    my_ids, my_mask = WordPieceTokenizer(d)(EVAL_TEXTS)
+    assert np.array_equal(my_ids, ids.numpy()) and np.array_equal(my_mask, mask.numpy()), (my_ids, ids)
+    om = EO.encode_motion(sd, motion, lengths, EVAL_DIMS['num_layers'], EVAL_DIMS['num_heads'])
+    ot = EO.encode_text_tokens(sd, ids, mask, EVAL_BERT['n_layers'], EVAL_BERT['n_heads'], EVAL_DIMS['num_layers'], EVAL_DIMS['num_heads'])
+    print(f'evaluator: motion mu {tuple(ref_m.shape)} oracle vs reference {maxabs(ref_m, om):.2e}; text mu oracle vs reference '
+          f'{maxabs(ref_t, ot):.2e}; tokenizer ids identical ({tuple(ids.shape)})')
+    assert maxabs(ref_m, om) <= 1e-5 and maxabs(ref_t, ot) <= 1e-5
+    save = dict(motion=motion.numpy(), lengths=np.array(lengths), motion_mu=ref_m.numpy(), input_ids=ids.numpy().astype(np.int32),
+                attention_mask=mask.numpy().astype(np.uint8), text_mu=ref_t.numpy(), seed=np.int64(6), vocab=np.array(vocab),
+                texts=np.array(EVAL_TEXTS))
+
+    # metric functions on seeded embeddings (float32 like .cpu().numpy() of the model output)
+    rs = np.random.RandomState(3)
+    a, b = rs.randn(40, 16).astype(np.float32), rs.randn(40, 16).astype(np.float32)
+    dist = ev.utils.euclidean_distance_matrix(a, b)
+    topk = ev.utils.calculate_top_k(np.argsort(dist, axis=1), 3)
+    mu1, c1 = ev.utils.calculate_activation_statistics(a, 1.0)
+    mu2, c2 = ev.utils.calculate_activation_statistics(b + 0.3, 1.0)
+    fd = ev.utils.calculate_frechet_distance(mu1, c1, mu2, c2)
+    np.random.seed(11)
+    div = ev.utils.calculate_diversity(a, 20, 1.0, 1.0)
+    mm = ev.utils.calculate_multimodality(a.reshape(5, 8, 16), 4)
+    assert np.allclose(EO.pairwise_l2(a, b), dist) and abs(EO.frechet(mu1, c1, mu2, c2) - fd) < 1e-9
+    np.random.seed(11)
+    assert abs(EO.diversity(a, 20) - div) < 1e-12 and abs(EO.multimodality(a.reshape(5, 8, 16), 4) - mm) < 1e-12
+    save.update(met_a=a, met_b=b, met_dist=dist, met_topk=topk, met_fid=np.float64(fd), met_div=np.float64(div), met_mm=np.float64(mm))
+
+    # the five evaluators, replication_times=2, driven by the stub model
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import StubEvalModel, stub_eval_results
+    stub, N, REP = StubEvalModel(), 48, 2
+    common = dict(replication_times=REP, replication_reduction='statistics', evaluator_model=stub)
+    np.random.seed(23)
+    mme = ev.multimodality.MultiModalityEvaluator(data_len=N, num_samples=4, num_repeats=5, num_picks=3, **common)
+    results = stub_eval_results(N, REP, mme.append_indexes)
+    evs = [ev.precision.PrecisionEvaluator(data_len=N, top_k=3, batch_size=16, **common),
+           ev.matching_score.MatchingScoreEvaluator(data_len=N, batch_size=16, **common),
+           ev.fid.FIDEvaluator(data_len=N, emb_scale=1.0, **common),
+           ev.diversity.DiversityEvaluator(data_len=N, num_samples=20, **common), mme]
+    np.random.seed(29)
+    metrics = {}
+    for e in evs:
+        metrics.update(e.evaluate(results))
+    print('evaluator: reference metrics on the stub model', {k: round(float(v), 4) for k, v in metrics.items()})
+    save['ev_names'] = np.array(list(metrics.keys()))
+    save['ev_values'] = np.array([float(v) for v in metrics.values()])
+    save['ev_append'] = np.stack(mme.append_indexes)
+    np.savez_compressed(os.path.join(OUT, 'evaluator.npz'), **save)
+
+
 def full():
     dims, B, T = FULL, 1, 196
     t0 = time.time()
@@ -469,7 +571,7 @@ if __name__ == '__main__':
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
-                  repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, full=full)
+                  repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, evaluator=evaluator, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):
             continue

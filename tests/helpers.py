@@ -36,3 +36,62 @@ def step_noise_from_seed(seed, shape, num):
     """The per-step randn_like stream of the reference loop under torch.manual_seed(seed)."""
     g = torch.Generator().manual_seed(int(seed))
     return [torch.randn(shape, generator=g) for _ in range(num)]
+
+
+# ---- evaluation-side fixtures (shared with tests/golden/make_golden.py) -----------------------------------------
+EVAL_DIMS = dict(nfeats=322, latent_dim=128, ff_size=256, num_layers=2, num_heads=2)
+EVAL_BERT = dict(dim=128, n_layers=2, n_heads=2, hidden_dim=256, max_position_embeddings=64)
+
+
+class StubEvalModel:
+    """Deterministic stand-in for the embedding model so that the evaluators' host logic can be compared end to end."""
+    device = 'cpu'
+
+    def __init__(self, nfeats=12, d=16):
+        g = torch.Generator().manual_seed(5)
+        self.P = torch.randn(nfeats, d, generator=g)
+
+    def encode_motion(self, motion, motion_length=None, motion_mask=None, **kw):
+        m = motion_mask[..., None].to(motion.dtype)
+        return torch.tanh(((motion * m).sum(1) / motion_length[:, None].to(motion.dtype)) @ self.P)
+
+    def encode_text(self, text, token=None, device=None, **kw):
+        v = torch.tensor([[float(ord(c) % 13) for c in (t + ' ' * 12)[:12]] for t in text])
+        return torch.tanh((v - 6.0) / 4.0 @ self.P)
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+
+def _stub_results(n, nfeats=12, seed=9, T=14):
+    """results as the test loop collects them: every motion padded to the dataset's fixed T with a length mask (the
+    reference's own prepare_results cannot pad the ground-truth side: base_evaluator.py:75 calls type_as on a list)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        n_i = int(torch.randint(6, T + 1, (1,), generator=g))
+        msk = (torch.arange(T) < n_i).float()
+        mot = torch.randn(T, nfeats, generator=g) * msk[:, None]
+        out.append(dict(motion=mot, pred_motion=mot + 0.7 * torch.randn(T, nfeats, generator=g) * msk[:, None], motion_mask=msk,
+                        pred_motion_mask=msk, motion_length=torch.tensor(n_i), pred_motion_length=torch.tensor(n_i),
+                        text=''.join(chr(97 + int(c)) for c in torch.randint(0, 26, (10,), generator=g)), token=None))
+    return out
+
+
+def stub_eval_results(n, replications, append_indexes):
+    """Result list in the layout the evaluators slice: per replication, n samples followed by the MultiModality repeats
+    (fresh predictions for the re-drawn indexes)."""
+    out = []
+    for rep in range(replications):
+        base = _stub_results(n, seed=9 + rep)
+        g = torch.Generator().manual_seed(100 + rep)
+        extra = []
+        for i in append_indexes[rep]:
+            r = dict(base[int(i)])
+            r['pred_motion'] = r['motion'] + 0.7 * torch.randn(r['motion'].shape, generator=g) * r['motion_mask'][:, None]
+            extra.append(r)
+        out += base + extra
+    return out

@@ -811,3 +811,113 @@ def test_control_branch_without_condition_cfg_vs_oracle():
         nm.close()
     assert maxabs(outs[True], T_(g['x0_t640'])) <= TOL_STEP
     assert maxabs(outs[True], outs[False]) > 1e-3          # the flag matters
+
+
+def _eval_model_dir(tmp_path, vocab, bert):
+    import json
+    (tmp_path / 'vocab.txt').write_text('\n'.join(vocab) + '\n', encoding='utf-8')
+    (tmp_path / 'config.json').write_text(json.dumps(dict(bert, vocab_size=len(vocab), model_type='distilbert')))
+    (tmp_path / 'tokenizer_config.json').write_text(json.dumps(dict(do_lower_case=True)))
+    return str(tmp_path)
+
+
+def test_evaluation_embedding_model_vs_reference_golden_and_oracle(tmp_path):
+    """SURVEY.md 8f.4: T2MContrastiveModel_SMPLX built through the registry with the configs' evaluator_model layout;
+    encode_motion / encode_text (own WordPiece tokenizer + DistilBERT + VAE-token transformer on the device) vs the
+    reference's outputs, then the shipped sizes (latent 256, 4 layers, DistilBERT-base widths, T=196) vs the oracle."""
+    import motioncraft_amd as mc
+    from motioncraft_amd import evaluation as E
+    from helpers import EVAL_BERT, EVAL_DIMS
+    from oracle import eval_encoder_oracle as EO, weights as W
+    g = load('evaluator.npz')
+    vocab = [str(v) for v in g['vocab']]
+    shapes = W.eval_encoder_param_shapes(bert=dict(EVAL_BERT, vocab_size=len(vocab)), **EVAL_DIMS)
+    sd = W.make_eval_encoder_state(shapes, seed=int(g['seed']))
+    enc_cfg = {k: v for k, v in EVAL_DIMS.items() if k != 'nfeats'}
+    model = mc.build_submodule(dict(type='T2MContrastiveModel_SMPLX',
+                                    motion_encoder=dict(nfeats=EVAL_DIMS['nfeats'], vae=True, **enc_cfg),
+                                    text_encoder=dict(modelpath=_eval_model_dir(tmp_path, vocab, EVAL_BERT), **enc_cfg),
+                                    state_dict=sd))
+    mu = model.encode_motion(T_(g['motion']).cuda(), torch.from_numpy(g['lengths']).cuda())
+    tu = model.encode_text([str(t) for t in g['texts']], device='cuda')
+    e1, e2 = maxabs(mu, T_(g['motion_mu'])), maxabs(tu, T_(g['text_mu']))
+    print(f'evaluation encoders (reduced): |hip - reference| motion {e1:.2e}, text {e2:.2e}')
+    assert e1 <= 5e-5 and e2 <= 5e-5
+    # frames past the length and padded tokens never reach the embedding
+    m2 = T_(g['motion']).clone()
+    m2[2, 9:] = 123.0
+    assert torch.equal(model.encode_motion(m2.cuda(), torch.from_numpy(g['lengths']).cuda())[2], mu[2])
+    ids2 = torch.from_numpy(g['input_ids']).clone()
+    ids2[torch.from_numpy(g['attention_mask']) == 0] = 7
+    t2 = model.encode_text(None, input_ids=ids2, attention_mask=torch.from_numpy(g['attention_mask']), device='cuda')
+    assert torch.equal(t2, tu)
+    # motion side alone: the text entry fails loudly
+    only_motion = E.NativeEvalEncoder({k: v for k, v in sd.items() if k.startswith('motionencoder.')}, **EVAL_DIMS)
+    with pytest.raises(RuntimeError):
+        only_motion.encode_tokens(ids2.cuda(), torch.from_numpy(g['attention_mask']).cuda())
+    only_motion.close()
+
+    # shipped sizes (motionx_bs128.py:38-51; DistilBERT-base widths with a 2000-piece vocabulary)
+    bert = dict(dim=768, n_layers=6, n_heads=12, hidden_dim=3072, max_position_embeddings=512, vocab_size=2000)
+    shapes = W.eval_encoder_param_shapes(bert=bert)
+    sd = W.make_eval_encoder_state(shapes, seed=8)
+    enc = E.NativeEvalEncoder(sd, bert=bert)
+    gen = torch.Generator().manual_seed(12)
+    B, T, S = 8, 196, 40
+    motion = torch.randn(B, T, 322, generator=gen)
+    lengths = [196, 150, 64, 63, 1, 196, 100, 12]
+    ids = torch.randint(0, 2000, (B, S), generator=gen)
+    tl = torch.tensor([40, 33, 5, 2, 17, 40, 21, 9])
+    mask = (torch.arange(S)[None] < tl[:, None]).to(torch.uint8)
+    mu = enc.encode_motion(motion.cuda(), lengths)
+    tu = enc.encode_tokens(ids.cuda(), mask.cuda())
+    e1 = maxabs(mu, EO.encode_motion(sd, motion, lengths))
+    e2 = maxabs(tu, EO.encode_text_tokens(sd, ids, mask, 6, 12))
+    print(f'evaluation encoders (shipped sizes): |hip - oracle| motion {e1:.2e}, text {e2:.2e}')
+    assert e1 <= 1e-4 and e2 <= 1e-4
+    enc.close()
+
+
+def test_fid_and_precision_evaluators_on_device_embeddings(tmp_path):
+    """The evaluators of mogen/core/evaluation driven by the device embedding model: metrics equal the same formulas
+    applied to the oracle's embeddings of the same result list."""
+    import motioncraft_amd as mc
+    from motioncraft_amd import evaluation as E
+    from helpers import EVAL_BERT, EVAL_DIMS
+    from oracle import eval_encoder_oracle as EO, weights as W
+    g = load('evaluator.npz')
+    vocab = [str(v) for v in g['vocab']]
+    sd = W.make_eval_encoder_state(W.eval_encoder_param_shapes(bert=dict(EVAL_BERT, vocab_size=len(vocab)), **EVAL_DIMS), seed=3)
+    enc_cfg = {k: v for k, v in EVAL_DIMS.items() if k != 'nfeats'}
+    model = mc.build_submodule(dict(type='T2MContrastiveModel_SMPLX', motion_encoder=dict(nfeats=322, vae=True, **enc_cfg),
+                                    text_encoder=dict(modelpath=_eval_model_dir(tmp_path, vocab, EVAL_BERT), **enc_cfg), state_dict=sd))
+    gen = torch.Generator().manual_seed(4)
+    N, T = 192, 24           # more samples than embedding dimensions: the covariances stay well conditioned
+    words = [w for w in vocab[57:] if not w.startswith('##') and w.isalpha()]
+    results = []
+    for i in range(N):
+        n = int(torch.randint(8, T + 1, (1,), generator=gen))
+        msk = (torch.arange(T) < n).float()
+        mot = torch.randn(T, 322, generator=gen) * msk[:, None]
+        text = ' '.join(words[int(j)] for j in torch.randint(0, len(words), (5,), generator=gen))
+        results.append(dict(motion=mot, pred_motion=mot + 0.5 * torch.randn(T, 322, generator=gen) * msk[:, None], motion_mask=msk,
+                            pred_motion_mask=msk, motion_length=torch.tensor(n), pred_motion_length=torch.tensor(n), text=text))
+    common = dict(data_len=N, replication_times=1, evaluator_model=model)
+    got = {}
+    got.update(E.FIDEvaluator(emb_scale=1.0, **common).evaluate(results))
+    got.update(E.PrecisionEvaluator(top_k=3, batch_size=32, **common).evaluate(results))
+    got.update(E.MatchingScoreEvaluator(batch_size=32, **common).evaluate(results))
+    lens = [int(r['motion_length']) for r in results]
+    pm = EO.encode_motion(sd, torch.stack([r['pred_motion'] for r in results]), lens, 2, 2).numpy()
+    gm = EO.encode_motion(sd, torch.stack([r['motion'] for r in results]), lens, 2, 2).numpy()
+    ids, mask = model.tokenizer([r['text'] for r in results])
+    tm = EO.encode_text_tokens(sd, torch.from_numpy(ids).long(), torch.from_numpy(mask), 2, 2, 2, 2).numpy()
+    fid = EO.fid(pm, gm)
+    hits = sum(EO.r_precision_counts(tm[i:i + 32], pm[i:i + 32]) for i in range(0, N, 32)) / N
+    match = sum(EO.matching_score_sum(tm[i:i + 32], pm[i:i + 32]) for i in range(0, N, 32)) / N
+    print(f"device evaluators: FID {got['FID (mean)']:.5f} (oracle {fid:.5f}), R-precision {[got['R_precision Top %d (mean)' % k] for k in (1, 2, 3)]}"
+          f" (oracle {hits.tolist()}), matching score {got['Matching Score (mean)']:.5f} (oracle {match:.5f})")
+    assert abs(got['FID (mean)'] - fid) <= 1e-3 * max(1.0, abs(fid))
+    assert abs(got['Matching Score (mean)'] - match) <= 1e-3
+    assert np.allclose([got['R_precision Top %d (mean)' % k] for k in (1, 2, 3)], hits, atol=1.5 / N)
+    assert got['FID (conf)'] == 0

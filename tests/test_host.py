@@ -277,3 +277,63 @@ def test_product_never_imports_oracle():
         if f.endswith('.py'):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+
+
+def test_wordpiece_tokenizer_matches_the_transformers_tokenizer_golden(tmp_path):
+    """The evaluator's text side tokenises with the DistilBERT directory's vocab.txt (t2m_bigru_smplx.py:229,276)."""
+    from motioncraft_amd.wordpiece import WordPieceTokenizer
+    g = load('evaluator.npz')
+    (tmp_path / 'vocab.txt').write_text('\n'.join(str(v) for v in g['vocab']) + '\n', encoding='utf-8')
+    tok = WordPieceTokenizer(str(tmp_path))
+    ids, mask = tok([str(t) for t in g['texts']])
+    assert np.array_equal(ids, g['input_ids']) and np.array_equal(mask, g['attention_mask'])
+    assert tok.encode('') == [tok.cls, tok.sep]
+    assert tok.pieces('q' * 101) == [tok.unk] and tok.pieces('walks') == [tok.ids['walk'], tok.ids['##s']]
+
+
+def test_evaluation_metric_functions_against_reference_golden():
+    """mogen/core/evaluation/utils.py outputs on seeded float32 embeddings."""
+    from motioncraft_amd import evaluation as E
+    g = load('evaluator.npz')
+    a, b = g['met_a'], g['met_b']
+    dist = E.euclidean_distance_matrix(a, b)
+    assert dist.dtype == np.float32 and np.array_equal(dist, g['met_dist'])
+    assert np.array_equal(E.calculate_top_k(np.argsort(dist, axis=1), 3), g['met_topk'])
+    mu1, c1 = E.calculate_activation_statistics(a, 1.0)
+    mu2, c2 = E.calculate_activation_statistics(b + 0.3, 1.0)
+    assert abs(E.calculate_frechet_distance(mu1, c1, mu2, c2) - float(g['met_fid'])) <= 1e-9
+    np.random.seed(11)
+    assert abs(E.calculate_diversity(a, 20, 1.0, 1.0) - float(g['met_div'])) <= 1e-12
+    assert abs(E.calculate_multimodality(a.reshape(5, 8, 16), 4) - float(g['met_mm'])) <= 1e-12
+    m, c = E.get_metric_statistics(np.array([1.0, 2.0, 4.0]), 3)
+    assert abs(m - 7 / 3) < 1e-12 and abs(c - 1.96 * np.std([1.0, 2.0, 4.0]) / np.sqrt(3)) < 1e-12
+
+
+def test_evaluators_host_logic_against_reference_golden():
+    """The five evaluators (replication slicing, batching, z-scoring, statistics) driven by the same stub embedding
+    model as the reference's own evaluators in tests/golden/make_golden.py; built through build_evaluator with the
+    configs' eval_cfg layout (configs/_base_/datasets/motionx_bs128.py:34-57)."""
+    from motioncraft_amd import evaluation as E
+    from helpers import StubEvalModel, stub_eval_results
+    g = load('evaluator.npz')
+    N, REP = 48, 2
+    eval_cfg = dict(shuffle_indexes=True, replication_times=REP, replication_reduction='statistics', evaluator_model=StubEvalModel(),
+                    metrics=[dict(type='R Precision', batch_size=16, top_k=3), dict(type='Matching Score', batch_size=16),
+                             dict(type='FID', emb_scale=1.0), dict(type='Diversity', num_samples=20),
+                             dict(type='MultiModality', num_samples=4, num_repeats=5, num_picks=3)])
+    idx = [np.arange(N) for _ in range(REP)]
+    evs = []
+    for metric in eval_cfg['metrics']:
+        if metric['type'] == 'MultiModality':
+            np.random.seed(23)
+        ev, idx = E.build_evaluator(metric, eval_cfg, N, idx)
+        evs.append(ev)
+    assert np.array_equal(np.stack(evs[-1].append_indexes), g['ev_append']) and len(idx[0]) == N + 20
+    results = stub_eval_results(N, REP, evs[-1].append_indexes)
+    np.random.seed(29)
+    metrics = {}
+    for ev in evs:
+        metrics.update(ev.evaluate(results))
+    assert list(metrics) == [str(n) for n in g['ev_names']]
+    got = np.array([float(v) for v in metrics.values()])
+    assert np.allclose(got, g['ev_values'], rtol=1e-6, atol=1e-7), (got, g['ev_values'])

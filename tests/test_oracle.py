@@ -179,3 +179,20 @@ def test_text_encoder_against_reference_golden():
     g = load('text_encoder.npz')
     sd = W.make_text_encoder_state(W.text_encoder_param_shapes(256, 2, 2048), seed=int(g['seed']))
     assert maxabs(TO.finetune_encoder(sd, T_(g['clip_feat']), 2), T_(g['xf_out'])) <= 1e-5
+
+
+def test_evaluation_encoders_against_reference_golden():
+    """oracle restatement of ActorAgnosticEncoder / DistilbertActorAgnosticEncoder vs the reference outputs."""
+    from oracle import eval_encoder_oracle as EO
+    from helpers import EVAL_BERT, EVAL_DIMS
+    g = load('evaluator.npz')
+    shapes = W.eval_encoder_param_shapes(bert=dict(EVAL_BERT, vocab_size=len(g['vocab'])), **EVAL_DIMS)
+    sd = W.make_eval_encoder_state(shapes, seed=int(g['seed']))
+    om = EO.encode_motion(sd, T_(g['motion']), g['lengths'].tolist(), EVAL_DIMS['num_layers'], EVAL_DIMS['num_heads'])
+    ot = EO.encode_text_tokens(sd, torch.from_numpy(g['input_ids']).long(), torch.from_numpy(g['attention_mask']),
+                               EVAL_BERT['n_layers'], EVAL_BERT['n_heads'], EVAL_DIMS['num_layers'], EVAL_DIMS['num_heads'])
+    assert maxabs(om, T_(g['motion_mu'])) <= 1e-5 and maxabs(ot, T_(g['text_mu'])) <= 1e-5
+    # padded frames / padded tokens must not reach the embedding
+    m2 = T_(g['motion']).clone()
+    m2[2, 9:] = 123.0
+    assert torch.equal(EO.encode_motion(sd, m2, g['lengths'].tolist(), EVAL_DIMS['num_layers'], EVAL_DIMS['num_heads'])[2], om[2])
