@@ -410,3 +410,41 @@ def build_evaluator(metric, eval_cfg, data_len, eval_indexes):
         for i in range(eval_cfg['replication_times']):
             eval_indexes[i] = np.concatenate((eval_indexes[i], ev.append_indexes[i]), axis=0)
     return ev, eval_indexes
+
+
+class EvaluationPlan:
+    """The evaluation flow a test-mode dataset drives (``BaseMotionDataset.prepare_evaluation`` / ``evaluate``,
+    mogen/datasets/base_dataset.py:99-139), detached from the dataset classes: build the embedding model once, draw the
+    per-replication sample orders, build one evaluator per entry of ``eval_cfg['metrics']`` (MultiModality extends the
+    orders), and reduce a result list to the metrics dict.  ``eval_indexes`` is the order in which the sampler has to
+    produce results (``dataset[i]`` of the reference returns sample ``eval_indexes[i]``)."""
+
+    def __init__(self, eval_cfg, data_len):
+        from .builder import build_submodule
+        cfg = dict(eval_cfg)
+        model = cfg.get('evaluator_model', None)
+        if isinstance(model, dict):
+            model = build_submodule(model).to('cuda').eval()
+        cfg['evaluator_model'] = self.evaluator_model = model
+        orders = []
+        for _ in range(cfg['replication_times']):
+            order = np.arange(data_len)
+            if cfg.get('shuffle_indexes', False):
+                np.random.shuffle(order)
+            orders.append(order)
+        self.evaluators = []
+        for metric in cfg['metrics']:
+            ev, orders = build_evaluator(metric, cfg, data_len, orders)
+            self.evaluators.append(ev)
+        self.eval_indexes = np.concatenate(orders)
+
+    def evaluate(self, results):
+        if results[0]['pred_motion'].shape[-1] == 322:
+            # the SMPL-X evaluators score body + hands only: face / expression channels are taken from the ground truth
+            for r in results:
+                r['pred_motion'][:, 156:309] = r['motion'][:, 156:309]
+                r['pred_motion'][:, 312:] = r['motion'][:, 312:]
+        metrics = {}
+        for ev in self.evaluators:
+            metrics.update(ev.evaluate(results))
+        return metrics

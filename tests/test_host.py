@@ -337,3 +337,32 @@ def test_evaluators_host_logic_against_reference_golden():
     assert list(metrics) == [str(n) for n in g['ev_names']]
     got = np.array([float(v) for v in metrics.values()])
     assert np.allclose(got, g['ev_values'], rtol=1e-6, atol=1e-7), (got, g['ev_values'])
+
+
+def test_evaluation_plan_orders_and_face_alignment():
+    """BaseMotionDataset.prepare_evaluation / evaluate (base_dataset.py:99-139): per-replication orders (shuffled, MultiModality
+    appends its repeats), one evaluator per metric, 322-d predictions get the ground-truth face channels before scoring."""
+    from motioncraft_amd import evaluation as E
+    from helpers import StubEvalModel
+    N, REP = 40, 2
+    cfg = dict(shuffle_indexes=True, replication_times=REP, replication_reduction='statistics', evaluator_model=StubEvalModel(nfeats=322),
+               metrics=[dict(type='R Precision', batch_size=20, top_k=3), dict(type='FID'), dict(type='Diversity', num_samples=10),
+                        dict(type='MultiModality', num_samples=3, num_repeats=4, num_picks=2)])
+    np.random.seed(5)
+    plan = E.EvaluationPlan(cfg, N)
+    assert len(plan.evaluators) == 4 and plan.eval_indexes.shape == (REP * (N + 12),)
+    first = plan.eval_indexes[:N]
+    assert sorted(first.tolist()) == list(range(N)) and first.tolist() != list(range(N))
+    g = torch.Generator().manual_seed(1)
+    results = []
+    for i in plan.eval_indexes:
+        gt = torch.randn(10, 322, generator=g)
+        results.append(dict(motion=gt, pred_motion=gt + torch.randn(10, 322, generator=g), motion_mask=torch.ones(10),
+                            pred_motion_mask=torch.ones(10), motion_length=torch.tensor(10), pred_motion_length=torch.tensor(10),
+                            text='sample %d' % int(i)))
+    metrics = plan.evaluate(results)
+    assert {'R_precision Top 3 (mean)', 'FID (mean)', 'FID (conf)', 'Diversity (mean)', 'MultiModality (mean)'} <= set(metrics)
+    r = results[7]
+    assert torch.equal(r['pred_motion'][:, 156:309], r['motion'][:, 156:309]) and torch.equal(r['pred_motion'][:, 312:], r['motion'][:, 312:])
+    assert not torch.equal(r['pred_motion'][:, :156], r['motion'][:, :156])
+    assert all(np.isfinite(float(v)) for v in metrics.values())
