@@ -5,7 +5,8 @@ Mirrors ``DiffusionTransformer.build_text_encoder`` / ``encode_text``
 ``text_pre_proj`` -> ``nn.TransformerEncoder`` (post-LN, GELU) -> ``text_ln``.  The reference accepts a precomputed
 ``clip_feat`` [B, 77, 512] in place of the raw prompt; that entry needs no tokenizer.  The raw-prompt entry needs
 ``clip.tokenize`` (BPE vocabulary of the un-vendored ``clip`` package): when that package is importable it is used on
-the host, otherwise token ids must be supplied.
+the host; with only its vocabulary file at hand ``clip_bpe.ClipBPE`` restates the scheme; otherwise token ids must be
+supplied.
 """
 import ctypes
 
@@ -102,14 +103,25 @@ class NativeTextEncoder:
                    'mc_textenc_forward_tokens')
         return (out, feat) if return_clip_feat else out
 
-    def encode_text(self, text, device):
-        """Raw prompts: needs the reference's own tokenizer (``clip.tokenize(text, truncate=True)``)."""
+    def encode_text(self, text, device, bpe_path=None):
+        """Raw prompts -> xf_out: ``clip.tokenize(text, truncate=True)`` of the reference when the ``clip`` package is
+        installed, else the restated byte-pair scheme over its vocabulary file (``bpe_path`` or $MC_CLIP_BPE,
+        ``bpe_simple_vocab_16e6.txt.gz``; see clip_bpe.py)."""
+        import os
         try:
             import clip
+            tokens = clip.tokenize(text, truncate=True)
         except ImportError as e:
-            raise NotImplementedError("raw prompts need clip.tokenize (the `clip` package and its BPE vocabulary are not "
-                                      'installed): pass clip_feat [B,77,512] or token ids instead') from e
-        return self.encode_tokens(clip.tokenize(text, truncate=True).to(device))
+            bpe_path = bpe_path or os.environ.get('MC_CLIP_BPE')
+            if not bpe_path:
+                raise NotImplementedError("raw prompts need clip.tokenize: neither the `clip` package nor its BPE vocabulary "
+                                          '(MC_CLIP_BPE=/path/to/bpe_simple_vocab_16e6.txt.gz) is available: pass clip_feat '
+                                          '[B,77,512] or token ids instead') from e
+            from .clip_bpe import ClipBPE
+            if getattr(self, '_bpe_path', None) != bpe_path:
+                self._bpe, self._bpe_path = ClipBPE(bpe_path, vocab_size=self.cfg.vocab), bpe_path
+            tokens = torch.from_numpy(self._bpe.tokenize(list(text), context_length=self.cfg.max_len, truncate=True))
+        return self.encode_tokens(tokens.to(device))
 
     def close(self):
         if self.handle:

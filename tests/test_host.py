@@ -366,3 +366,33 @@ def test_evaluation_plan_orders_and_face_alignment():
     assert torch.equal(r['pred_motion'][:, 156:309], r['motion'][:, 156:309]) and torch.equal(r['pred_motion'][:, 312:], r['motion'][:, 312:])
     assert not torch.equal(r['pred_motion'][:, :156], r['motion'][:, :156])
     assert all(np.isfinite(float(v)) for v in metrics.values())
+
+
+def test_clip_byte_pair_tokenizer_on_a_synthetic_merges_file(tmp_path):
+    """clip_bpe.ClipBPE (restated clip.tokenize; the real vocabulary is un-vendored -> parity unpinned): id layout, merge
+    order, byte fallback, clean-up, markers, padding and truncation on a hand-made merges file."""
+    import gzip
+    from motioncraft_amd.clip_bpe import ClipBPE, byte_symbols
+    merges = ['#version: test', 'w a', 'l k</w>', 'wa lk</w>', 'r u', 'ru n</w>', 'a </w>']          # last line never applies
+    path = tmp_path / 'bpe.txt.gz'
+    with gzip.open(path, 'wb') as f:
+        f.write('\n'.join(merges).encode('utf-8'))
+    n = len(merges) - 1
+    bpe = ClipBPE(str(path), vocab_size=256 + 256 + n + 2)
+    sym = byte_symbols()
+    assert len(set(sym.values())) == 256 and sym[ord('a')] == 'a' and sym[ord(' ')] == chr(256 + 32)
+    assert bpe.ids['!'] == 0 and bpe.ids['!</w>'] == 256 and bpe.ids['wa'] == 512 and bpe.sot == 512 + n and bpe.eot == 513 + n
+    # "walk" -> w a l k</w> -> wa l k</w> -> wa lk</w> -> walk</w>
+    assert bpe.encode('walk') == [bpe.ids['walk</w>']]
+    assert bpe.encode('  WALK \n run ') == [bpe.ids['walk</w>'], bpe.ids['run</w>']]
+    # no merge for these symbols: one id per byte symbol, the last one tagged; punctuation splits off
+    assert bpe.encode('ok!') == [bpe.ids['o'], bpe.ids['k</w>'], bpe.ids['!</w>']]
+    e_acute = 'é'.encode('utf-8')
+    assert bpe.encode('é') == [bpe.ids[sym[e_acute[0]]], bpe.ids[sym[e_acute[1]] + '</w>']]
+    assert bpe.encode('a &amp;amp; 7') == [bpe.ids['a</w>'], bpe.ids['&</w>'], bpe.ids['7</w>']]
+    t = bpe.tokenize(['walk', 'run ' * 100], context_length=8)
+    assert t.dtype == np.int64 and t.shape == (2, 8)
+    assert t[0].tolist() == [bpe.sot, bpe.ids['walk</w>'], bpe.eot, 0, 0, 0, 0, 0]
+    assert t[1, 0] == bpe.sot and t[1, -1] == bpe.eot and (t[1, 1:-1] == bpe.ids['run</w>']).all()
+    with pytest.raises(RuntimeError):
+        bpe.tokenize(['run ' * 100], context_length=8, truncate=False)
