@@ -807,18 +807,31 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     // large batches: the CFG halves run on two streams (see run_layer); with a control branch the extra whole-batch
     // ops between layers need both halves, so the halves re-join after every layer
     const bool fused = mc_chain_enabled(1) && mc_chain_enabled(2) && mc_mlp_supported(L, 32);
-    const int split = (c->side && mc_chain_enabled(5) && c->N > 65536 && fused) ? (NC > 0 ? 1 : 2) : 0;
+    const int split = (c->side && mc_chain_enabled(5) && c->N > 65536 && fused) ? ((NC > 0 && !mc_chain_enabled(9)) ? 1 : 2) : 0;
+    // row-wise op between layers, on the stream of the sample group that owns the rows (one launch when not split)
+    auto by_group = [&](auto&& fn) -> int {
+        if (split != 2) return fn(0L, c->rows, s);
+        for (int k = 0; k < c->nparts; ++k) {
+            const long r0 = part_row0(c, k);
+            if (int e = fn(r0, part_row0(c, k + 1) - r0, part_stream(c, k, s))) return e;
+        }
+        return MC_OK;
+    };
     for (int i = 0; i < nl; ++i) {
         // ControlT2MHalf.forward_test (controlnet.py:372-413): base block 0, then for index 1..copy:
         //   c, c_skip = controlnet[index-1](x=h, c=c);  h = base[index](h + c_skip)
         if (i >= 1 && i <= NC) {
             const int j = i - 1, slot = g.num_layers + j;
-            if (j == 0) {
-                if ((r = mc_launch_add_rows(c->hc, c->h, c->cb, nullptr, c->rows, D, s))) return r;   // x + before_proj(c)
+            if (j == 0) {                                                                              // x + before_proj(c)
+                if ((r = by_group([&](long r0, long n, hipStream_t sk) {
+                         return mc_launch_add_rows(c->hc + r0 * D, c->h + r0 * D, c->cb + r0 * D, nullptr, n, D, sk); })))
+                    return r;
             }
-            if ((r = run_layer(c, slot, c->hc, step, false, split ? 1 : 0, s))) return r;                        // copied_block
+            if ((r = run_layer(c, slot, c->hc, step, false, split, s))) return r;                       // copied_block
             const LayerW& cw = c->lw[slot];
-            if ((r = dense(c->hc, D, cw.after_w, D, cw.after_b, c->h, D, c->h, D, c->rows, D, D, ACT_NONE, s))) return r;  // h += after_proj(c)
+            if ((r = by_group([&](long r0, long n, hipStream_t sk) {                                   // h += after_proj(c)
+                     return dense(c->hc + r0 * D, D, cw.after_w, D, cw.after_b, c->h + r0 * D, D, c->h + r0 * D, D, n, D, D, ACT_NONE, sk); })))
+                return r;
         }
         if ((r = run_layer(c, i, c->h, step, i == 0, split, s))) return r;
     }
