@@ -62,7 +62,7 @@ def synth_condition(B, seed):
     return xf
 
 
-def cpu_baseline(B=4, T=196, steps=3):
+def cpu_baseline(B=8, T=196, steps=6):
     """The oracle on the host cores: `steps` DDPM steps at batch B, same synthetic inputs/weights.
     torch-CPU does not scale to every core of a many-core host (256-thread runs are >100x slower
     than 16-32 threads), so the thread count is calibrated first on one B=1 denoiser call and the
