@@ -19,6 +19,8 @@
  *                                                                      mogen/models/transformers/diffusion_transformer.py:109-172
  *   mc_evalenc_*          T2MContrastiveModel_SMPLX.encode_motion / encode_text (evaluation embeddings)
  *                                                                      mogen/models/rnns/t2m_bigru_smplx.py:66-437
+ *   mc_t2meval_*          T2MContrastiveModel.encode_motion / encode_text (HumanML3D / KIT evaluation embeddings)
+ *                                                                      mogen/models/rnns/t2m_bigru.py:72-299
  *   mc_wavenc_*           WavEncoder (audio condition pre-encoder)     mogen/models/utils/blocks.py:11-71; controlnet.py:90-105,187
  *   mc_postprocess_smplx  de-normalise + SMPL-X re-pack + temporal filter  tools/visualize.py:39-44,217-246; tools/s2g_test.py:289-297
  *   mc_op_renoise         GaussianDiffusion._undo (resampling jumps)   gaussian_diffusion.py:429-435, 1113-1118
@@ -214,6 +216,34 @@ int mc_evalenc_encode_motion(mc_evalenc* e, const float* motion_dev, const int32
 /* encode_text(...).loc after the tokenizer: ids_dev int32 [B, S], mask_dev uint8 [B, S] (attention_mask) -> mu_out_dev */
 int mc_evalenc_encode_text(mc_evalenc* e, const int32_t* ids_dev, const uint8_t* mask_dev, int32_t B, int32_t S,
                            float* mu_out_dev, void* stream);
+
+/* ---- HumanML3D / KIT evaluation embedding model (T2MContrastiveModel; mogen/models/rnns/t2m_bigru.py:284-299) --------
+ * motion side: T2MMotionEncoder = MovementConvEncoder + MotionEncoderBiGRUCo (:72-110, :226-282); text side:
+ * TextEncoderBiGRUCo on word vectors + part-of-speech one-hots (:186-223; the GloVe lookup stays with the dataset). */
+typedef struct mc_t2meval mc_t2meval;
+typedef struct mc_t2meval_config {
+    int32_t input_size;       /* motion_encoder.input_size (263 / 251); the last 4 channels are dropped            */
+    int32_t movement_hidden;  /* 512                                                                               */
+    int32_t movement_latent;  /* 512                                                                               */
+    int32_t motion_hidden;    /* 1024                                                                              */
+    int32_t motion_latent;    /* 512                                                                               */
+    int32_t word_size;        /* 300; 0 = motion side only                                                         */
+    int32_t pos_size;         /* 15                                                                                */
+    int32_t text_hidden;      /* 512                                                                               */
+    int32_t text_out;         /* 512                                                                               */
+} mc_t2meval_config;
+int mc_t2meval_create(const mc_t2meval_config* cfg, mc_t2meval** out);
+void mc_t2meval_destroy(mc_t2meval* e);
+/* fp32 parameters from host memory: the checkpoint's three state dicts flattened with their names as prefixes
+ * ("movement_encoder.main.0.weight" [O, C, 4] as stored, "motion_encoder.gru.weight_ih_l0_reverse", "text_encoder.hidden", ...) */
+int mc_t2meval_set_param(mc_t2meval* e, const char* name, const float* host, int64_t numel);
+int mc_t2meval_finalize(mc_t2meval* e);
+/* motion_dev [B, T, input_size], lengths_dev int32 [B] (frames, >= 4) -> out_dev [B, motion_latent] */
+int mc_t2meval_encode_motion(mc_t2meval* e, const float* motion_dev, const int32_t* lengths_dev, int32_t B, int32_t T,
+                             float* out_dev, void* stream);
+/* word_emb_dev [B, S, word_size], pos_onehot_dev [B, S, pos_size], sent_len_dev int32 [B] (>= 1) -> out_dev [B, text_out] */
+int mc_t2meval_encode_text(mc_t2meval* e, const float* word_emb_dev, const float* pos_onehot_dev, const int32_t* sent_len_dev,
+                           int32_t B, int32_t S, float* out_dev, void* stream);
 
 /* ---- WavEncoder: step-invariant audio condition encoder of the speech-to-gesture configs ------------------ */
 typedef struct mc_wavenc mc_wavenc;

@@ -448,3 +448,136 @@ class EvaluationPlan:
         for ev in self.evaluators:
             metrics.update(ev.evaluate(results))
         return metrics
+
+
+# ---- HumanML3D / KIT evaluator (mogen/models/rnns/t2m_bigru.py) ------------------------------------------------------
+class NativeT2MEvaluator:
+    """Device encoders of ``T2MContrastiveModel`` over the checkpoint's three state dicts flattened with their names as
+    prefixes (``movement_encoder.*``, ``motion_encoder.*``, ``text_encoder.*``)."""
+
+    def __init__(self, state_dict, input_size=263, movement_hidden_size=512, movement_latent_size=512, motion_hidden_size=1024,
+                 motion_latent_size=512, word_size=300, pos_size=15, hidden_size=512, output_size=512):
+        self.lib = _lib.load(require_gpu=True)
+        sd = dict(state_dict)
+        self.has_text = 'text_encoder.pos_emb.weight' in sd
+        cfg = _lib.T2MEvalConfig()
+        cfg.input_size, cfg.movement_hidden, cfg.movement_latent = input_size, movement_hidden_size, movement_latent_size
+        cfg.motion_hidden, cfg.motion_latent = motion_hidden_size, motion_latent_size
+        cfg.word_size, cfg.pos_size, cfg.text_hidden, cfg.text_out = (word_size if self.has_text else 0), pos_size, hidden_size, output_size
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mc_t2meval_create(ctypes.byref(cfg), ctypes.byref(h)), 'mc_t2meval_create')
+        self.handle = h
+        for k, v in sd.items():
+            if not k.startswith(('movement_encoder.', 'motion_encoder.', 'text_encoder.')):
+                continue
+            a = np.ascontiguousarray(torch.as_tensor(v).detach().cpu().float().numpy())
+            _lib.check(self.lib.mc_t2meval_set_param(self.handle, k.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                       f'mc_t2meval_set_param({k})')
+        _lib.check(self.lib.mc_t2meval_finalize(self.handle), 'mc_t2meval_finalize')
+
+    def encode_motion(self, motion, motion_length):
+        if not (motion.is_cuda and motion.dim() == 3 and motion.shape[2] == self.cfg.input_size):
+            raise ValueError(f'motion must be a device tensor [B, T, {self.cfg.input_size}]')
+        m = motion.to(torch.float32).contiguous()
+        n = torch.as_tensor(motion_length).reshape(-1).to(device=m.device, dtype=torch.int32).contiguous()
+        if n.numel() != m.shape[0] or int(n.min()) < 4 or int(n.max()) > m.shape[1]:
+            raise ValueError('motion_length: one length in [4, T] per sample (lengths // 4 must be >= 1, like pack_padded_sequence)')
+        out = torch.empty(m.shape[0], self.cfg.motion_latent, device=m.device, dtype=torch.float32)
+        _lib.check(self.lib.mc_t2meval_encode_motion(self.handle, ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(n.data_ptr()),
+                                                     m.shape[0], m.shape[1], ctypes.c_void_p(out.data_ptr()),
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   'mc_t2meval_encode_motion')
+        return out
+
+    def encode_word_vectors(self, word_emb, pos_onehot, sent_len):
+        """word_emb [B, S, word_size], pos_onehot [B, S, pos_size], sent_len [B] (device) -> [B, output_size]."""
+        if not self.has_text:
+            raise RuntimeError('the evaluator was built without text_encoder.* weights')
+        w = word_emb.to(torch.float32).contiguous()
+        p = pos_onehot.to(device=w.device, dtype=torch.float32).contiguous()
+        n = torch.as_tensor(sent_len).reshape(-1).to(device=w.device, dtype=torch.int32).contiguous()
+        if not w.is_cuda or w.dim() != 3 or w.shape[2] != self.cfg.word_size or tuple(p.shape) != (w.shape[0], w.shape[1], self.cfg.pos_size):
+            raise ValueError('word_emb [B, S, word_size] / pos_onehot [B, S, pos_size] device tensors expected')
+        if n.numel() != w.shape[0] or int(n.min()) < 1 or int(n.max()) > w.shape[1]:
+            raise ValueError('sent_len: one length in [1, S] per sentence')
+        out = torch.empty(w.shape[0], self.cfg.text_out, device=w.device, dtype=torch.float32)
+        _lib.check(self.lib.mc_t2meval_encode_text(self.handle, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(p.data_ptr()),
+                                                   ctypes.c_void_p(n.data_ptr()), w.shape[0], w.shape[1], ctypes.c_void_p(out.data_ptr()),
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   'mc_t2meval_encode_text')
+        return out
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.mc_t2meval_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def vectorize_tokens(token, w_vectorizer, max_text_len):
+    """T2MTextEncoder.forward's host part (t2m_bigru.py:131-165): ``token`` strings of 'word/POS' items -> padded word
+    vectors, part-of-speech one-hots and sentence lengths.  ``w_vectorizer['word/POS']`` returns (vector, one-hot) -- the
+    GloVe-backed ``WordVectorizer`` of the dataset side."""
+    words, poss, lens = [], [], []
+    for sent in token:
+        items = sent.split(' ')
+        if len(items) < max_text_len:
+            items = ['sos/OTHER'] + items + ['eos/OTHER']
+            n = len(items)
+            items += ['unk/OTHER'] * (max_text_len + 2 - n)
+        else:
+            items = ['sos/OTHER'] + items[:max_text_len] + ['eos/OTHER']
+            n = len(items)
+        pairs = [w_vectorizer[it] for it in items]
+        words.append(np.stack([np.asarray(p[0], dtype=np.float32) for p in pairs]))
+        poss.append(np.stack([np.asarray(p[1], dtype=np.float32) for p in pairs]))
+        lens.append(n)
+    return torch.from_numpy(np.stack(words)), torch.from_numpy(np.stack(poss)), torch.tensor(lens, dtype=torch.int32)
+
+
+@SUBMODULES.register_module()
+class T2MContrastiveModel:
+    """``evaluator_model=dict(type='T2MContrastiveModel', motion_encoder=dict(input_size, movement_hidden_size, ...),
+    text_encoder=dict(word_size, pos_size, hidden_size, output_size, max_text_len), init_cfg=dict(type='Pretrained',
+    checkpoint=...))`` (configs/_base_/datasets/human_ml3d_bs128.py:42-58).  The checkpoint holds the three state dicts
+    ``movement_encoder`` / ``motion_encoder`` / ``text_encoder`` (t2m_bigru.py:84-87,126-128).  ``w_vectorizer``: the
+    dataset side's word-vector lookup (the reference builds ``WordVectorizer('./data/glove', 'our_vab')`` itself)."""
+
+    def __init__(self, motion_encoder=None, text_encoder=None, init_cfg=None, state_dict=None, w_vectorizer=None):
+        me, te = dict(motion_encoder or {}), dict(text_encoder or {})
+        if state_dict is None:
+            assert init_cfg is not None and init_cfg['type'] == 'Pretrained'
+            ck = torch.load(init_cfg['checkpoint'], map_location='cpu', weights_only=False)
+            state_dict = {f'{part}.{k}': v for part in ('movement_encoder', 'motion_encoder', 'text_encoder') if part in ck
+                          for k, v in ck[part].items()}
+        self.max_text_len = te.pop('max_text_len', 20)
+        self.w_vectorizer = w_vectorizer
+        self.encoder = NativeT2MEvaluator(state_dict, **me, **te)
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def encode_motion(self, motion, motion_length=None, motion_mask=None, **kwargs):
+        if motion_length is None:
+            motion_length = [motion.shape[1]] * motion.shape[0]
+        return self.encoder.encode_motion(motion, motion_length)
+
+    def encode_text(self, text, token=None, device=None, **kwargs):
+        if 'word_emb' in kwargs:
+            w, p, n = kwargs['word_emb'], kwargs['pos_onehot'], kwargs['sent_len']
+        else:
+            if self.w_vectorizer is None:
+                raise RuntimeError('encode_text needs the word-vector lookup: pass w_vectorizer= (GloVe WordVectorizer of the dataset '
+                                   'side) at construction, or word_emb / pos_onehot / sent_len tensors')
+            w, p, n = vectorize_tokens(token, self.w_vectorizer, self.max_text_len)
+        device = device if device is not None else 'cuda'
+        return self.encoder.encode_word_vectors(w.to(device), p.to(device), n.to(device))

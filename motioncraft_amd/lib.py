@@ -40,6 +40,11 @@ class EvalEncConfig(ctypes.Structure):
                                               'bert_layers', 'bert_heads', 'bert_ff', 'bert_vocab', 'bert_max_pos')]
 
 
+class T2MEvalConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('input_size', 'movement_hidden', 'movement_latent', 'motion_hidden', 'motion_latent',
+                                              'word_size', 'pos_size', 'text_hidden', 'text_out')]
+
+
 class TextEncConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('clip_dim', 'text_latent_dim', 'num_layers', 'ff_size', 'num_heads', 'max_len',
                                               'clip_layers', 'clip_heads', 'clip_ff', 'vocab')]
@@ -85,6 +90,12 @@ _SIGNATURES = {
     'mc_evalenc_finalize': (ctypes.c_int, [_P]),
     'mc_evalenc_encode_motion': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
     'mc_evalenc_encode_text': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    'mc_t2meval_create': (ctypes.c_int, [ctypes.POINTER(T2MEvalConfig), ctypes.POINTER(_P)]),
+    'mc_t2meval_destroy': (None, [_P]),
+    'mc_t2meval_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),
+    'mc_t2meval_finalize': (ctypes.c_int, [_P]),
+    'mc_t2meval_encode_motion': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    'mc_t2meval_encode_text': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
     'mc_wavenc_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     'mc_wavenc_destroy': (None, [_P]),
     'mc_wavenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),

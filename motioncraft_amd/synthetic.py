@@ -349,6 +349,48 @@ def make_eval_encoder_state(shapes, seed=0):
     return sd
 
 
+def _bigru_head_shapes(s, pre, din, hid, dout):
+    s[pre + 'hidden'] = (2, 1, hid)
+    s[pre + 'input_emb.weight'], s[pre + 'input_emb.bias'] = (hid, din), (hid,)
+    for sfx in ('', '_reverse'):
+        s[pre + 'gru.weight_ih_l0' + sfx], s[pre + 'gru.weight_hh_l0' + sfx] = (3 * hid, hid), (3 * hid, hid)
+        s[pre + 'gru.bias_ih_l0' + sfx], s[pre + 'gru.bias_hh_l0' + sfx] = (3 * hid,), (3 * hid,)
+    s[pre + 'output_net.0.weight'], s[pre + 'output_net.0.bias'] = (hid, 2 * hid), (hid,)
+    s[pre + 'output_net.1.weight'], s[pre + 'output_net.1.bias'] = (hid,), (hid,)
+    s[pre + 'output_net.3.weight'], s[pre + 'output_net.3.bias'] = (dout, hid), (dout,)
+
+
+def t2m_eval_param_shapes(input_size=263, movement_hidden_size=512, movement_latent_size=512, motion_hidden_size=1024,
+                          motion_latent_size=512, word_size=300, pos_size=15, hidden_size=512, output_size=512, **unused):
+    """The three state dicts of the T2M evaluator checkpoint (``movement_encoder`` / ``motion_encoder`` / ``text_encoder``,
+    t2m_bigru.py:84-87,126-128) flattened with their names as prefixes."""
+    s = OrderedDict()
+    m = 'movement_encoder.'
+    s[m + 'main.0.weight'], s[m + 'main.0.bias'] = (movement_hidden_size, input_size - 4, 4), (movement_hidden_size,)
+    s[m + 'main.3.weight'], s[m + 'main.3.bias'] = (movement_latent_size, movement_hidden_size, 4), (movement_latent_size,)
+    s[m + 'out_net.weight'], s[m + 'out_net.bias'] = (movement_latent_size, movement_latent_size), (movement_latent_size,)
+    _bigru_head_shapes(s, 'motion_encoder.', movement_latent_size, motion_hidden_size, motion_latent_size)
+    s['text_encoder.pos_emb.weight'], s['text_encoder.pos_emb.bias'] = (word_size, pos_size), (word_size,)
+    _bigru_head_shapes(s, 'text_encoder.', word_size, hidden_size, output_size)
+    return s
+
+
+def make_t2m_eval_state(shapes, seed=0):
+    sd = OrderedDict()
+    for k, shape in shapes.items():
+        r = _randn(seed, 't2m.' + k, shape)
+        if k.endswith('hidden'):
+            sd[k] = r
+        elif 'bias' in k:
+            sd[k] = (0.1 if 'output_net.1' in k else 0.05) * r
+        elif 'output_net.1' in k:
+            sd[k] = 1.0 + 0.1 * r
+        else:
+            fan = shape[1] * (shape[2] if len(shape) == 3 else 1)
+            sd[k] = r / math.sqrt(fan)
+    return sd
+
+
 def make_wav_encoder_state(out_dim, audio_in, seed=0):
     """Deterministic non-trivial WavEncoder weights (BatchNorm running stats included) keyed like the reference."""
     from .wav_encoder import wav_encoder_param_shapes

@@ -31,6 +31,7 @@ Fixtures
   evaluator.npz         evaluation embedding model (ActorAgnosticEncoder + DistilbertActorAgnosticEncoder over a reduced
                         DistilBERT), the transformers WordPiece tokenizer on tricky sentences, mogen/core/evaluation
                         metric functions and the five evaluators driven by a stub embedding model
+  t2m_evaluator.npz     HumanML3D/KIT evaluator (MovementConvEncoder + BiGRU motion and text heads), reduced widths
   full_denoise.npz      0.125b config, B=1, T=196: x0 prediction at t=999 and t=57
   full_ddim.npz         0.125b config, B=1: final sample of the 50-step DDIM loop
 """
@@ -524,6 +525,56 @@ def evaluator():
     np.savez_compressed(os.path.join(OUT, 'evaluator.npz'), **save)
 
 
+from helpers import T2M_DIMS, T2M_TEXT  # noqa: E402
+
+
+def t2m_evaluator():
+    """HumanML3D / KIT evaluator (T2MContrastiveModel, t2m_bigru.py): movement conv encoder + BiGRU motion / text heads."""
+    import importlib
+    from oracle import t2m_eval_oracle as TO
+    ref_shim.install()
+    ref_shim._shell('mogen.models.rnns', ref_shim.REF + '/mogen/models/rnns')
+    m = importlib.import_module('mogen.models.rnns.t2m_bigru')
+    mov = m.MovementConvEncoder(T2M_DIMS['input_size'] - 4, T2M_DIMS['movement_hidden_size'], T2M_DIMS['movement_latent_size']).eval()
+    mot = m.MotionEncoderBiGRUCo(T2M_DIMS['movement_latent_size'], T2M_DIMS['motion_hidden_size'], T2M_DIMS['motion_latent_size']).eval()
+    txt = m.TextEncoderBiGRUCo(**T2M_TEXT).eval()
+    shapes = W.t2m_eval_param_shapes(**T2M_DIMS, **T2M_TEXT)
+    ref_keys = {}
+    for pre, mod in (('movement_encoder.', mov), ('motion_encoder.', mot), ('text_encoder.', txt)):
+        ref_keys.update({pre + k: v for k, v in mod.state_dict().items()})
+    assert set(ref_keys) == set(shapes), sorted(set(ref_keys) ^ set(shapes))[:8]
+    for k, v in ref_keys.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sd = W.make_t2m_eval_state(shapes, seed=12)
+    for pre, mod in (('movement_encoder.', mov), ('motion_encoder.', mot), ('text_encoder.', txt)):
+        mod.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+
+    class Enc(torch.nn.Module):          # T2MMotionEncoder.forward without its constructor (which only wires the two modules)
+        movement_encoder, motion_encoder = mov, mot
+        forward = m.T2MMotionEncoder.forward
+    g = torch.Generator().manual_seed(81)
+    B, T, S = 4, 40, 12
+    motion = torch.randn(B, T, T2M_DIMS['input_size'], generator=g)
+    lengths = torch.tensor([33, 40, 8, 21])
+    word = torch.randn(B, S, T2M_TEXT['word_size'], generator=g)
+    pos = F_one_hot(torch.randint(0, 15, (B, S), generator=g), 15)
+    sent = torch.tensor([12, 5, 9, 3])
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        ref_m = Enc()(motion, lengths, None)
+        ref_t = txt(word, pos, sent)
+    om = TO.encode_motion(sd, motion, lengths)
+    ot = TO.encode_text(sd, word, pos, sent)
+    print(f't2m_evaluator: motion {tuple(ref_m.shape)} oracle vs reference {maxabs(ref_m, om):.2e}; text oracle vs reference {maxabs(ref_t, ot):.2e}')
+    assert maxabs(ref_m, om) <= 1e-5 and maxabs(ref_t, ot) <= 1e-5
+    np.savez_compressed(os.path.join(OUT, 't2m_evaluator.npz'), motion=motion.numpy(), lengths=lengths.numpy(), motion_emb=ref_m.numpy(),
+                        word_emb=word.numpy(), pos_onehot=pos.numpy(), sent_len=sent.numpy(), text_emb=ref_t.numpy(), seed=np.int64(12))
+
+
+def F_one_hot(idx, n):
+    return torch.nn.functional.one_hot(idx, n).float()
+
+
 def full():
     dims, B, T = FULL, 1, 196
     t0 = time.time()
@@ -571,7 +622,7 @@ if __name__ == '__main__':
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
-                  repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, evaluator=evaluator, full=full)
+                  repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, evaluator=evaluator, t2m_evaluator=t2m_evaluator, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):
             continue

@@ -41,6 +41,8 @@ def step_noise_from_seed(seed, shape, num):
 # ---- evaluation-side fixtures (shared with tests/golden/make_golden.py) -----------------------------------------
 EVAL_DIMS = dict(nfeats=322, latent_dim=128, ff_size=256, num_layers=2, num_heads=2)
 EVAL_BERT = dict(dim=128, n_layers=2, n_heads=2, hidden_dim=256, max_position_embeddings=64)
+T2M_DIMS = dict(input_size=263, movement_hidden_size=64, movement_latent_size=64, motion_hidden_size=128, motion_latent_size=32)
+T2M_TEXT = dict(word_size=300, pos_size=15, hidden_size=64, output_size=32)
 
 
 class StubEvalModel:

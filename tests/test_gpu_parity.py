@@ -921,3 +921,44 @@ def test_fid_and_precision_evaluators_on_device_embeddings(tmp_path):
     assert abs(got['Matching Score (mean)'] - match) <= 1e-3
     assert np.allclose([got['R_precision Top %d (mean)' % k] for k in (1, 2, 3)], hits, atol=1.5 / N)
     assert got['FID (conf)'] == 0
+
+
+def test_t2m_bigru_evaluator_vs_reference_golden_and_oracle():
+    """HumanML3D / KIT evaluator (T2MContrastiveModel, t2m_bigru.py) through mc_t2meval_*: conv-as-GEMM movement encoder and
+    BiGRU heads vs the reference's outputs (reduced widths), then the shipped widths (263-d, 512 / 1024 / 512; 196 frames;
+    word_size 300, hidden 512, 22 tokens) vs the oracle; word vectors past a sentence's length do not matter."""
+    import motioncraft_amd as mc
+    from motioncraft_amd import evaluation as E
+    from helpers import T2M_DIMS, T2M_TEXT
+    from oracle import t2m_eval_oracle as TO, weights as W
+    g = load('t2m_evaluator.npz')
+    sd = W.make_t2m_eval_state(W.t2m_eval_param_shapes(**T2M_DIMS, **T2M_TEXT), seed=int(g['seed']))
+    model = mc.build_submodule(dict(type='T2MContrastiveModel', motion_encoder=dict(T2M_DIMS), text_encoder=dict(T2M_TEXT, max_text_len=10),
+                                    state_dict=sd))
+    me = model.encode_motion(T_(g['motion']).cuda(), torch.from_numpy(g['lengths']).cuda())
+    te = model.encode_text(None, word_emb=T_(g['word_emb']), pos_onehot=T_(g['pos_onehot']), sent_len=torch.from_numpy(g['sent_len']))
+    e1, e2 = maxabs(me, T_(g['motion_emb'])), maxabs(te, T_(g['text_emb']))
+    print(f't2m evaluator (reduced): |hip - reference| motion {e1:.2e}, text {e2:.2e}')
+    assert e1 <= 5e-5 and e2 <= 5e-5
+    w2 = T_(g['word_emb']).clone()                           # (motion: the conv windows do reach past the length, as in the reference)
+    w2[3, 3:] = -9.0
+    assert torch.equal(model.encode_text(None, word_emb=w2, pos_onehot=T_(g['pos_onehot']), sent_len=torch.from_numpy(g['sent_len']))[3], te[3])
+    with pytest.raises(ValueError):
+        model.encode_motion(T_(g['motion']).cuda(), torch.tensor([3, 40, 8, 21]))
+    with pytest.raises(RuntimeError):
+        model.encode_text(['a'], token=['walk/VERB'])            # no word-vector lookup given
+    shapes = W.t2m_eval_param_shapes()
+    sd = W.make_t2m_eval_state(shapes, seed=2)
+    enc = E.NativeT2MEvaluator(sd)
+    gen = torch.Generator().manual_seed(6)
+    B, T, S = 6, 196, 22
+    motion = torch.randn(B, T, 263, generator=gen)
+    lengths = torch.tensor([196, 120, 64, 7, 4, 199 - 3])
+    word = torch.randn(B, S, 300, generator=gen)
+    pos = torch.nn.functional.one_hot(torch.randint(0, 15, (B, S), generator=gen), 15).float()
+    sent = torch.tensor([22, 1, 9, 15, 3, 22])
+    me, te = enc.encode_motion(motion.cuda(), lengths), enc.encode_word_vectors(word.cuda(), pos.cuda(), sent)
+    e1, e2 = maxabs(me, TO.encode_motion(sd, motion, lengths)), maxabs(te, TO.encode_text(sd, word, pos, sent))
+    print(f't2m evaluator (shipped widths): |hip - oracle| motion {e1:.2e}, text {e2:.2e}')
+    assert e1 <= 1e-4 and e2 <= 1e-4
+    enc.close()

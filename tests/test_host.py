@@ -396,3 +396,18 @@ def test_clip_byte_pair_tokenizer_on_a_synthetic_merges_file(tmp_path):
     assert t[1, 0] == bpe.sot and t[1, -1] == bpe.eot and (t[1, 1:-1] == bpe.ids['run</w>']).all()
     with pytest.raises(RuntimeError):
         bpe.tokenize(['run ' * 100], context_length=8, truncate=False)
+
+
+def test_t2m_token_vectorisation_layout():
+    """T2MTextEncoder.forward's host part (t2m_bigru.py:131-165): sos / eos / unk padding and truncation at max_text_len."""
+    from motioncraft_amd.evaluation import vectorize_tokens
+
+    class Lookup:
+        def __getitem__(self, item):
+            word, pos = item.split('/')
+            return np.full(4, float(len(word))), np.eye(3)[0 if pos == 'OTHER' else 1]
+    w, p, n = vectorize_tokens(['walk/VERB fast/ADV', ' '.join(['a/DET'] * 7)], Lookup(), max_text_len=5)
+    assert w.shape == (2, 7, 4) and p.shape == (2, 7, 3) and n.tolist() == [4, 7]
+    assert w[0, :, 0].tolist() == [3, 4, 4, 3, 3, 3, 3]            # sos walk fast eos unk unk unk
+    assert w[1, :, 0].tolist() == [3, 1, 1, 1, 1, 1, 3]            # sos + 5 kept + eos
+    assert p[0, 1].tolist() == [0, 1, 0] and p[0, 0].tolist() == [1, 0, 0]

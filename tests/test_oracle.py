@@ -196,3 +196,14 @@ def test_evaluation_encoders_against_reference_golden():
     m2 = T_(g['motion']).clone()
     m2[2, 9:] = 123.0
     assert torch.equal(EO.encode_motion(sd, m2, g['lengths'].tolist(), EVAL_DIMS['num_layers'], EVAL_DIMS['num_heads'])[2], om[2])
+
+
+def test_t2m_evaluator_against_reference_golden():
+    """HumanML3D / KIT evaluator (t2m_bigru.py): explicit-loop GRU restatement vs the reference modules' outputs."""
+    from oracle import t2m_eval_oracle as TO
+    from helpers import T2M_DIMS, T2M_TEXT
+    g = load('t2m_evaluator.npz')
+    sd = W.make_t2m_eval_state(W.t2m_eval_param_shapes(**T2M_DIMS, **T2M_TEXT), seed=int(g['seed']))
+    om = TO.encode_motion(sd, T_(g['motion']), torch.from_numpy(g['lengths']))
+    ot = TO.encode_text(sd, T_(g['word_emb']), T_(g['pos_onehot']), torch.from_numpy(g['sent_len']))
+    assert maxabs(om, T_(g['motion_emb'])) <= 1e-5 and maxabs(ot, T_(g['text_emb'])) <= 1e-5

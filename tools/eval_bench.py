@@ -34,3 +34,21 @@ for name, fn, fl in (('encode_motion', lambda: enc.encode_motion(motion, lengths
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f'{name} B={B} (T={T} / S={S}): {ms:.3f} ms/batch -> {B / ms * 1e3:.0f} samples/s, {fl / ms / 1e9:.1f} TFLOP/s')
+
+# HumanML3D / KIT evaluator (T2MContrastiveModel) at the shipped widths
+from motioncraft_amd.evaluation import NativeT2MEvaluator
+from motioncraft_amd.synthetic import make_t2m_eval_state, t2m_eval_param_shapes
+t2m = NativeT2MEvaluator(make_t2m_eval_state(t2m_eval_param_shapes(), seed=0))
+m263 = torch.randn(B, T, 263, device='cuda')
+word = torch.randn(B, 22, 300, device='cuda')
+pos = torch.nn.functional.one_hot(torch.randint(0, 15, (B, 22), device='cuda'), 15).float()
+sent = torch.randint(3, 23, (B,), device='cuda', dtype=torch.int32)
+for name, fn in (('t2m encode_motion', lambda: t2m.encode_motion(m263, lengths)), ('t2m encode_text', lambda: t2m.encode_word_vectors(word, pos, sent))):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f'{name} B={B}: {ms:.3f} ms/batch -> {B / ms * 1e3:.0f} samples/s')
