@@ -64,6 +64,11 @@ struct RowChainArgs {
     int L = 0, Nout = 0;
     long twin_from = 0;            // kind 0: tokens >= twin_from (> 0) read the expert outputs of token - twin_from
     TwinAlias alias;               // tokens >= alias.from are neither computed nor stored while *alias.split_flag == 0
+    // projqkv (kind 0 followed by kind 1 on the first L output columns, in one kernel): the second weight stream
+    const float* W2 = nullptr;     // [3L][L]
+    const float* bias2 = nullptr;
+    float* Y2 = nullptr;           // [N][ldy2]
+    long ldy2 = 0;
 };
 
 bool mc_chain_enabled(int which);   // 0: fused mlp, 1: gate, 2: rowchain (proj, qkv)   (env MC_CHAIN bitmask, default all)
@@ -71,3 +76,4 @@ bool mc_mlp_supported(int L, int hidden);
 int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStream_t s);
 int mc_launch_gate(const GateArgs& g, hipStream_t s);
 int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s);   // 0: combine+GELU+proj, 1: LN+linear
+int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s);              // both in one pass (gamma/beta = the LayerNorm of kind 1)

@@ -436,7 +436,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 1015;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers
+        v = e ? atoi(e) : 2039;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches)
     }
     return v;
 }
@@ -485,6 +485,95 @@ int mc_launch_gate(const GateArgs& g, hipStream_t s) {
         case 64: hipLaunchKernelGGL(gate_k<64>, grid, dim3(256), 0, s, g); break;
         case 32: hipLaunchKernelGGL(gate_k<32>, grid, dim3(256), 0, s, g); break;
         default: mc_set_error("gate: L=%d unsupported", g.L); return MC_ERR_ARG;
+    }
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+// =================================================================================================
+// projqkv_k: rowchain_k<0> and rowchain_k<1> in one pass.  The first L output columns of the projection
+// (body_value) are exactly the row fragment the q/k/v GEMM needs: they stay in VGPRs, get the shared
+// LayerNorm in fragment layout and become the B operand of the second weight stream -- body_value is
+// never re-read from HBM and the 12 q/k/v chunks share the tile prologue of the 16 projection chunks.
+// =================================================================================================
+template <int L>
+__global__ __launch_bounds__(256, 2) void projqkv_k(RowChainArgs g) {
+    constexpr int NJ = L / 8, NC0 = 4 * L / 32, NC1 = 3 * L / 32, NKEEP = L / 32;
+    using SP = ChunkStage<32, L>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 7 * L];
+    auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
+    float* s_bias = smem + 2 * 32 * SP::LDS_LD;      // proj bias [4L] | qkv bias [3L]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
+    for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
+    const long tok = g.tok0 + (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
+    if (aliasing && g.tok0 + (long)blockIdx.x * 128 >= g.alias.from) return;
+    const bool rok = tok < g.N && !(aliasing && tok >= g.alias.from);
+    const int kq = (lane >> 5) * 4;
+    SP sp;
+    // global chunk cg: 0 .. NC0-1 = projection rows, NC0 .. NC0+NC1-1 = q/k/v rows
+    auto fetch = [&](int cg) {
+        if (cg < NC0) sp.fetch(g.W, L, cg * 32, 0, tid);
+        else sp.fetch(g.W2, L, (cg - NC0) * 32, 0, tid);
+    };
+    fetch(0);
+    f32x4 xf[NJ];
+    {
+        const long tk = tok < g.N ? tok : 0;
+        const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
+        const long ty = (g.twin_from > 0 && tk >= g.twin_from) ? tk - g.twin_from : tk;
+        const float* y0 = g.X + 2 * ty * L + kq;
+        f32x4 ya[NJ], yb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            ya[j] = *reinterpret_cast<const f32x4*>(y0 + 8 * j);
+            yb[j] = *reinterpret_cast<const f32x4*>(y0 + L + 8 * j);
+        }
+        const bool k0 = w0 != 0.f, k1 = w1 != 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[j][i] = gelu_exact((k0 ? w0 * ya[j][i] : 0.f) + (k1 ? w1 * yb[j][i] : 0.f));
+    }
+    sp.commit(Ws(0), tid);
+    fetch(1);
+    __syncthreads();
+    float* orow = g.Y + tok * g.ldy + kq;
+    f32x4 bvf[NJ];                                   // body_value fragment = k-groups 4c + q of output chunks c < L/32
+    // one chunk: MFMAs -> commit(next) -> bias + stores -> fetch(next + 1)   (order: see rowchain_k)
+#define MC_PQ_CHUNK(cg, XF, OUT, BIAS0, KEEP)                                                              \
+    {                                                                                                      \
+        const f32x16 a = chunk_mma<NJ>(Ws((cg) & 1), XF, lane);                                           \
+        if ((cg) + 1 < NC0 + NC1) sp.commit(Ws(((cg) & 1) ^ 1), tid);                                     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + (BIAS0) + 8 * q + kq);              \
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]}; \
+            if (rok) *reinterpret_cast<f32x4*>((OUT) + 8 * q) = v;                                        \
+            KEEP                                                                                           \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if ((cg) + 2 < NC0 + NC1) fetch((cg) + 2);                                                         \
+        __syncthreads();                                                                                   \
+    }
+#pragma unroll
+    for (int c = 0; c < NKEEP; ++c) MC_PQ_CHUNK(c, xf, orow + c * 32, c * 32, bvf[4 * c + q] = v;)
+    for (int c = NKEEP; c < NC0; ++c) MC_PQ_CHUNK(c, xf, orow + c * 32, c * 32, )
+    frag_layernorm<NJ>(bvf, g.gamma, g.beta, kq);
+    float* qrow = g.Y2 + tok * g.ldy2 + kq;
+    for (int c = 0; c < NC1; ++c) MC_PQ_CHUNK(NC0 + c, bvf, qrow + c * 32, 4 * L + c * 32, )
+#undef MC_PQ_CHUNK
+}
+
+int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
+    MC_REQUIRE(g.Nout == 4 * g.L && g.ldy % 4 == 0 && g.ldy2 % 4 == 0 && g.W2 && g.bias2 && g.Y2, "projqkv: bad arguments");
+    if (g.N <= g.tok0) return MC_OK;
+    dim3 grid(cdiv(g.N - g.tok0, 128));
+    switch (g.L) {
+        case 128: hipLaunchKernelGGL(projqkv_k<128>, grid, dim3(256), 0, s, g); break;
+        case 64: hipLaunchKernelGGL(projqkv_k<64>, grid, dim3(256), 0, s, g); break;
+        case 32: hipLaunchKernelGGL(projqkv_k<32>, grid, dim3(256), 0, s, g); break;
+        default: mc_set_error("projqkv: L=%d unsupported", g.L); return MC_ERR_ARG;
     }
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -335,13 +335,19 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     const long tok0 = row0 * H, ntok = nrows * H;
     int r;
     // ---- post-score combine + GELU + MOE.proj -> mf [N][4L] ----
+    // large batches: proj + body LayerNorm + q/k/v as one kernel (small ones keep them apart: the temporal branch then
+    // starts on the side stream right after the projection)
+    const bool pq_fused = mc_chain_enabled(2) && mc_chain_enabled(10) && c->N > 65536 && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0;
     if (mc_chain_enabled(2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
         RowChainArgs p;
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.mm.proj_w; p.bias = w.mm.proj_b;
         p.Y = c->mf; p.ldy = 4 * L; p.tok0 = tok0; p.N = tok0 + ntok; p.L = L; p.Nout = 4 * L;
         p.twin_from = twin ? c->N / 2 : 0;
         p.alias = tok_alias;
-        if ((r = mc_launch_rowchain(0, p, s))) return r;
+        if (pq_fused) {       // + the dynamic body topology's shared LayerNorm and q/k/v on the body_value columns
+            p.gamma = w.dyn_g; p.beta = w.dyn_b; p.W2 = w.qkv_w; p.bias2 = w.qkv_b; p.Y2 = c->qkv; p.ldy2 = 3 * L;
+            if ((r = mc_launch_projqkv(p, s))) return r;
+        } else if ((r = mc_launch_rowchain(0, p, s))) return r;
     } else {
         GemmArgs p;
         p.A = c->y2 + 2 * tok0 * L; p.lda = L; p.comb_w = c->rb.comb_w + 2 * tok0;
@@ -359,7 +365,9 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         MC_HIP(hipEventRecord(c->ev_join, st));
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
-    if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
+    if (pq_fused) {
+        // q/k/v were produced by projqkv_k above
+    } else if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
         RowChainArgs q;
         q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
         q.Y = c->qkv; q.ldy = 3 * L; q.tok0 = tok0; q.N = tok0 + ntok; q.L = L; q.Nout = 3 * L;
