@@ -436,7 +436,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 2039;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches)
+        v = e ? atoi(e) : 4087;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel
     }
     return v;
 }

@@ -49,6 +49,7 @@ struct mc_ctx {
     std::vector<LayerW> lw;
     const float *enc_w, *enc_b, *seq_emb, *time_w0, *time_b0, *time_w2, *time_b2, *dec_w, *dec_b;
     const float *dec_wf = nullptr, *dec_bf = nullptr;   // decoder folded with the last StylizationBlock Linear (optional)
+    float *dec_cat_w = nullptr, *dec_cat_b = nullptr;   // [2][C][D] = dec_w | dec_wf and [2][C] = dec_bf | 0: the folded tail as ONE grouped GEMM
     const float *ctrl_in_w = nullptr, *ctrl_in_b = nullptr;
     int NLA = 0;                 // base + control layers (weights, text K/V and FiLM tables are per layer slot)
     float *hc = nullptr, *cb = nullptr, *cenc = nullptr;   // control stream, before_proj(c) [rows,D], forward_c(c) [B*T,D]
@@ -147,6 +148,13 @@ int bind_weights(mc_ctx* c) {
     if (m->params.count("dec.wf") && m->params.count("dec.bf")) {
         GP(c->dec_wf, "dec.wf", (int64_t)g.input_feats * D);
         GP(c->dec_bf, "dec.bf", g.input_feats);
+        const size_t wn = (size_t)g.input_feats * D, bn = (size_t)g.input_feats;
+        int rr;
+        if ((rr = ws_alloc(c, &c->dec_cat_w, 2 * wn)) != MC_OK || (rr = ws_alloc(c, &c->dec_cat_b, 2 * bn)) != MC_OK) return rr;
+        MC_HIP(hipMemcpy(c->dec_cat_w, c->dec_w, wn * sizeof(float), hipMemcpyDeviceToDevice));
+        MC_HIP(hipMemcpy(c->dec_cat_w + wn, c->dec_wf, wn * sizeof(float), hipMemcpyDeviceToDevice));
+        MC_HIP(hipMemcpy(c->dec_cat_b, c->dec_bf, bn * sizeof(float), hipMemcpyDeviceToDevice));
+        MC_HIP(hipMemset(c->dec_cat_b + bn, 0, bn * sizeof(float)));
     }
     c->NLA = g.num_layers + g.num_ctrl_layers;
     c->lw.resize(c->NLA);
@@ -861,7 +869,9 @@ static SamplerCoefs to_coefs(const mc_step_coefs* k) {
 // The pose decoder is affine, so  w dec(h_text) + (1 - w) dec(h_none) = dec(w h_text + (1 - w) h_none):  the sampler
 // entry points combine the two CFG halves of the residual stream first and decode B*T rows instead of 2*B*T
 // (mc_denoise, which hands out both decoded halves, keeps the reference's order).
-static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, void* stream, const float** x0c) {
+// -> x0 = *x0a (+ *x0b when it is not null: the two partial products of the folded tail, summed by the sampler kernel)
+static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, void* stream, const float** x0a,
+                            const float** x0b) {
     const mc_model_config& g = c->m->cfg;
     // ... and so is the Linear of the very last StylizationBlock (h += a W^T + b): it, too, runs once on the combined
     // rows  h_c = comb(h) + comb(a) W^T + b  instead of on both halves.
@@ -874,46 +884,60 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
     const int D = g.latent_dim * g.num_parts, C = g.input_feats;
     const long BT = (long)c->B * c->T;
     const LayerW& w = c->lw[g.num_layers - 1];
+    *x0b = nullptr;
     if ((r = mc_launch_axpby(c->h, c->h + BT * D, k->text_coef, k->none_coef, c->z2, BT * D, s))) return r;     // h_c
     if (defer) {
+        if (c->dec_cat_w && mc_chain_enabled(11)) {
+            // ... and that Linear composed with the decoder is one [C, D] matrix (folded at pack time):
+            //   x0 = [dec(h_c) + Wd b] + [a_c (Wd W)^T]
+            // the two skinny products (N = C = 322: 294 tiles each, half a chip) are the two groups of ONE grouped GEMM
+            // over (h_c | a_c) x (Wd | Wd W); the sampler kernel adds the two partial outputs
+            if ((r = mc_launch_axpby(c->a, c->a + BT * D, k->text_coef, k->none_coef, c->z2 + BT * D, BT * D, s))) return r;      // a_c
+            GemmArgs t;
+            t.A = c->z2; t.lda = D; t.a_gstride = BT * D; t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D;
+            t.bias = c->dec_cat_b; t.b_gstride = C; t.C = c->out2; t.ldc = C; t.c_gstride = BT * C;
+            t.M = (int)BT; t.N = C; t.K = D;
+            if ((r = mc_launch_gemm(GM_PLAIN, t, 2, 0, s))) return r;
+            *x0a = c->out2;
+            *x0b = c->out2 + BT * C;
+            return MC_OK;
+        }
         if ((r = mc_launch_axpby(c->a, c->a + BT * D, k->text_coef, k->none_coef, c->a, BT * D, s))) return r;      // a_c
         if (c->dec_wf) {
-            // ... and that Linear composed with the decoder is one [C, D] matrix (folded at pack time):
-            // x0 = dec(h_c) + a_c (Wd W)^T + Wd b  -- two skinny GEMMs instead of a 1536^2 one plus the decoder
             if ((r = dense(c->z2, D, c->dec_w, D, c->dec_bf, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
             if ((r = dense(c->a, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
-            *x0c = c->out2;
+            *x0a = c->out2;
             return MC_OK;
         }
         if ((r = dense(c->a, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
     }
     if ((r = dense(c->z2, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
-    *x0c = c->out2;
+    *x0a = c->out2;
     return MC_OK;
 }
 
-static SamplerCoefs combined_coefs(const mc_step_coefs* k) {
+static SamplerCoefs combined_coefs(const mc_step_coefs* k, bool two_parts) {
     SamplerCoefs sc = to_coefs(k);
-    sc.text_coef = 1.f;                  // x0 is already the CFG-combined prediction
-    sc.none_coef = 0.f;
+    sc.text_coef = 1.f;                  // x0 is already the CFG-combined prediction ...
+    sc.none_coef = two_parts ? 1.f : 0.f;   // ... or the sum of its two partial products
     return sc;
 }
 
 int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
                    float* x_prev, float* x0, void* stream) {
     MC_REQUIRE(c && x_t && k && noise && x_prev, "null argument");
-    const float* x0c = nullptr;
-    int r = denoise_combined(c, x_t, step, k, stream, &x0c);
+    const float *x0a = nullptr, *x0b = nullptr;
+    int r = denoise_combined(c, x_t, step, k, stream, &x0a, &x0b);
     if (r != MC_OK) return r;
     const long n = (long)c->B * c->T * c->m->cfg.input_feats;
-    return mc_launch_sampler_update(x_t, x0c, x0c, noise, x_prev, x0, n, combined_coefs(k), (hipStream_t)stream);
+    return mc_launch_sampler_update(x_t, x0a, x0b ? x0b : x0a, noise, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream);
 }
 
 int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
                            const mc_inpaint* ip, float* x_prev, float* x0, void* stream) {
     MC_REQUIRE(c && x_t && k && noise && x_prev && ip, "null argument");
-    const float* x0c = nullptr;
-    int r = denoise_combined(c, x_t, step, k, stream, &x0c);
+    const float *x0a = nullptr, *x0b = nullptr;
+    int r = denoise_combined(c, x_t, step, k, stream, &x0a, &x0b);
     if (r != MC_OK) return r;
     const int C = c->m->cfg.input_feats;
     const long n = (long)c->B * c->T * C;
@@ -921,7 +945,7 @@ int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_s
     a.gt = ip->gt_dev; a.keep = ip->keep_dev; a.gt_noise = ip->gt_noise_dev; a.blend_w = ip->blend_w_dev;
     a.blend_len = ip->blend_len; a.T = c->T; a.C = C;
     MC_REQUIRE(a.blend_len >= 0 && a.blend_len <= c->T, "blend_len %d outside the %d-frame window", a.blend_len, c->T);
-    return mc_launch_sampler_inpaint(x_t, x0c, x0c, noise, a, x_prev, x0, n, combined_coefs(k), (hipStream_t)stream);
+    return mc_launch_sampler_inpaint(x_t, x0a, x0b ? x0b : x0a, noise, a, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream);
 }
 
 int mc_postprocess_smplx(const float* pred, const int32_t* lengths, const double* mean, const double* stdv,
