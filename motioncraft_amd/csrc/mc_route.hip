@@ -15,6 +15,7 @@
 // no host sync, graph-capturable.
 #include "mc_common.h"
 #include "mc_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -309,7 +310,149 @@ __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Small batches (a few thousand tokens): the whole routing step -- problem setup, the 8 radix passes with their picks,
+// keep / combine weights, slot ranges + tile map, compaction -- as ONE workgroup instead of 12 launches of a few
+// microseconds of work each.  Same state block, same decisions (integer arithmetic on the same composite keys).
+// ---------------------------------------------------------------------------------------
+constexpr int SMALL_THREADS = 1024;
+__global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __restrict__ idx, const float* __restrict__ gate,
+                                                              const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
+                                                              int E, int capacity, int cnt_mul, float* __restrict__ comb_w,
+                                                              int* __restrict__ state, int* __restrict__ src_row,
+                                                              int* __restrict__ dst_row, int* __restrict__ tile_group,
+                                                              int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
+    __shared__ int h[MAXP * 256];
+    __shared__ int s_act[MAXP], s_rank[MAXP];
+    __shared__ unsigned long long s_pre[MAXP];
+    __shared__ int s_kept[2 * MAXE], s_fill[2 * MAXE], s_off[2 * MAXE + 1], s_t0[2][MAXE + 1];
+    __shared__ int s_any, s_split;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_any = 0; s_split = 0; }
+    if (tid < 2 * MAXE) { s_kept[tid] = 0; s_fill[tid] = 0; }
+    __syncthreads();
+    if (tid < MAXP) {                                            // problem setup (route_init_k)
+        const int choice = tid / MAXE, e = tid % MAXE;
+        int act = 0, rank = 0;
+        if (e < E) {
+            const int c0 = state[ST_CNT + e] * cnt_mul;
+            const int cnt = state[ST_CNT + tid] * cnt_mul;
+            const int limit = choice == 0 ? capacity : capacity - c0;
+            if (limit <= 0) act = cnt > 0 ? -1 : 0;
+            else if (cnt > limit) { act = 1; rank = limit; }
+        }
+        s_act[tid] = act;
+        s_rank[tid] = rank;
+        s_pre[tid] = 0ull;
+        if (act == 1) atomicOr(&s_any, 1);
+    }
+    __syncthreads();
+    if (s_any) {
+        for (int pass = 0; pass < 8; ++pass) {                   // radix select, one byte per pass (route_hist_k + pick)
+            for (int i = tid; i < MAXP * 256; i += SMALL_THREADS) h[i] = 0;
+            __syncthreads();
+            const int shift = 56 - 8 * pass;
+            for (long a = tid; a < 2 * N; a += SMALL_THREADS) {
+                const long tok = a >> 1;
+                const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+                const int p = (int)(a & 1) * MAXE + idx[2 * ts + (a & 1)];
+                if (s_act[p] != 1) continue;
+                const unsigned long long V = composite(key[ts], (uint32_t)tok);
+                if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
+                atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
+            }
+            __syncthreads();
+            for (int p = wave; p < MAXP; p += SMALL_THREADS / 64) {
+                if (s_act[p] != 1) continue;
+                int cb[4], t = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cb[j] = h[p * 256 + 4 * lane + j]; t += cb[j]; }
+                int suf = t;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_down(suf, o, 64);
+                    if (lane + o < 64) suf += v;
+                }
+                const int rank = s_rank[p];
+                int above = suf - t, found = -1, above_found = 0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int incl = above + cb[j];
+                    if (found < 0 && incl >= rank && above < rank) { found = 4 * lane + j; above_found = above; }
+                    above = incl;
+                }
+                if (found >= 0) {                                // exactly one lane finds the bin
+                    s_pre[p] = (s_pre[p] << 8) | (unsigned long long)found;
+                    s_rank[p] = rank - above_found;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (long a = tid; a < 2 * N; a += SMALL_THREADS) {           // keep / drop, combine weights, kept counts (route_keep_k)
+        const long tok = a >> 1;
+        const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+        const long as = 2 * ts + (a & 1);
+        const int e = idx[as];
+        const int p = (int)(a & 1) * MAXE + e;
+        bool keep = true;
+        if (s_act[p] == -1) keep = false;
+        else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok) >= s_pre[p];
+        comb_w[a] = keep ? gate[as] : 0.f;
+        if (tok >= Nsrc && s_act[p] == 1) {
+            const bool keep_orig = composite(key[ts], (uint32_t)ts) >= s_pre[p];
+            if (keep_orig != keep) s_split = 1;
+        }
+        if (keep && tok < Nsrc) atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {                                              // slot ranges + tile counts (route_plan_k)
+        int off = 0;
+        for (int g = 0; g < 2; ++g) {
+            int nt = 0;
+            for (int e = 0; e < E; ++e) {
+                s_off[g * MAXE + e] = off;
+                s_t0[g][e] = nt;
+                state[ST_OFF + g * MAXE + e] = off;
+                const int cnt = s_kept[g * MAXE + e];
+                off += cnt;
+                nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+            }
+            for (int e = E; e < MAXE; ++e) { s_off[g * MAXE + e] = off; state[ST_OFF + g * MAXE + e] = off; }
+            s_t0[g][E] = nt;
+            state[ST_NTILES + g] = min(nt, max_tiles);
+        }
+        s_off[2 * MAXE] = off;
+        state[ST_OFF + 2 * MAXE] = off;
+        state[ST_SPLIT] = s_split;
+        state[ST_DONE] = 0;
+    }
+    __syncthreads();
+    for (int g = 0; g < 2; ++g)
+        for (int e = 0; e < E; ++e) {
+            const int ve = g * MAXE + e, t1 = min(s_t0[g][e + 1], max_tiles);
+            for (int t = s_t0[g][e] + tid; t < t1; t += SMALL_THREADS) {
+                const int r = (t - s_t0[g][e]) * TILE_ROWS;
+                tile_group[g * max_tiles + t] = e;
+                tile_row0[g * max_tiles + t] = s_off[ve] + r;
+                tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+            }
+        }
+    for (long a = tid; a < 2 * Nsrc; a += SMALL_THREADS) {        // compaction (route_fill_k): a -> thread mapping as in the keep loop
+        if (comb_w[a] == 0.f) continue;
+        const int le = ((a >> 1) >= gsplit ? MAXE : 0) + idx[a];
+        const int slot = s_off[le] + atomicAdd(&s_fill[le], 1);
+        src_row[slot] = (int)(a >> 1);
+        dst_row[slot] = (int)a;
+    }
+}
+
 }  // namespace
+
+static long route_small_pairs() {
+    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); return e ? atol(e) : 32768L; }();
+    return v;
+}
 
 size_t mc_route_state_ints(int) { return ST_TOTAL; }
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
@@ -334,6 +477,13 @@ int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* lo
 // gsplit: tokens >= gsplit form slot group 1 (own slot ranges and tile map at [max_tiles, 2 max_tiles)); >= N: one group.
 int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBufs rb, hipStream_t s) {
     MC_REQUIRE(Nsrc == N || 2 * Nsrc == N, "route: Nsrc=%ld must be N or N/2 (N=%ld)", Nsrc, N);
+    if (2 * N <= route_small_pairs()) {
+        hipLaunchKernelGGL(route_small_k, dim3(1), dim3(SMALL_THREADS), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity,
+                           (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,
+                           rb.max_tiles);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
     hipLaunchKernelGGL(route_init_k, dim3(1), dim3(256), 0, s, rb.state, E, capacity, (int)(N / Nsrc));
     int blocks = cdiv(2 * N, 256 * 8);
     if (blocks > 1024) blocks = 1024;
