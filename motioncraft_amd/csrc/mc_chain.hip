@@ -378,8 +378,12 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     if (aliasing && g.tok0 + (long)blockIdx.x * 128 >= g.alias.from) return;
     const bool rok = tok < g.N && !(aliasing && tok >= g.alias.from);
     const int kq = (lane >> 5) * 4;
+    // output chunks [cs, ce) of this workgroup: all of them, or (small batches, gridDim.y > 1) one slice per blockIdx.y --
+    // the row fragment is rebuilt by every slice, the serial chunk chain gets gridDim.y times shorter
+    const int nc_all = g.Nout / 32;
+    const int cs = nc_all * (int)blockIdx.y / (int)gridDim.y, ce = nc_all * ((int)blockIdx.y + 1) / (int)gridDim.y;
     SP sp;
-    sp.fetch(g.W, L, 0, 0, tid);          // first weight chunk requested before the row loads: its latency hides behind them
+    sp.fetch(g.W, L, cs * 32, 0, tid);    // first weight chunk requested before the row loads: its latency hides behind them
     f32x4 xf[NJ];
     if constexpr (KIND == 0) {
         const long tk = tok < g.N ? tok : 0;
@@ -407,9 +411,8 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
         for (int j = 0; j < NJ; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
         frag_layernorm<NJ>(xf, g.gamma, g.beta, kq);
     }
-    const int nc = g.Nout / 32;
     sp.commit(Ws(0), tid);
-    if (nc > 1) sp.fetch(g.W, L, 32, 0, tid);
+    if (cs + 1 < ce) sp.fetch(g.W, L, (cs + 1) * 32, 0, tid);
     __syncthreads();
     float* orow = g.Y + tok * g.ldy + kq;
     // Order inside an iteration: MFMAs(c) -> commit(c+1) -> stores(c) -> fetch(c+2).  gfx9 counts loads and
@@ -417,9 +420,9 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     // loop-entry path too, so it always drains everything issued before the fetch it waits for.  With the fetch
     // issued AFTER the stores of the same iteration, what gets drained is one MFMA phase old (free); with the
     // fetch issued before them (the obvious order) every chunk stalls on the write latency of its own stores.
-    for (int c = 0; c < nc; ++c) {
-        const f32x16 a = chunk_mma<NJ>(Ws(c & 1), xf, lane);
-        if (c + 1 < nc) sp.commit(Ws((c & 1) ^ 1), tid);
+    for (int c = cs; c < ce; ++c) {
+        const f32x16 a = chunk_mma<NJ>(Ws((c - cs) & 1), xf, lane);
+        if (c + 1 < ce) sp.commit(Ws(((c - cs) & 1) ^ 1), tid);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + c * 32 + 8 * q + kq);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
             if (rok) *reinterpret_cast<f32x4*>(orow + c * 32 + 8 * q) = v;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < nc) sp.fetch(g.W, L, (c + 2) * 32, 0, tid);
+        if (c + 2 < ce) sp.fetch(g.W, L, (c + 2) * 32, 0, tid);
         __syncthreads();
     }
 }
@@ -579,10 +582,15 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
     return MC_OK;
 }
 
+static long rowchain_split_tokens() {
+    static const long v = [] { const char* e = getenv("MC_ROWCHAIN_SPLIT"); return e ? atol(e) : 20480L; }();
+    return v;
+}
+
 int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s) {
     MC_REQUIRE(g.Nout % 32 == 0 && g.ldy % 4 == 0, "rowchain: Nout=%d / ldy unsupported", g.Nout);
     if (g.N <= g.tok0) return MC_OK;
-    dim3 grid(cdiv(g.N - g.tok0, 128));
+    dim3 grid(cdiv(g.N - g.tok0, 128), (g.N - g.tok0 <= rowchain_split_tokens() && (g.Nout / 32) % 4 == 0) ? 4 : 1);
 #define MC_RC_CASE(LL)                                                                    \
     case LL:                                                                              \
         if (kind == 0) hipLaunchKernelGGL((rowchain_k<LL, 0>), grid, dim3(256), 0, s, g);  \
