@@ -222,7 +222,8 @@ int dense_splitk(const float* A, const float* W, const float* bias, const float*
                  float* ws, size_t ws_floats, hipStream_t s) {
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
     int S = 1;
-    while (S < 8 && tiles * (S * 2) <= 512 && K % (S * 2 * 32) == 0 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
+    // (up to two rounds of the 512 workgroup slots: measured better than stopping at one, B=4 -4.5 %)
+    while (S < 8 && tiles * (S * 2) <= 1024 && K % (S * 2 * 32) == 0 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
     if (S == 1) return dense(A, K, W, K, bias, R, N, C, N, M, N, K, ACT_NONE, s);
     GemmArgs g;
     g.A = A; g.lda = K; g.a_gstride = K / S;          // split s reads columns [s K/S, (s+1) K/S) of A and of W
