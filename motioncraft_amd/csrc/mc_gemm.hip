@@ -407,6 +407,71 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_k(GemmArgs g) {
     else epilogue_vec<GM_PLAIN, false, ACT_LRELU>(g, 0, row0, BM, tn, wm, wn, lane, acc);
 }
 
+// ---------------------------------------------------------------------------------------
+// Small-M variant (latency-bound launches of a few hundred rows): 64 x 64 tiles, each wave one 32 x 32 MFMA tile, so
+// the serial MFMA chain per k-tile is 16 instead of 64 instructions and a K = 1536 product takes ~30 us instead of
+// ~105 us per tile; 4x more workgroups fill the chip without splitting K (no partial sums, no reduction pass).
+// C = A W^T + bias + R, fp32, lda / ldw / ldc / ldr % 4 == 0, N % 64 == 0, K % 32 == 0.
+// ---------------------------------------------------------------------------------------
+constexpr int SM = 64, SN = 64;
+__global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][SM][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SN][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = g.N / SN;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    const int row0 = tm * SM;
+    // staging: thread -> (row sr, 16-byte chunk sc) of the 64 x 32 slabs, two rows 32 apart each for A and W
+    const int sr = tid >> 3, sc = (tid & 7) * 4;
+    const int ar0 = min(row0 + sr, g.M - 1), ar1 = min(row0 + sr + 32, g.M - 1);      // rows past M re-read the last row (never stored)
+    const float* a0 = g.A + (long)ar0 * g.lda + g.a_col + sc;
+    const float* a1 = g.A + (long)ar1 * g.lda + g.a_col + sc;
+    const float* w0 = g.W + (long)(tn * SN + sr) * g.ldw + sc;
+    const float* w1 = w0 + (long)32 * g.ldw;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = g.K / BK;
+    f32x4 ra0 = *reinterpret_cast<const f32x4*>(a0), ra1 = *reinterpret_cast<const f32x4*>(a1);
+    f32x4 rw0 = *reinterpret_cast<const f32x4*>(w0), rw1 = *reinterpret_cast<const f32x4*>(w1);
+    const int frow = lane & 31, hf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        *reinterpret_cast<f32x4*>(&As[buf][sr][sc]) = ra0;
+        *reinterpret_cast<f32x4*>(&As[buf][sr + 32][sc]) = ra1;
+        *reinterpret_cast<f32x4*>(&Bs[buf][sr][sc]) = rw0;
+        *reinterpret_cast<f32x4*>(&Bs[buf][sr + 32][sc]) = rw1;
+        if (kt + 1 < nk) {
+            const int ko = (kt + 1) * BK;
+            ra0 = *reinterpret_cast<const f32x4*>(a0 + ko); ra1 = *reinterpret_cast<const f32x4*>(a1 + ko);
+            rw0 = *reinterpret_cast<const f32x4*>(w0 + ko); rw1 = *reinterpret_cast<const f32x4*>(w1 + ko);
+        }
+        __syncthreads();                          // one barrier per k-tile: the other buffer was last read two tiles ago
+        const float* At = &As[buf][wm * 32 + frow][0];
+        const float* Bt = &Bs[buf][wn * 32 + frow][0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(At + (2 * j + hf) * 4);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(Bt + (2 * j + hf) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[i], fa[i], acc, 0, 0, 0);
+        }
+    }
+    const int m = row0 + wm * 32 + frow;
+    if (m >= g.M) return;
+    float* crow = g.C + (long)m * g.ldc + g.c_col;
+    const float* rrow = g.R ? g.R + (long)m * g.ldr + g.c_col : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = tn * SN + wn * 32 + 8 * q + 4 * hf;
+        f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+        if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+        *reinterpret_cast<f32x4*>(crow + n) = v;
+    }
+}
+
 }  // namespace
 
 static int tune_bits() {
@@ -416,6 +481,16 @@ static int tune_bits() {
         v = e ? atoi(e) : 17;
     }
     return v;
+}
+
+int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
+    MC_REQUIRE(g.N % SN == 0 && g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.ldc % 4 == 0 && g.a_col % 4 == 0 && g.c_col % 4 == 0 &&
+                   (!g.R || g.ldr % 4 == 0) && g.act == ACT_NONE && !g.add && !g.dup_rows,
+               "gemm_small: unsupported shape / options (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    if (g.M <= 0) return MC_OK;
+    hipLaunchKernelGGL(gemm_small_k, dim3(cdiv(g.M, SM) * (g.N / SN)), dim3(256), 0, stream, g);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
 }
 
 int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipStream_t stream) {

@@ -310,6 +310,11 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     return mc_launch_gemm(GM_COMB, p, 1, 0, s);
 }
 
+static long small_gemm_rows() {
+    static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 5120L; }();
+    return v;
+}
+
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
@@ -320,6 +325,12 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
+    if (nrows <= small_gemm_rows() && D % 64 == 0) {     // up to a few thousand rows: 64 x 64 tiles, short MFMA chains, no K split (B=8: -11 % per step)
+        GemmArgs q;
+        q.A = c->a + o; q.lda = D; q.W = out_w; q.ldw = D; q.bias = out_b; q.R = hs + o; q.ldr = D; q.C = hs + o; q.ldc = D;
+        q.M = (int)nrows; q.N = D; q.K = D;
+        return mc_launch_gemm_small(q, s);
+    }
     if (nrows <= 2048 && c->hbuf_floats)       // few output tiles: split K (hbuf is free scratch on the fused path)
         return dense_splitk(c->a + o, out_w, out_b, hs + o, hs + o, nrows, D, D, c->hbuf, c->hbuf_floats, s);
     return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
