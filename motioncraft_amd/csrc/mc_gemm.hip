@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_k(GemmArgs g) {
 // Small-M variant (latency-bound launches of a few hundred rows): 64 x 64 tiles, each wave one 32 x 32 MFMA tile, so
 // the serial MFMA chain per k-tile is 16 instead of 64 instructions and a K = 1536 product takes ~30 us instead of
 // ~105 us per tile; 4x more workgroups fill the chip without splitting K (no partial sums, no reduction pass).
-// C = A W^T + bias + R, fp32, lda / ldw / ldc / ldr % 4 == 0, N % 64 == 0, K % 32 == 0.
+// C = A W^T + bias (+ add[(r % add_mod)]) + R (also written dup_rows below), fp32, lda / ldw / ldc / ldr % 4 == 0,
+// N % 64 == 0, K % 32 == 0.
 // ---------------------------------------------------------------------------------------
 constexpr int SM = 64, SN = 64;
 __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
@@ -462,13 +463,16 @@ __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
     if (m >= g.M) return;
     float* crow = g.C + (long)m * g.ldc + g.c_col;
     const float* rrow = g.R ? g.R + (long)m * g.ldr + g.c_col : nullptr;
+    const float* arow = g.add ? g.add + (long)(m % g.add_mod) * g.ld_add : nullptr;      // row-periodic table (pose encoder)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = tn * SN + wn * 32 + 8 * q + 4 * hf;
         f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+        if (arow) v += *reinterpret_cast<const f32x4*>(arow + n);
         if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
         *reinterpret_cast<f32x4*>(crow + n) = v;
+        if (g.dup_rows) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
     }
 }
 
@@ -485,7 +489,7 @@ static int tune_bits() {
 
 int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
     MC_REQUIRE(g.N % SN == 0 && g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.ldc % 4 == 0 && g.a_col % 4 == 0 && g.c_col % 4 == 0 &&
-                   (!g.R || g.ldr % 4 == 0) && g.act == ACT_NONE && !g.add && !g.dup_rows,
+                   (!g.R || g.ldr % 4 == 0) && g.act == ACT_NONE && (!g.add || g.ld_add % 4 == 0),
                "gemm_small: unsupported shape / options (M=%d N=%d K=%d)", g.M, g.N, g.K);
     if (g.M <= 0) return MC_OK;
     hipLaunchKernelGGL(gemm_small_k, dim3(cdiv(g.M, SM) * (g.N / SN)), dim3(256), 0, stream, g);

@@ -827,7 +827,8 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
         e.add = c->seq_emb; e.add_mod = c->T; e.ld_add = D;
         e.C = c->h; e.ldc = D; e.dup_rows = BT;
         e.M = (int)BT; e.N = D; e.K = c->m->Cp;
-        if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
+        if (BT <= small_gemm_rows() && D % 64 == 0 && c->m->Cp % 32 == 0) { if ((r = mc_launch_gemm_small(e, s))) return r; }
+        else if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
     c->no_alias = stop_after >= 0 && stop_after < g.num_layers;
