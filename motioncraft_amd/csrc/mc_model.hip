@@ -207,11 +207,19 @@ int bind_weights(mc_ctx* c) {
     return MC_OK;
 }
 
+static long small_gemm_rows() {
+    static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 5120L; }();
+    return v;
+}
+
 int dense(const float* A, long lda, const float* W, long ldw, const float* bias, const float* R, long ldr,
           float* C, long ldc, long M, int N, int K, int act, hipStream_t s) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R = R; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
+    if (M <= small_gemm_rows() && act == ACT_NONE && N % 64 == 0 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 &&
+        (!R || ldr % 4 == 0))
+        return mc_launch_gemm_small(g, s);          // latency-bound sizes: 64 x 64 tiles (see gemm_small_k)
     return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
 }
 
@@ -308,11 +316,6 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     p.W = w.proj_w; p.ldw = din; p.bias = w.proj_b;
     p.C = out; p.ldc = ldout; p.M = (int)Ntok; p.N = w.dout; p.K = din;
     return mc_launch_gemm(GM_COMB, p, 1, 0, s);
-}
-
-static long small_gemm_rows() {
-    static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 5120L; }();
-    return v;
 }
 
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
