@@ -43,5 +43,6 @@ struct GemmArgs {
 };
 
 int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream);
-// small-M plain GEMM (64 x 64 tiles, one MFMA tile per wave): C = A W^T + bias + R, N % 64 == 0, K % 32 == 0
-int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream);
+// small-M plain GEMM (64 x 64 tiles, one MFMA tile per wave): C = A W^T + bias (+ add) + R, K % 32 == 0; any N (guarded scalar
+// epilogue when rows are not 16-byte aligned); `groups` as in mc_launch_gemm (the *_gstride fields)
+int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups = 1);

@@ -415,21 +415,25 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_k(GemmArgs g) {
 // N % 64 == 0, K % 32 == 0.
 // ---------------------------------------------------------------------------------------
 constexpr int SM = 64, SN = 64;
+template <bool VEC>     // VEC: N % 64 == 0 and 16-byte aligned output rows (float4 epilogue); else guarded scalar stores
 __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][SM][LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][SN][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = g.N / SN;
-    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    const int ntn = (g.N + SN - 1) / SN;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn, grp = blockIdx.y;
     const int row0 = tm * SM;
     // staging: thread -> (row sr, 16-byte chunk sc) of the 64 x 32 slabs, two rows 32 apart each for A and W
     const int sr = tid >> 3, sc = (tid & 7) * 4;
-    const int ar0 = min(row0 + sr, g.M - 1), ar1 = min(row0 + sr + 32, g.M - 1);      // rows past M re-read the last row (never stored)
-    const float* a0 = g.A + (long)ar0 * g.lda + g.a_col + sc;
-    const float* a1 = g.A + (long)ar1 * g.lda + g.a_col + sc;
-    const float* w0 = g.W + (long)(tn * SN + sr) * g.ldw + sc;
-    const float* w1 = w0 + (long)32 * g.ldw;
+    const int ar0 = min(row0 + sr, g.M - 1), ar1 = min(row0 + sr + 32, g.M - 1);      // rows past M / N re-read the last row (never stored)
+    const int wr0 = min(tn * SN + sr, g.N - 1), wr1 = min(tn * SN + sr + 32, g.N - 1);
+    const float* Ab = g.A + (long)grp * g.a_gstride + g.a_col + sc;
+    const float* Wb = g.W + (long)grp * g.w_gstride + sc;
+    const float* a0 = Ab + (long)ar0 * g.lda;
+    const float* a1 = Ab + (long)ar1 * g.lda;
+    const float* w0 = Wb + (long)wr0 * g.ldw;
+    const float* w1 = Wb + (long)wr1 * g.ldw;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -461,18 +465,33 @@ __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
     }
     const int m = row0 + wm * 32 + frow;
     if (m >= g.M) return;
-    float* crow = g.C + (long)m * g.ldc + g.c_col;
-    const float* rrow = g.R ? g.R + (long)m * g.ldr + g.c_col : nullptr;
+    float* crow = g.C + (long)grp * g.c_gstride + (long)m * g.ldc + g.c_col;
+    const long rgs = g.r_gstride >= 0 ? g.r_gstride : g.c_gstride;
+    const float* rrow = g.R ? g.R + (long)grp * rgs + (long)m * g.ldr + g.c_col : nullptr;
     const float* arow = g.add ? g.add + (long)(m % g.add_mod) * g.ld_add : nullptr;      // row-periodic table (pose encoder)
+    const float* bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = tn * SN + wn * 32 + 8 * q + 4 * hf;
         f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-        if (arow) v += *reinterpret_cast<const f32x4*>(arow + n);
-        if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
-        *reinterpret_cast<f32x4*>(crow + n) = v;
-        if (g.dup_rows) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
+        if constexpr (VEC) {
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+            if (arow) v += *reinterpret_cast<const f32x4*>(arow + n);
+            if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+            *reinterpret_cast<f32x4*>(crow + n) = v;
+            if (g.dup_rows) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (n + i >= g.N) continue;
+                float x = v[i];
+                if (bias) x += bias[n + i];
+                if (arow) x += arow[n + i];
+                if (rrow) x += rrow[n + i];
+                crow[n + i] = x;
+                if (g.dup_rows) crow[g.dup_rows * g.ldc + n + i] = x;
+            }
+        }
     }
 }
 
@@ -487,12 +506,16 @@ static int tune_bits() {
     return v;
 }
 
-int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
-    MC_REQUIRE(g.N % SN == 0 && g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.ldc % 4 == 0 && g.a_col % 4 == 0 && g.c_col % 4 == 0 &&
-                   (!g.R || g.ldr % 4 == 0) && g.act == ACT_NONE && (!g.add || g.ld_add % 4 == 0),
+int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
+    MC_REQUIRE(g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.a_col % 4 == 0 && g.a_gstride % 4 == 0 && g.w_gstride % 4 == 0 &&
+                   g.act == ACT_NONE,
                "gemm_small: unsupported shape / options (M=%d N=%d K=%d)", g.M, g.N, g.K);
-    if (g.M <= 0) return MC_OK;
-    hipLaunchKernelGGL(gemm_small_k, dim3(cdiv(g.M, SM) * (g.N / SN)), dim3(256), 0, stream, g);
+    if (g.M <= 0 || g.N <= 0) return MC_OK;
+    const bool vec = g.N % SN == 0 && g.ldc % 4 == 0 && g.c_col % 4 == 0 && g.c_gstride % 4 == 0 && (!g.R || (g.ldr % 4 == 0 && (g.r_gstride < 0 || g.r_gstride % 4 == 0))) &&
+                     (!g.add || g.ld_add % 4 == 0) && g.b_gstride % 4 == 0;
+    dim3 grid(cdiv(g.M, SM) * cdiv(g.N, SN), groups > 0 ? groups : 1);
+    if (vec) hipLaunchKernelGGL(gemm_small_k<true>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(gemm_small_k<false>, grid, dim3(256), 0, stream, g);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -217,8 +217,7 @@ int dense(const float* A, long lda, const float* W, long ldw, const float* bias,
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R = R; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
-    if (M <= small_gemm_rows() && act == ACT_NONE && N % 64 == 0 && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 &&
-        (!R || ldr % 4 == 0))
+    if (M <= small_gemm_rows() && act == ACT_NONE && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0)
         return mc_launch_gemm_small(g, s);          // latency-bound sizes: 64 x 64 tiles (see gemm_small_k)
     return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
 }
@@ -913,7 +912,8 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
             t.A = c->z2; t.lda = D; t.a_gstride = BT * D; t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D;
             t.bias = c->dec_cat_b; t.b_gstride = C; t.C = c->out2; t.ldc = C; t.c_gstride = BT * C;
             t.M = (int)BT; t.N = C; t.K = D;
-            if ((r = mc_launch_gemm(GM_PLAIN, t, 2, 0, s))) return r;
+            if (BT <= small_gemm_rows() && D % 32 == 0) { if ((r = mc_launch_gemm_small(t, s, 2))) return r; }
+            else if ((r = mc_launch_gemm(GM_PLAIN, t, 2, 0, s))) return r;
             *x0a = c->out2;
             *x0b = c->out2 + BT * C;
             return MC_OK;
