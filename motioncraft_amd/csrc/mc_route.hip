@@ -349,6 +349,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
     __syncthreads();
     if (s_any) {
         for (int pass = 0; pass < 8; ++pass) {                   // radix select, one byte per pass (route_hist_k + pick)
+            if (pass == 4 || pass == 5) {
+                // token indices are < 2^16 here (<= 32768 pairs), so the two upper bytes of ~token are 0xFF for every key:
+                // the pass cannot split the candidates, append the byte and go on (rank unchanged)
+                if (tid < MAXP && s_act[tid] == 1) s_pre[tid] = (s_pre[tid] << 8) | 0xFFull;
+                __syncthreads();
+                continue;
+            }
             for (int i = tid; i < MAXP * 256; i += SMALL_THREADS) h[i] = 0;
             __syncthreads();
             const int shift = 56 - 8 * pass;
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
 }  // namespace
 
 static long route_small_pairs() {
-    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); return e ? atol(e) : 32768L; }();
+    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 32768L; return x > 131072L ? 131072L : x; }();   // route_small_k assumes token indices < 2^16
     return v;
 }
 
