@@ -208,7 +208,7 @@ int bind_weights(mc_ctx* c) {
 }
 
 static long small_gemm_rows() {
-    static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 5120L; }();
+    static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 6400L; }();
     return v;
 }
 
