@@ -912,7 +912,7 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
             t.A = c->z2; t.lda = D; t.a_gstride = BT * D; t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D;
             t.bias = c->dec_cat_b; t.b_gstride = C; t.C = c->out2; t.ldc = C; t.c_gstride = BT * C;
             t.M = (int)BT; t.N = C; t.K = D;
-            if (BT <= small_gemm_rows() && D % 32 == 0) { if ((r = mc_launch_gemm_small(t, s, 2))) return r; }
+            if (D % 32 == 0) { if ((r = mc_launch_gemm_small(t, s, 2))) return r; }
             else if ((r = mc_launch_gemm(GM_PLAIN, t, 2, 0, s))) return r;
             *x0a = c->out2;
             *x0b = c->out2 + BT * C;
