@@ -39,7 +39,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 TOTAL_DDPM_STEPS = 1000
 # HBM bytes of one B=64 step from rocprofv3 PMC passes (cannot be collected from inside this process);
 # re-measured when the kernel schedule changes: profiles/r01_pmc_hbm_traffic.txt
-MEASURED_HBM_GB_PER_STEP_B64 = 30.56
+MEASURED_HBM_GB_PER_STEP_B64 = 30.75
 
 DIMS = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77, E=16, topk=2,
             scale=6.5)
