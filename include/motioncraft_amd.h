@@ -15,6 +15,7 @@
  *   mc_denoise            model(x, ts, **model_kwargs)                 diffusion_transformer.py:186-238 -> stmogen.py:725-761
  *   mc_sample_step        GaussianDiffusion.p_sample / ddim_sample     gaussian_diffusion.py:634-696, 799-852
  *   mc_sample_step_inpaint  the same with y = {gt, outpainting_mask}   gaussian_diffusion.py:492-501, 855-877
+ *   mc_sample_step_seeded   the same with pre_seq / transl_req         gaussian_diffusion.py:664-674, 816-820
  *   mc_textenc_*          DiffusionTransformer.encode_text (CLIP text tower, text_pre_proj, textTransEncoder, text_ln)
  *                                                                      mogen/models/transformers/diffusion_transformer.py:109-172
  *   mc_evalenc_*          T2MContrastiveModel_SMPLX.encode_motion / encode_text (evaluation embeddings)
@@ -91,6 +92,19 @@ typedef struct mc_inpaint {
     int32_t blend_len;            /* overlap_len if sqrt(1-alpha_bar_prev) < 0.2 and opt.addBlend, else 0 */
 } mc_inpaint;
 
+/* pre_seq / transl_req seeding of one step (p_sample :664-674, ddim_sample :816-820): before the network sees x_t,
+ * x[:, :pre_len, :] = q_sample(pre_seq, t, randn_like(pre_seq)) and x[:, :2, channel_k] = q_sample(transl_k, t, randn(2)) */
+#define MC_MAX_TRANSL 8
+typedef struct mc_seed {
+    const float* pre_seq_dev;     /* [B, pre_len, C]; may be NULL when pre_len == 0                                  */
+    const float* pre_noise_dev;   /* [B, pre_len, C] the randn_like(pre_seq) of THIS step                            */
+    int32_t pre_len;              /* pre_seq.shape[1]                                                                */
+    float sqrt_ab, sqrt_1mab;     /* sqrt_alphas_cumprod[i], sqrt_one_minus_alphas_cumprod[i] cast to fp32           */
+    int32_t num_transl;           /* len(transl_req) <= MC_MAX_TRANSL (DDPM only)                                     */
+    int32_t transl_channel[MC_MAX_TRANSL];   /* item[0]                                                              */
+    float transl_value[MC_MAX_TRANSL][2];    /* q_sample(item[1:], t, randn(2)): 2 scalars, evaluated by the host     */
+} mc_seed;
+
 const char* mc_last_error(void);
 int mc_device_count(int* n);
 int mc_set_device(int dev);
@@ -126,6 +140,11 @@ int mc_denoise(mc_ctx* c, const float* x_t_dev, int32_t step_index, float* out2_
 int mc_sample_step(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
                    const float* noise_dev, float* x_prev_dev, float* x0_dev, void* stream);
 
+/* mc_sample_step with the seeding above; x_t_dev is MODIFIED IN PLACE on the seeded elements (the reference writes
+ * into `img`) before the denoiser and the sampler update read it */
+int mc_sample_step_seeded(mc_ctx* c, float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
+                          const float* noise_dev, const mc_seed* seed, float* x_prev_dev, float* x0_dev, void* stream);
+
 /* mc_sample_step with the kept region of x0 / of the new sample taken from gt (RePaint) */
 int mc_sample_step_inpaint(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
                            const float* noise_dev, const mc_inpaint* inpaint, float* x_prev_dev, float* x0_dev,
@@ -155,6 +174,14 @@ int mc_postprocess_smplx(const float* pred_dev, const int32_t* lengths_dev, cons
                          const double* std_dev, const double* taps_dev, const int32_t radius[4], int32_t stats_f32,
                          int32_t B, int32_t T, int32_t C, double* poses_dev, double* expr_dev, double* trans_dev,
                          void* stream);
+/* The same over the STITCHED sequence the tools save when several --text / --motion_length intervals are given
+ * (tools/visualize.py:216-246: the intervals' valid frames are concatenated FIRST, the Gaussian filter then runs over
+ * the whole sequence, so smoothing crosses the seams).  rows_dev int32 [n_frames]: row (b*T + t) of pred_dev [*,322]
+ * that stitched frame i shows; filter support is clamped to [0, n_frames).  Outputs [n_frames, 165|100|3] fp64. */
+int mc_postprocess_smplx_stitched(const float* pred_dev, const int32_t* rows_dev, int32_t n_frames,
+                                  const double* mean_dev, const double* std_dev, const double* taps_dev,
+                                  const int32_t radius[4], int32_t stats_f32, int32_t C, double* poses_dev,
+                                  double* expr_dev, double* trans_dev, void* stream);
 
 /* ---- text condition encoder (encode_text, diffusion_transformer.py:142-172); run once per prompt batch -------- */
 typedef struct mc_textenc mc_textenc;

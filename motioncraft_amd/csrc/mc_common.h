@@ -115,11 +115,3 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// Static MFMA-pipe priority by hardware wave slot: the two waves that share a SIMD (one from each
-// co-resident workgroup) otherwise run their MFMA-free stretches (staging, barrier, first fragment
-// reads) in lockstep and leave the matrix pipe idle together.  Giving the odd slot priority 1 lets it
-// drain its MFMA stream first, which de-phases the pair (MI355X_MICROARCH.md, "Two waves per SIMD").
-__device__ __forceinline__ void prio_by_wave_slot() {
-    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_HW_ID.WAVE_ID[3:0]
-    if (hw & 1) __builtin_amdgcn_s_setprio(1);
-}

@@ -106,10 +106,9 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
         load_tile<MODE, GUARD>(g, Ab, Wb, st, sk, ra, rb);
         store_tile(0);
         __syncthreads();
-        const bool abl_nostage = g.tune & 4, abl_nobar = g.tune & 8;   // ABLATION ONLY (wrong results)
         for (int kt = 0; kt < nk; ++kt) {
-            const int buf = abl_nostage ? 0 : (kt & 1);
-            if (kt + 1 < nk && !abl_nostage) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 1) * BK + sk, ra, rb);
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile<MODE, GUARD>(g, Ab, Wb, st, (kt + 1) * BK + sk, ra, rb);
             const float* Ap = As + buf * BM * LD + (wm * 64 + frow) * LD + fk;
             const float* Bp = Bs + buf * BN * LD + (wn * 64 + frow) * LD + fk;
             Frag f0 = ld_frag(Ap, Bp, 0);
@@ -120,8 +119,8 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
             f1 = ld_frag(Ap, Bp, 3);
             mma(f0);
             mma(f1);
-            if (kt + 1 < nk && !abl_nostage) store_tile(buf ^ 1);
-            if (!abl_nobar) __syncthreads();
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
         }
     } else {
         // Staging in the MIDDLE of the MFMA stream with ONE register set: after the first 16 MFMAs of
@@ -258,7 +257,6 @@ __global__ __launch_bounds__(256, 2) void gemm_k(GemmArgs g) {
     const float* __restrict__ Ab = g.A + (long)grp * g.a_gstride + g.a_col;
     const float* __restrict__ Wb = g.W + (long)grp * g.w_gstride;
 
-    if (g.tune & 2) prio_by_wave_slot();
     // staging assignment: thread -> rows (tid>>3) + 32*i, k-column (tid&7)*4
     const int sr = tid >> 3;
     const int sk = (tid & 7) * 4;

@@ -52,6 +52,19 @@ int mc_launch_sampler_inpaint(const float* x_t, const float* out_text, const flo
                               InpaintArgs ip, float* x_prev, float* x0_out, long n, SamplerCoefs c, hipStream_t s);
 // Y[r][0:Cp] = X[r][0:C], zero padded (aligned rows for the pose-encoder GEMM)
 int mc_launch_pad_rows(const float* X, float* Y, long rows, int C, int Cp, hipStream_t s);
+// pre_seq / transl_req seeding of p_sample / ddim_sample (gaussian_diffusion.py:664-674, 816-820), fused into the pad pass:
+// X[b][t < pre_len][:] = sqrt_ab * pre[b][t][:] + sqrt_1mab * pre_noise[b][t][:], then X[b][t < 2][ch_k] = transl_value[k][t],
+// written back to X IN PLACE (the sampler update reads x_t again) and to the padded copy
+struct SeedArgs {
+    const float* pre = nullptr;        // [B][pre_len][C]
+    const float* pre_noise = nullptr;  // [B][pre_len][C]
+    int pre_len = 0, T = 0;
+    float sqrt_ab = 0.f, sqrt_1mab = 0.f;
+    int num_transl = 0;
+    int transl_channel[8];
+    float transl_value[8][2];
+};
+int mc_launch_pad_rows_seeded(float* X, float* Y, long rows, int C, int Cp, const SeedArgs& sd, hipStream_t s);
 // out[M][N] (contiguous) = sum_s part[s][M][N] + bias[N] + res[M][N]
 int mc_launch_splitk_reduce(const float* part, int S, long M, int N, const float* bias, const float* res, float* out,
                             hipStream_t s);
@@ -59,7 +72,7 @@ int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out
 
 // ---- mc_post.hip ----------------------------------------------------------------------
 // de-normalise + 322 -> (poses 165, expressions 100, trans 3) + Gaussian temporal filter (tools/visualize.py:217-246)
-int mc_launch_smplx_post(const float* pred, const int* lengths, const double* mean, const double* stdv,
+int mc_launch_smplx_post(const float* pred, const int* lengths, const int* rows, const double* mean, const double* stdv,
                          const double* taps, const int* radius, int stats_f32, int B, int T, int C,
                          double* poses, double* expr, double* trans, hipStream_t s);
 int mc_smplx_post_maxtap();

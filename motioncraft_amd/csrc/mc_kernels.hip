@@ -235,6 +235,41 @@ __global__ __launch_bounds__(256) void pad_rows_k(const float* __restrict__ X, f
     }
 }
 
+// q_sample (gaussian_diffusion.py:416-421) is three tensor ops: two products, each rounded, then their sum (no FMA)
+__device__ __forceinline__ float axpby_unfused(float a, float x, float b, float y) {
+#pragma clang fp contract(off)
+    const float p0 = a * x;
+    const float p1 = b * y;
+    return p0 + p1;
+}
+
+// the same pass with the reference's per-step seeding of the first frames (SeedArgs, mc_kernels.h): the seeded value goes to
+// the padded copy AND back into X (p_sample / ddim_sample overwrite x in place before the network sees it)
+__global__ __launch_bounds__(256) void pad_rows_seeded_k(float* __restrict__ X, float* __restrict__ Y, long rows, int C, int Cp,
+                                                         SeedArgs sd) {
+    const long n = rows * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / Cp;
+        const int c = (int)(i % Cp);
+        if (c >= C) { Y[i] = 0.f; continue; }
+        const int t = (int)(r % sd.T);
+        const long b = r / sd.T;
+        float v = X[r * C + c];
+        bool seeded = false;
+        if (t < sd.pre_len) {
+            const long j = (b * sd.pre_len + t) * C + c;
+            v = axpby_unfused(sd.sqrt_ab, sd.pre[j], sd.sqrt_1mab, sd.pre_noise[j]);
+            seeded = true;
+        }
+        if (t < 2) {
+            for (int k = 0; k < sd.num_transl; ++k)
+                if (sd.transl_channel[k] == c) { v = sd.transl_value[k][t]; seeded = true; }
+        }
+        if (seeded) X[r * C + c] = v;
+        Y[i] = v;
+    }
+}
+
 // split-K reduction: out[r][n] = sum_s part[s][r][n] (s ascending: deterministic) + bias[n] + res[r][n]
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ part, int S, long MN, int N,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
@@ -345,6 +380,17 @@ int mc_launch_pad_rows(const float* X, float* Y, long rows, int C, int Cp, hipSt
     int blocks = cdiv(rows * Cp, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pad_rows_k, dim3(blocks), dim3(256), 0, s, X, Y, rows, C, Cp);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_pad_rows_seeded(float* X, float* Y, long rows, int C, int Cp, const SeedArgs& sd, hipStream_t s) {
+    if (rows <= 0) return MC_OK;
+    MC_REQUIRE(sd.T >= 1 && sd.pre_len >= 0 && sd.pre_len <= sd.T && sd.num_transl >= 0 && sd.num_transl <= 8, "bad seed arguments");
+    MC_REQUIRE(sd.pre_len == 0 || (sd.pre && sd.pre_noise), "pre_seq seeding without pre_seq / noise");
+    int blocks = cdiv(rows * Cp, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pad_rows_seeded_k, dim3(blocks), dim3(256), 0, s, X, Y, rows, C, Cp, sd);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -148,13 +148,6 @@ int bind_weights(mc_ctx* c) {
     if (m->params.count("dec.wf") && m->params.count("dec.bf")) {
         GP(c->dec_wf, "dec.wf", (int64_t)g.input_feats * D);
         GP(c->dec_bf, "dec.bf", g.input_feats);
-        const size_t wn = (size_t)g.input_feats * D, bn = (size_t)g.input_feats;
-        int rr;
-        if ((rr = ws_alloc(c, &c->dec_cat_w, 2 * wn)) != MC_OK || (rr = ws_alloc(c, &c->dec_cat_b, 2 * bn)) != MC_OK) return rr;
-        MC_HIP(hipMemcpy(c->dec_cat_w, c->dec_w, wn * sizeof(float), hipMemcpyDeviceToDevice));
-        MC_HIP(hipMemcpy(c->dec_cat_w + wn, c->dec_wf, wn * sizeof(float), hipMemcpyDeviceToDevice));
-        MC_HIP(hipMemcpy(c->dec_cat_b, c->dec_bf, bn * sizeof(float), hipMemcpyDeviceToDevice));
-        MC_HIP(hipMemset(c->dec_cat_b + bn, 0, bn * sizeof(float)));
     }
     c->NLA = g.num_layers + g.num_ctrl_layers;
     c->lw.resize(c->NLA);
@@ -204,6 +197,22 @@ int bind_weights(mc_ctx* c) {
         GP(w.ffn_out_w, p + "ffn.out_w", (int64_t)D * D);
         GP(w.ffn_out_b, p + "ffn.out_b", D);
     }
+    return MC_OK;
+}
+
+// context-only derived weights (bind_weights itself is a pure lookup / validation pass, also run by mc_model_finalize):
+// [2][C][D] = dec_w | dec_wf and [2][C] = dec_bf | 0 -- the folded decoder tail as ONE grouped GEMM
+int build_ctx_weights(mc_ctx* c) {
+    if (!c->dec_wf) return MC_OK;
+    const mc_model_config& g = c->m->cfg;
+    const int D = g.latent_dim * g.num_parts;
+    const size_t wn = (size_t)g.input_feats * D, bn = (size_t)g.input_feats;
+    int rr;
+    if ((rr = ws_alloc(c, &c->dec_cat_w, 2 * wn)) != MC_OK || (rr = ws_alloc(c, &c->dec_cat_b, 2 * bn)) != MC_OK) return rr;
+    MC_HIP(hipMemcpy(c->dec_cat_w, c->dec_w, wn * sizeof(float), hipMemcpyDeviceToDevice));
+    MC_HIP(hipMemcpy(c->dec_cat_w + wn, c->dec_wf, wn * sizeof(float), hipMemcpyDeviceToDevice));
+    MC_HIP(hipMemcpy(c->dec_cat_b, c->dec_bf, bn * sizeof(float), hipMemcpyDeviceToDevice));
+    MC_HIP(hipMemset(c->dec_cat_b + bn, 0, bn * sizeof(float)));
     return MC_OK;
 }
 
@@ -633,7 +642,8 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     c->N = c->rows * H;
     c->Ntxt = B2 * g.max_text_len;
     int r = bind_weights(c);
-    if (r != MC_OK) { delete c; return r; }
+    if (r == MC_OK) r = build_ctx_weights(c);
+    if (r != MC_OK) { mc_ctx_destroy(c); return r; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -810,7 +820,16 @@ int mc_ctx_set_control(mc_ctx* c, const float* c_feat_dev, int32_t Tc, void* str
     return MC_OK;
 }
 
+static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32_t stop_after, void* stream,
+                        const SeedArgs* seed);
+
 int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32_t stop_after, void* stream) {
+    return denoise_impl(c, x_t, step, out2_dev, stop_after, stream, nullptr);
+}
+
+// `seed` != nullptr: x_t is overwritten in place on its first frames before the network reads it (mc_sample_step_seeded)
+static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32_t stop_after, void* stream,
+                        const SeedArgs* seed) {
     MC_REQUIRE(c && x_t, "null argument");
     MC_REQUIRE(c->have_cond, "mc_ctx_set_condition not called");
     MC_REQUIRE(step >= 0 && step < c->S, "step_index %d outside the %d-step schedule", step, c->S);
@@ -822,7 +841,8 @@ int mc_denoise(mc_ctx* c, const float* x_t, int32_t step, float* out2_dev, int32
     // PoseEncoder as one dense [C -> D] GEMM with the scattered weight, + sequence_embedding[:T],
     // written to both CFG halves (stmogen.py:336-353; diffusion_transformer.py:215-218; stmogen.py:740)
     {
-        if ((r = mc_launch_pad_rows(x_t, c->xpad, BT, C, c->m->Cp, s))) return r;
+        if (seed) { if ((r = mc_launch_pad_rows_seeded(const_cast<float*>(x_t), c->xpad, BT, C, c->m->Cp, *seed, s))) return r; }
+        else if ((r = mc_launch_pad_rows(x_t, c->xpad, BT, C, c->m->Cp, s))) return r;
         GemmArgs e;
         e.A = c->xpad; e.lda = c->m->Cp;
         e.W = c->enc_w; e.ldw = c->m->Cp; e.bias = c->enc_b;
@@ -886,13 +906,13 @@ static SamplerCoefs to_coefs(const mc_step_coefs* k) {
 // (mc_denoise, which hands out both decoded halves, keeps the reference's order).
 // -> x0 = *x0a (+ *x0b when it is not null: the two partial products of the folded tail, summed by the sampler kernel)
 static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, void* stream, const float** x0a,
-                            const float** x0b) {
+                            const float** x0b, const SeedArgs* seed = nullptr) {
     const mc_model_config& g = c->m->cfg;
     // ... and so is the Linear of the very last StylizationBlock (h += a W^T + b): it, too, runs once on the combined
     // rows  h_c = comb(h) + comb(a) W^T + b  instead of on both halves.
     const bool defer = mc_chain_enabled(7);
     c->defer_last_gemm = defer;
-    int r = mc_denoise(c, x_t, step, nullptr, g.num_layers, stream);          // all layers (minus that GEMM), no decoder
+    int r = denoise_impl(c, x_t, step, nullptr, g.num_layers, stream, seed);   // all layers (minus that GEMM), no decoder
     c->defer_last_gemm = false;
     if (r != MC_OK) return r;
     hipStream_t s = (hipStream_t)stream;
@@ -949,6 +969,28 @@ int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coef
     return mc_launch_sampler_update(x_t, x0a, x0b ? x0b : x0a, noise, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream);
 }
 
+int mc_sample_step_seeded(mc_ctx* c, float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
+                          const mc_seed* sd, float* x_prev, float* x0, void* stream) {
+    MC_REQUIRE(c && x_t && k && noise && x_prev && sd, "null argument");
+    MC_REQUIRE(sd->pre_len >= 0 && sd->pre_len <= c->T, "pre_seq has %d frames, the window %d", sd->pre_len, c->T);
+    MC_REQUIRE(sd->num_transl >= 0 && sd->num_transl <= MC_MAX_TRANSL, "num_transl=%d outside [0, %d]", sd->num_transl, MC_MAX_TRANSL);
+    MC_REQUIRE(sd->num_transl == 0 || c->T >= 2, "transl_req seeds frames 0 and 1: the window has %d", c->T);
+    SeedArgs a;
+    a.pre = sd->pre_seq_dev; a.pre_noise = sd->pre_noise_dev; a.pre_len = sd->pre_len; a.T = c->T;
+    a.sqrt_ab = sd->sqrt_ab; a.sqrt_1mab = sd->sqrt_1mab; a.num_transl = sd->num_transl;
+    for (int i = 0; i < sd->num_transl; ++i) {
+        MC_REQUIRE(sd->transl_channel[i] >= 0 && sd->transl_channel[i] < c->m->cfg.input_feats, "transl_req channel %d", sd->transl_channel[i]);
+        a.transl_channel[i] = sd->transl_channel[i];
+        a.transl_value[i][0] = sd->transl_value[i][0];
+        a.transl_value[i][1] = sd->transl_value[i][1];
+    }
+    const float *x0a = nullptr, *x0b = nullptr;
+    int r = denoise_combined(c, x_t, step, k, stream, &x0a, &x0b, &a);
+    if (r != MC_OK) return r;
+    const long n = (long)c->B * c->T * c->m->cfg.input_feats;
+    return mc_launch_sampler_update(x_t, x0a, x0b ? x0b : x0a, noise, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream);
+}
+
 int mc_sample_step_inpaint(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,
                            const mc_inpaint* ip, float* x_prev, float* x0, void* stream) {
     MC_REQUIRE(c && x_t && k && noise && x_prev && ip, "null argument");
@@ -970,8 +1012,17 @@ int mc_postprocess_smplx(const float* pred, const int32_t* lengths, const double
     MC_REQUIRE(pred && mean && stdv && taps && radius && poses && expr && trans, "null argument");
     static_assert(MC_POST_MAXTAP == 129, "header / kernel tap table size");
     MC_REQUIRE(mc_smplx_post_maxtap() == MC_POST_MAXTAP, "tap table size mismatch");
-    return mc_launch_smplx_post(pred, lengths, mean, stdv, taps, radius, stats_f32, B, T, C, poses, expr, trans,
+    return mc_launch_smplx_post(pred, lengths, nullptr, mean, stdv, taps, radius, stats_f32, B, T, C, poses, expr, trans,
                                 (hipStream_t)stream);
+}
+
+int mc_postprocess_smplx_stitched(const float* pred, const int32_t* rows, int32_t n_frames, const double* mean,
+                                  const double* stdv, const double* taps, const int32_t radius[4], int32_t stats_f32,
+                                  int32_t C, double* poses, double* expr, double* trans, void* stream) {
+    MC_REQUIRE(pred && rows && mean && stdv && taps && radius && poses && expr && trans && n_frames >= 0, "bad argument");
+    MC_REQUIRE(mc_smplx_post_maxtap() == MC_POST_MAXTAP, "tap table size mismatch");
+    return mc_launch_smplx_post(pred, nullptr, rows, mean, stdv, taps, radius, stats_f32, 1, n_frames, C, poses, expr,
+                                trans, (hipStream_t)stream);
 }
 
 int mc_op_renoise(const float* x, const float* noise, float a, float b, float* out, int64_t n, void* stream) {

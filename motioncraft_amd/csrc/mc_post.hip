@@ -17,6 +17,7 @@ constexpr int NPOSE = 165, NEXPR = 100, NTRANS = 3, NOUT = NPOSE + NEXPR + NTRAN
 struct PostArgs {
     const float* pred;        // [B][T][322] normalised
     const int* lengths;       // [B] valid frames (filter support is clamped to [0, len))
+    const int* rows;          // stitched mode (B == 1, T == stitched frames): frame t reads row rows[t] of pred [*, 322]
     const double* mean;       // [322]
     const double* stdv;       // [322]
     const double* taps;       // 4 tables of MAXTAP doubles: centre at [radius[g]]
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(256) void smplx_post_k(PostArgs a) {
         }
         const int len = a.lengths ? a.lengths[b] : a.T;
         if (src < 0 || t >= len) { *out = 0.0; continue; }
-        const float* col = a.pred + (long)b * a.T * a.C + src;
+        const float* col = a.pred + (long)b * a.T * a.C + src;      // (stitched mode: B == 1 -> b == 0)
         const double m = a.mean[src], s = a.stdv[src];
         const float mf = (float)m, sf = (float)s;
         auto denorm = [&](int tt) -> double {
-            const float p = col[(long)tt * a.C];
+            const float p = col[(long)(a.rows ? a.rows[tt] : tt) * a.C];
             if (a.stats_f32) return (double)mul_then_add<float>(p, sf, mf);
             return mul_then_add<double>((double)p, s, m);
         };
@@ -84,12 +85,13 @@ __global__ __launch_bounds__(256) void smplx_post_k(PostArgs a) {
 
 }  // namespace
 
-int mc_launch_smplx_post(const float* pred, const int* lengths, const double* mean, const double* stdv,
+int mc_launch_smplx_post(const float* pred, const int* lengths, const int* rows, const double* mean, const double* stdv,
                          const double* taps, const int* radius, int stats_f32, int B, int T, int C,
                          double* poses, double* expr, double* trans, hipStream_t s) {
     MC_REQUIRE(C == 322, "smplx post-processing: input_feats=%d (the SMPL-X layout is 322-d)", C);
+    MC_REQUIRE(!rows || (B == 1 && !lengths), "smplx post-processing: the stitched mode takes one sequence of `T` mapped frames");
     PostArgs a;
-    a.pred = pred; a.lengths = lengths; a.mean = mean; a.stdv = stdv; a.taps = taps;
+    a.pred = pred; a.lengths = lengths; a.rows = rows; a.mean = mean; a.stdv = stdv; a.taps = taps;
     for (int g = 0; g < 4; ++g) {
         MC_REQUIRE(radius[g] < (MAXTAP + 1) / 2, "smplx post-processing: filter radius %d too large", radius[g]);
         a.radius[g] = radius[g];

@@ -110,8 +110,6 @@ class GaussianDiffusion:
         if clip_denoised or denoised_fn is not None or cond_fn is not None:
             raise NotImplementedError('clip_denoised / denoised_fn / cond_fn are not on the MotionDiffusion eval path '
                                       '(diffusion_architecture.py:177-191 passes clip_denoised=False)')
-        if pre_seq is not None or transl_req is not None:
-            raise NotImplementedError('pre_seq / transl_req seeding is not on this path (SURVEY.md section 8f)')
 
     def _inpaint_operands(self, mode, model_kwargs, shape, device):
         """y = {gt, outpainting_mask} of the long-sequence windows (tools/m2d_test.py:177-195) -> device operands,
@@ -150,7 +148,7 @@ class GaussianDiffusion:
         return c
 
     def _loop(self, mode, model, shape, noise, model_kwargs, device, progress, eta, step_noise, generator,
-              num_steps=None, trajectory=None):
+              num_steps=None, trajectory=None, pre_seq=None, transl_req=None):
         if model_kwargs is None:
             model_kwargs = {}
         if not isinstance(shape, (tuple, list)):
@@ -186,7 +184,31 @@ class GaussianDiffusion:
         if progress:
             from tqdm.auto import tqdm
             plan = tqdm(plan)
+        seeded = pre_seq is not None or bool(transl_req)
+        if seeded:
+            # p_sample :664-674 / ddim_sample :816-820: every step re-noises pre_seq (and the requested translation
+            # channels of frames 0-1) to the step's level and writes it over the first frames of x before the network call
+            if inp is not None:
+                raise NotImplementedError('pre_seq / transl_req together with the outpainting mask: no reference tool combines them')
+            if pre_seq is not None:
+                pre_seq = pre_seq.to(device=device, dtype=torch.float32).contiguous()
+                if pre_seq.dim() != 3 or pre_seq.shape[0] != B or pre_seq.shape[2] != C or pre_seq.shape[1] > T:
+                    raise RuntimeError(f'pre_seq of shape {tuple(pre_seq.shape)} cannot be written into x[:, :T, :] of {tuple(shape)}')
+            transl_req = [list(it) for it in (transl_req or [])]
+            if transl_req and B > 2:
+                # _extract_into_tensor(arr, t, (2,)) expands a [B] tensor to (2,): the reference raises for B > 2 as well
+                raise RuntimeError(f'transl_req: the expanded size of the tensor (2) must match the batch size ({B})')
+            if any(len(it) != 3 for it in transl_req):
+                raise ValueError('transl_req items are [channel, value_frame0, value_frame1]')
+            if step_noise is not None and not hasattr(step_noise, '__next__'):
+                raise ValueError('with pre_seq / transl_req several tensors of different shapes are drawn per step: '
+                                 'step_noise must be an iterator yielding them in the order the reference draws them '
+                                 '(randn_like(pre_seq), one randn(2) per transl_req item, randn_like(x))')
         draw_no = [0]
+        if inp is not None and step_noise is not None and not (hasattr(step_noise, '__next__') or callable(step_noise)):
+            raise ValueError('the outpainting mode draws several independent randn_like tensors per step index: '
+                             'step_noise must be an iterator or a callable of the running draw number there, not a '
+                             'sequence indexed by step (every draw of a step would get the same tensor)')
 
         def draw(i):
             """the next randn_like(x) of the reference loop; in the outpainting mode several are drawn per step,
@@ -215,6 +237,21 @@ class GaussianDiffusion:
             if not denoise:                                                   # _undo (:429-435)
                 beta = np.float32(self.betas[i])
                 ctx.renoise(img, draw(i), np.sqrt(np.float32(1) - beta), np.sqrt(beta), out=nxt)
+            elif seeded:
+                a_, b_ = np.float32(self.sqrt_alphas_cumprod[i]), np.float32(self.sqrt_one_minus_alphas_cumprod[i])
+                pre_noise = None
+                if pre_seq is not None:
+                    pre_noise = (next(step_noise).to(device=device, dtype=torch.float32).contiguous() if step_noise is not None
+                                 else torch.randn(*pre_seq.shape, device=device, generator=generator))
+                transl = []
+                for it in transl_req:                                        # th.randn(2) on the host, then q_sample in fp32
+                    n2 = (next(step_noise) if step_noise is not None else torch.randn(2, generator=generator if generator is not None and generator.device.type == 'cpu' else None))
+                    n2 = n2.detach().cpu().numpy().astype(np.float32)
+                    v = a_ * np.asarray(it[1:], dtype=np.float32) + b_ * n2
+                    transl.append((int(it[0]), float(v[0]), float(v[1])))
+                eps = draw(i)
+                ctx.sample_step_seeded(img, i, self.step_coefs(i, mode, model.cfg_scale, eta), eps, a_, b_, pre_seq=pre_seq,
+                                       pre_noise=pre_noise, transl=transl, x_prev=nxt, x0=x0)
             elif inp is None:
                 eps = draw(i)                                                 # drawn every step, DDIM too
                 ctx.sample_step(img, i, self.step_coefs(i, mode, model.cfg_scale, eta), eps, x_prev=nxt, x0=x0)
@@ -239,7 +276,7 @@ class GaussianDiffusion:
                       step_noise=None, generator=None, num_steps=None, trajectory=None):
         self._check_supported(clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq, transl_req)
         return self._loop('ddpm', model, shape, noise, model_kwargs, device, progress, 0.0, step_noise, generator,
-                          num_steps, trajectory)
+                          num_steps, trajectory, pre_seq=pre_seq, transl_req=transl_req)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, pre_seq=None,
@@ -250,7 +287,7 @@ class GaussianDiffusion:
                                       '(gaussian_diffusion.py:879-881) without ever creating it, so that option has '
                                       'no defined behaviour to reproduce')
         return self._loop('ddim', model, shape, noise, model_kwargs, device, progress, float(eta), step_noise,
-                          generator, num_steps, trajectory)
+                          generator, num_steps, trajectory, pre_seq=pre_seq)
 
 
 def get_schedule_jump_cjm_ddim(time_respacing=25, jump_length=1, jump_n_sample=1):

@@ -139,6 +139,32 @@ class NativeContext:
                                            _ptr(x_prev), _ptr(x0), _stream()), 'mc_sample_step')
         return x_prev
 
+    def sample_step_seeded(self, x_t, step_index, coefs, noise, sqrt_ab, sqrt_1mab, pre_seq=None, pre_noise=None,
+                           transl=(), x_prev=None, x0=None):
+        """One step with the reference's pre_seq / transl_req seeding: ``x_t`` is overwritten IN PLACE on its first
+        frames (q_sample of ``pre_seq`` with ``pre_noise``; ``transl`` = [(channel, v0, v1), ...] already q-sampled)."""
+        x = _dev_f32(x_t, 'x_t')
+        n = _dev_f32(noise, 'noise')
+        sd = _lib.Seed()
+        sd.pre_len = 0
+        if pre_seq is not None:
+            p, pn = _dev_f32(pre_seq, 'pre_seq'), _dev_f32(pre_noise, 'pre_noise')
+            if p.dim() != 3 or p.shape[0] != self.B or p.shape[2] != self.C or p.shape[1] > self.T or pn.shape != p.shape:
+                raise ValueError(f'pre_seq shape {tuple(p.shape)} does not fit the window {(self.B, self.T, self.C)}')
+            sd.pre_seq_dev, sd.pre_noise_dev, sd.pre_len = p.data_ptr(), pn.data_ptr(), int(p.shape[1])
+        sd.sqrt_ab, sd.sqrt_1mab = float(sqrt_ab), float(sqrt_1mab)
+        if len(transl) > _lib.MAX_TRANSL:
+            raise ValueError(f'at most {_lib.MAX_TRANSL} transl_req items')
+        sd.num_transl = len(transl)
+        for k, (ch, v0, v1) in enumerate(transl):
+            sd.transl_channel[k] = int(ch)
+            sd.transl_value[k][0], sd.transl_value[k][1] = float(v0), float(v1)
+        if x_prev is None:
+            x_prev = torch.empty_like(x)
+        _lib.check(self.lib.mc_sample_step_seeded(self.handle, _ptr(x), int(step_index), ctypes.byref(coefs), _ptr(n),
+                                                  ctypes.byref(sd), _ptr(x_prev), _ptr(x0), _stream()), 'mc_sample_step_seeded')
+        return x_prev
+
     def sample_step_inpaint(self, x_t, step_index, coefs, noise, gt, keep, gt_noise=None, blend_w=None, blend_len=0,
                             x_prev=None, x0=None):
         """RePaint step: ``keep`` is the bool outpainting_mask, ``gt`` the kept motion (both [B,T,C] on the device)."""

@@ -35,6 +35,16 @@ class Inpaint(ctypes.Structure):
                 ('blend_w_dev', ctypes.c_void_p), ('blend_len', ctypes.c_int32)]
 
 
+MAX_TRANSL = 8               # MC_MAX_TRANSL
+
+
+class Seed(ctypes.Structure):
+    """mc_seed (include/motioncraft_amd.h): pre_seq / transl_req operands of one step."""
+    _fields_ = [('pre_seq_dev', ctypes.c_void_p), ('pre_noise_dev', ctypes.c_void_p), ('pre_len', ctypes.c_int32),
+                ('sqrt_ab', ctypes.c_float), ('sqrt_1mab', ctypes.c_float), ('num_transl', ctypes.c_int32),
+                ('transl_channel', ctypes.c_int32 * MAX_TRANSL), ('transl_value', (ctypes.c_float * 2) * MAX_TRANSL)]
+
+
 class EvalEncConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('nfeats', 'latent_dim', 'ff_size', 'num_layers', 'num_heads', 'pe_len', 'bert_dim',
                                               'bert_layers', 'bert_heads', 'bert_ff', 'bert_vocab', 'bert_max_pos')]
@@ -67,6 +77,7 @@ _SIGNATURES = {
     'mc_ctx_set_control': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'mc_denoise': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
     'mc_sample_step': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, _P, _P, _P]),
+    'mc_sample_step_seeded': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, ctypes.POINTER(Seed), _P, _P, _P]),
     'mc_sample_step_inpaint': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P,
                                               ctypes.POINTER(Inpaint), _P, _P, _P]),
     'mc_ctx_get_buffer': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P),
@@ -78,6 +89,8 @@ _SIGNATURES = {
     'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
     'mc_postprocess_smplx': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int32 * 4), ctypes.c_int32,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    'mc_postprocess_smplx_stitched': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, _P, _P, ctypes.POINTER(ctypes.c_int32 * 4),
+                                                     ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
     'mc_textenc_create': (ctypes.c_int, [ctypes.POINTER(TextEncConfig), ctypes.POINTER(_P)]),
     'mc_textenc_destroy': (None, [_P]),
     'mc_textenc_set_param': (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64]),

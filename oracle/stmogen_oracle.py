@@ -402,13 +402,22 @@ def ddim_step(sched, i, x, x0, noise, eta=0.0):
     return mean_pred + nonzero * sigma * noise
 
 
+def q_sample(sched, i, x_start, noise):
+    """gaussian_diffusion.py:405-421: sqrt(alpha_bar_i) x_0 + sqrt(1 - alpha_bar_i) noise, tables cast to fp32 first."""
+    return _f32(np.sqrt(sched.alphas_cumprod[i])) * x_start + _f32(np.sqrt(1.0 - sched.alphas_cumprod[i])) * noise
+
+
 def sample_loop(p, dims, sched, mode, x_T, xf_out, motion_mask, step_noise=None, generator=None,
-                num_steps=None, trajectory=None, hoist_text=True):
+                num_steps=None, trajectory=None, hoist_text=True, pre_seq=None, transl_req=None, draws=None):
     """p_sample_loop_progressive (:746-797) / ddim_sample_loop_progressive (:998-1049) with eta=0.
 
     ``step_noise`` (callable i -> tensor) or ``generator`` supplies the per-step
     ``randn_like(x)`` the reference draws EVERY step, DDIM included (:685, :847).
     ``num_steps`` truncates the loop (first num_steps iterations from i = S-1 down).
+    ``pre_seq`` [B,Tp,C] / ``transl_req`` [[channel, v0, v1], ...] (DDPM only): p_sample :664-674 and ddim_sample
+    :816-820 overwrite ``x[:, :Tp]`` with q_sample(pre_seq, t, randn_like(pre_seq)) and ``x[:, :2, channel]`` with
+    q_sample(transl, t, randn(2)) before every network call; ``draws`` then is an iterator yielding the random tensors in
+    the order the reference draws them (pre_seq noise, one randn(2) per item, randn_like(x)); None = torch's global RNG.
     """
     x = x_T.to(torch.float32) if x_T.dtype != torch.float64 else x_T
     text_feats = precompute_text(p, xf_out, dims) if hoist_text else None
@@ -416,9 +425,21 @@ def sample_loop(p, dims, sched, mode, x_T, xf_out, motion_mask, step_noise=None,
     indices = list(range(S))[::-1]
     if num_steps is not None:
         indices = indices[:num_steps]
+    seeded = pre_seq is not None or bool(transl_req)
+    if seeded:
+        x = x.clone()
+        draws = iter(draws) if draws is not None else None
+        rnd = lambda shape: next(draws) if draws is not None else torch.randn(shape, generator=generator)
     for n, i in enumerate(indices):
+        if seeded:
+            if pre_seq is not None:
+                x[:, :pre_seq.shape[1], :] = q_sample(sched, i, pre_seq, rnd(pre_seq.shape))
+            for item in (transl_req or []) if mode == 'ddpm' else []:
+                x[:, :2, int(item[0])] = q_sample(sched, i, torch.tensor(item[1:], dtype=torch.float32), rnd((2,)))
         x0 = denoise(p, dims, x, sched.timestep_map[i], xf_out, motion_mask, text_feats=text_feats)
-        if step_noise is not None:
+        if seeded:
+            noise = rnd(x.shape)
+        elif step_noise is not None:
             noise = step_noise(i)
         else:
             noise = torch.randn(x.shape, generator=generator, dtype=x.dtype)

@@ -20,6 +20,7 @@ Fixtures
                         call at t=777 with per-layer intermediates captured by hooks
   small_ddim.npz        reduced config: 50-step DDIM trajectory (every 10th x_t) + final
   small_ddpm.npz        reduced config: 1000-step schedule, first 20 DDPM steps
+  preseq_small.npz      reduced config: pre_seq (5 frames) + transl_req seeding, first 12 DDPM steps and the 50-step DDIM loop
   control_small.npz     ControlT2MHalf (copy_blocks_num=2, 35-d condition of 20 frames, NL=3): x0 at t=640, 3
   repaint_small.npz     RePaint / outpainting DDIM mode (reduced config, first 6 frames kept): harmonize loop with
                         resampling (jump 3 x 5), without resampling, and no_repaint (plain 50 steps + blending)
@@ -223,6 +224,58 @@ def small_loops():
     np.savez_compressed(os.path.join(OUT, 'small_ddpm.npz'), x_T=x_T.numpy(), xf_out=xf.numpy(),
                         motion_mask=mask.numpy(), noise_seed=np.int64(6),
                         traj=np.stack([t.numpy() for t in tr[4::5]]))
+
+
+def preseq():
+    """pre_seq / transl_req seeding of p_sample (:664-674) and ddim_sample (:816-820): the reference's own loops with
+    ``pre_seq`` [2, 5, 322] (and two transl_req items for DDPM; B = 2 is the largest batch the reference's
+    ``_extract_into_tensor(arr, t, (2,))`` accepts there), torch's global RNG seeded like the other loop fixtures."""
+    dims, B, T = SMALL, 2, 24
+    m, sd = build_ref(dims, SMALL_SEED)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=14, lengths=[24, 21])
+    g = torch.Generator().manual_seed(15)
+    pre = torch.randn(B, 5, dims['input_feats'], generator=g)
+    transl = [[309, 0.25, -0.5], [311, 1.0, 0.75]]
+
+    def ref_loop(diff, mode, seed, num_steps=None):
+        torch.manual_seed(seed)
+        gen = diff.p_sample_loop_progressive if mode == 'ddpm' else diff.ddim_sample_loop_progressive
+        kw = dict(noise=x_T.clone(), clip_denoised=False, model_kwargs=model_kwargs(xf, mask), pre_seq=pre.clone())
+        if mode == 'ddim':
+            kw['eta'] = 0
+        else:
+            kw['transl_req'] = transl
+        traj = []
+        with torch.no_grad():
+            for n, sres in enumerate(gen(m, (B, T, dims['input_feats']), **kw)):
+                traj.append(sres['sample'].clone())
+                if num_steps is not None and n + 1 >= num_steps:
+                    break
+        return traj
+
+    def oracle_loop(sched, mode, seed, num_steps=None):
+        torch.manual_seed(seed)
+        traj = []
+        O.sample_loop(sd, dims, sched, mode, x_T, xf, mask, num_steps=num_steps, trajectory=traj, pre_seq=pre,
+                      transl_req=transl if mode == 'ddpm' else None)
+        return [t[1] for t in traj]
+
+    diff = ref_shim.build_reference_diffusion(DIFF_DDPM)
+    tr = ref_loop(diff, 'ddpm', 16, 12)
+    to = oracle_loop(O.Schedule(1000, None), 'ddpm', 16, 12)
+    e = [maxabs(a, b) for a, b in zip(tr, to)]
+    print(f'preseq ddpm: oracle vs reference over 12 steps: max {max(e):.2e}')
+    assert max(e) <= 1e-5
+    diff = ref_shim.build_reference_diffusion(DIFF_DDIM)
+    tr2 = ref_loop(diff, 'ddim', 17)
+    to2 = oracle_loop(O.Schedule(1000, DIFF_DDIM['respace']), 'ddim', 17)
+    e = [maxabs(a, b) for a, b in zip(tr2, to2)]
+    print(f'preseq ddim: oracle vs reference over 50 steps: max {max(e):.2e} final {e[-1]:.2e}')
+    assert max(e) <= 1e-5
+    np.savez_compressed(os.path.join(OUT, 'preseq_small.npz'), x_T=x_T.numpy(), xf_out=xf.numpy(), motion_mask=mask.numpy(),
+                        pre_seq=pre.numpy(), transl_req=np.array(transl, dtype=np.float64), ddpm_seed=np.int64(16),
+                        ddim_seed=np.int64(17), ddpm_traj=np.stack([t.numpy() for t in tr[3::4]]),
+                        ddim_traj=np.stack([t.numpy() for t in tr2[9::10]]), ddim_final=tr2[-1].numpy())
 
 
 def control():
@@ -621,7 +674,7 @@ if __name__ == '__main__':
     ap.add_argument('--only', default=None, help='comma list of fixture groups to regenerate')
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
-    groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, control=control,
+    groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, preseq=preseq, control=control,
                   repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, evaluator=evaluator, t2m_evaluator=t2m_evaluator, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):

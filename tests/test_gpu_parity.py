@@ -203,6 +203,63 @@ def test_small_ddim_and_ddpm_trajectories(small_model):
         m.ctx.close()
 
 
+def test_pre_seq_and_transl_req_seeding_vs_reference_golden(small_model):
+    """gaussian_diffusion.py:664-674, 816-820: every step overwrites x[:, :Tp] with q_sample(pre_seq, t) (and the
+    requested translation channels of frames 0-1) before the network call -- fused into the pose-row padding pass
+    (mc_sample_step_seeded).  Golden: the reference's p_sample_loop / ddim_sample_loop with pre_seq / transl_req,
+    through MotionDiffusion.forward(inference_kwargs=...) like the reference passes them (diffusion_architecture.py:175)."""
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = small_model
+    g = load('preseq_small.npz')
+    x_T, xf, mask, pre = T_(g['x_T']), T_(g['xf_out']), T_(g['motion_mask']), T_(g['pre_seq'])
+    transl = [[int(r[0]), float(r[1]), float(r[2])] for r in g['transl_req']]
+    B, T, C = x_T.shape
+
+    def draws(seed, nsteps, ntransl):
+        # the reference's global-RNG stream: per step randn_like(pre_seq), randn(2) per item, randn_like(x)
+        gen = torch.Generator().manual_seed(int(seed))
+        for _ in range(nsteps):
+            yield torch.randn(pre.shape, generator=gen)
+            for _ in range(ntransl):
+                yield torch.randn(2, generator=gen)
+            yield torch.randn(B, T, C, generator=gen)
+
+    class M:
+        cfg_scale = SMALL['scale']
+
+        def sampling_context(self, B, T, tmap, kw, device=None):
+            ctx = nm.context(B, T, max_steps=len(tmap))
+            ctx.set_timesteps(tmap)
+            ctx.set_condition(kw['xf_out'].cuda(), kw['motion_mask'].cuda())
+            self.ctx = ctx
+            return ctx
+    base = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large')
+    kw = dict(xf_out=xf, motion_mask=mask, y={})
+    d, m, traj = build_diffusion(base), M(), []
+    d.p_sample_loop(m, (B, T, C), noise=x_T, clip_denoised=False, model_kwargs=kw, pre_seq=pre, transl_req=transl,
+                    step_noise=draws(g['ddpm_seed'], 12, len(transl)), num_steps=12, trajectory=traj)
+    for n, ref in zip(range(3, 12, 4), g['ddpm_traj']):
+        assert maxabs(traj[n][1], T_(ref)) <= TOL_FINAL, n
+    m.ctx.close()
+    with pytest.raises(ValueError):          # a per-step list cannot serve draws of three different shapes
+        d.p_sample_loop(m, (B, T, C), noise=x_T, clip_denoised=False, model_kwargs=kw, pre_seq=pre, step_noise=[x_T] * 1000)
+    m.ctx.close()
+    with pytest.raises(RuntimeError):        # like the reference: transl_req only broadcasts for B <= 2
+        d.p_sample_loop(m, (3, T, C), noise=torch.zeros(3, T, C), clip_denoised=False,
+                        model_kwargs=dict(xf_out=xf[:1].repeat(3, 1, 1), motion_mask=mask[:1].repeat(3, 1), y={}), transl_req=transl)
+    m.ctx.close()
+    # DDIM through the architecture API
+    cfg, arch = _arch_small(sd)
+    res = arch(motion=torch.zeros(B, T, C), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+               motion_metas=[{'text': 'a'}, {'text': 'b'}], xf_out=xf,
+               inference_kwargs=dict(noise=x_T, pre_seq=pre, step_noise=draws(g['ddim_seed'], 50, 0)))
+    final = torch.stack([r['pred_motion'] for r in res])
+    err = maxabs(final, T_(g['ddim_final']))
+    print(f'pre_seq DDIM 50 steps: |hip - reference| {err:.2e}')
+    assert err <= TOL_FINAL
+    arch.model.release()
+
+
 def test_full_size_denoise_vs_reference_golden(full_model):
     sd, nm = full_model
     g = load('full_denoise.npz')
@@ -445,6 +502,21 @@ def test_smplx_postprocessing_vs_scipy_restatement(tmp_path):
                 assert np.abs(post['expressions'][b, :n].cpu().numpy() - expr).max() <= tol
                 assert np.abs(post['trans'][b, :n].cpu().numpy() - trans).max() <= tol
                 assert float(post['poses'][b, n:].abs().sum()) == 0.0
+            # several intervals in one file (tools/visualize.py:216-246): concatenate the valid frames FIRST, then filter
+            # the stitched sequence -- the smoothing crosses the seams, only the two outer ends replicate their edge
+            st = P.postprocess_smplx_stitched(pred.cuda(), lens, mean, std, sig)
+            pose, expr, trans = fn(PO.denormalise([pred[b, :n].numpy() for b, n in enumerate(lens)], mean, std))
+            assert st['poses'].shape == (sum(lens), 165)
+            assert np.abs(st['poses'].cpu().numpy() - pose).max() <= 1e-9
+            assert np.abs(st['expressions'].cpu().numpy() - expr).max() <= tol
+            assert np.abs(st['trans'].cpu().numpy() - trans).max() <= tol
+            if sig is P.SIGMAS_T2M:          # ... which differs from filtering each interval on its own near a seam
+                assert np.abs(st['poses'][lens[0] - 1].cpu().numpy() - post['poses'][0, lens[0] - 1].cpu().numpy()).max() > 1e-3
+    path = P.save_smplx_npz(str(tmp_path), 'a person walks. fast/slow', pred.cuda(), lens, mean, std)
+    z = np.load(path)
+    assert z['poses'].shape == (sum(lens), 165)
+    pose, expr, trans = PO.t2m_result(PO.denormalise([pred[b, :n].numpy() for b, n in enumerate(lens)], mean, std))
+    assert np.abs(z['poses'] - pose).max() <= 1e-9 and np.abs(z['trans'] - trans).max() <= 1e-9
     path = P.save_smplx_npz(str(tmp_path), 'a person walks. fast/slow', pred[:1].cuda(), [120], mean, std)
     assert os.path.basename(path) == 'res_a_person_walks_fast_slow_120.npz'
     z = np.load(path)

@@ -76,6 +76,23 @@ def test_small_ddpm_truncated():
         assert float((traj[n][1] - T_(ref)).abs().max()) <= 1e-5
 
 
+def test_pre_seq_and_transl_req_seeding_against_reference_golden():
+    """p_sample :664-674 / ddim_sample :816-820: the oracle's seeded loops vs the reference's own (preseq_small.npz)."""
+    g = load('preseq_small.npz')
+    sd = W.make_state_dict(SMALL, SMALL_SEED)
+    x_T, xf, mask, pre = T_(g['x_T']), T_(g['xf_out']), T_(g['motion_mask']), T_(g['pre_seq'])
+    transl = [[int(r[0]), float(r[1]), float(r[2])] for r in g['transl_req']]
+    traj = []
+    torch.manual_seed(int(g['ddpm_seed']))
+    O.sample_loop(sd, SMALL, O.Schedule(1000, None), 'ddpm', x_T, xf, mask, num_steps=12, trajectory=traj, pre_seq=pre,
+                  transl_req=transl)
+    for n, ref in zip(range(3, 12, 4), g['ddpm_traj']):
+        assert float((traj[n][1] - T_(ref)).abs().max()) <= 1e-5
+    torch.manual_seed(int(g['ddim_seed']))
+    out = O.sample_loop(sd, SMALL, O.Schedule(1000, '15,15,8,6,6'), 'ddim', x_T, xf, mask, pre_seq=pre)
+    assert float((out - T_(g['ddim_final'])).abs().max()) <= 1e-5
+
+
 def test_full_size_denoise_against_golden():
     g = load('full_denoise.npz')
     sd = W.make_state_dict(FULL, 0)
