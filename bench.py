@@ -37,9 +37,25 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 TOTAL_DDPM_STEPS = 1000
-# HBM bytes of one B=64 step from rocprofv3 PMC passes (cannot be collected from inside this process);
-# re-measured when the kernel schedule changes: profiles/r01_pmc_hbm_traffic.txt
-MEASURED_HBM_GB_PER_STEP_B64 = 30.75
+
+
+def measured_hbm_traffic():
+    """HBM bytes of one B=64 step.  PMC counters cannot be collected from inside this process, so the number is READ from the
+    newest tracked rocprofv3 summary profiles/rNN_pmc_hbm_traffic.txt (two separate --pmc passes, FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, written by tools/hbm_traffic.py; its header names the command and the commit it was taken
+    at).  Returns (GB per step or None, source file)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.txt')))
+    if not files:
+        return None, None
+    src = files[-1]
+    m = None
+    for line in open(src):
+        mm = re.match(r'# per denoising step .*= ([0-9.]+) GB', line)
+        if mm:
+            m = mm
+    return (float(m.group(1)) if m else None), os.path.relpath(src, ROOT)
 
 DIMS = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77, E=16, topk=2,
             scale=6.5)
@@ -117,6 +133,7 @@ def main():
     ap.add_argument('--frames', type=int, default=196)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the side measurements (dominant-kernel probe, 2 batches in flight)')
+    ap.add_argument('--no-full-loop', action='store_true', help='skip the complete 1000-step loop (measured-vs-extrapolated check, ~20 s)')
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for plumbing smoke tests")
     a = ap.parse_args()
 
@@ -199,6 +216,19 @@ def main():
     t_loop = time.perf_counter() - t0
     ev_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
 
+    # ---- the COMPLETE loop once, outside the K-step region: x_T -> x_0 over all 1000 steps, every step index used once
+    # (`value` extrapolates 1000 * t_step from the K timed steps; this is the measured counterpart) ----
+    t_full = None
+    if not a.no_full_loop:
+        x.normal_(generator=gen)
+        barrier()
+        t0 = time.perf_counter()
+        for j in range(TOTAL_DDPM_STEPS - 1, -1, -1):
+            one_step(j)
+        barrier()
+        t_full = time.perf_counter() - t0
+        assert bool(torch.isfinite(x).all()), 'the 1000-step loop produced non-finite poses'
+
     # ---- finish: all-gather of the finished sequences (RCCL) ----
     barrier()
     t0 = time.perf_counter()
@@ -270,15 +300,23 @@ def main():
         c2[0].close()
         c2[1].close()
 
-    t = torch.tensor([t_loop, t_setup, t_gather, ev_ms], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
+    t = torch.tensor([t_loop, t_setup, t_gather, ev_ms, t_full or 0.0], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_loop, t_setup, t_gather, ev_ms = (float(v) for v in t)
+    t_loop, t_setup, t_gather, ev_ms, t_full_max = (float(v) for v in t)
     t_step = t_loop / a.steps
     value = GB * T / (t_setup + TOTAL_DDPM_STEPS * t_step + t_gather)
 
     if rank == 0:
         flops_step = algorithmic_flops_per_sample_step(DIMS, T) * B
+        traffic_gb, traffic_src = measured_hbm_traffic()
+        full_loop = None
+        if t_full is not None:
+            v_meas = GB * T / (t_setup + t_full_max + t_gather)
+            full_loop = {'loop_s': round(t_full_max, 3), 'value_measured': round(v_meas, 2), 'value_extrapolated': round(value, 2),
+                         'measured_over_extrapolated': round(v_meas / value, 4),
+                         'note': 'complete 1000-step loop run once after the timed region (x_T -> x_0, max over ranks); '
+                                 '`value` uses the K timed steps as the contract asks'}
         ach = flops_step / (ev_ms * 1e-3) / 1e12
         line = {
             'metric': 'sampled SMPL-X frames/sec (196-frame seq, 1000-step DDPM)',
@@ -291,14 +329,15 @@ def main():
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
+                       'full_loop': full_loop,
                        'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
                        'exact_reductions': 'results equal the unreduced computation (tests/test_gpu_parity.py): CFG twins of base layer 0 '
                                            'share gate / expert / proj / qkv / body work (identical inputs); the last StylizationBlock '
                                            'Linear + affine pose decoder run once on the CFG-combined rows; FLOPs in `roofline` are '
                                            'counted as the reference performs them (DESIGN.md section 4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': MEASURED_HBM_GB_PER_STEP_B64 if (B, T) == (64, 196) else None,
-                         'traffic_unit': 'GB per step (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate PMC passes; profiles/r01_pmc_hbm_traffic.txt)',
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic_gb if (B, T) == (64, 196) else None,
+                         'traffic_unit': f'GB per step, read from {traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction)',
                          'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_dma_k fp32 MFMA GEMMs)',
                          'algorithmic_gflop_per_sample_step': round(algorithmic_flops_per_sample_step(DIMS, T) / 1e9, 3),
                          'event_ms_per_step': round(ev_ms, 4), 'dominant_kernel': dom},

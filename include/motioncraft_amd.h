@@ -123,6 +123,15 @@ int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
 /* tests: keep the routing decisions (expert ids, combine weights; 0 = dropped) of every layer of the
  * last mc_denoise call in buffers "cap_idx" / "cap_w" */
 int mc_ctx_enable_capture(mc_ctx* c);
+/* tutel boundary (parity unpinned): order of tokens with EXACTLY equal importance (max gate score) at an
+ * expert's capacity cut.  tutel ranks by `importance_scores.argsort(dim=0)` -- not a stable sort, so the order of ties is
+ * implementation-defined there.  MC_TIE_STABLE (default): lower token index first (what a stable sort / radix sort
+ * gives; oracle/tutel_restated.py TIE_POLICY='stable'); MC_TIE_REVERSE: higher index first.  One switch in the kernel
+ * and one in the oracle, so a golden from a real tutel install can be matched without kernel work.  Call before
+ * mc_ctx_set_condition (the hoisted text K/V are routed too). */
+#define MC_TIE_STABLE 0
+#define MC_TIE_REVERSE 1
+int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy);
 int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t num_steps, void* stream);
 int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_dev, void* stream);
 /* control condition (ControlT2MHalf.forward_c + controlnet[0].before_proj, controlnet.py:186-199, 66):

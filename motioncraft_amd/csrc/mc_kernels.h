@@ -90,6 +90,7 @@ struct RouteBufs {
     int* tile_group; int* tile_row0; int* tile_nrows;   // [2][max_tiles] (one map per slot group)
     int* state;        // small int block, layout in mc_route.hip
     int max_tiles;
+    uint32_t tie_xor = 0xFFFFFFFFu;   // order of equal-importance tokens at the capacity cut: ~0 = lower index first (stable), 0 = higher first
 };
 size_t mc_route_state_ints(int E);
 // proj [N][256] (cosine_projector output incl. bias) -> idx/gate/key + per-expert choice counts

@@ -492,7 +492,8 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     // The two CFG halves enter base layer 0 with the same residual stream (the pose encoder output is written to
     // both, stmogen.py:736-740), so gate scores and expert outputs of token i + N/2 equal those of token i:
     // gate and experts run on the first half only, routing still ranks all N tokens ("twin" mode, mc_route.hip).
-    const bool twin = twin_ok && fused_gate && mc_chain_enabled(2) && mc_chain_enabled(4) && (c->N % 2 == 0);
+    const bool twin = twin_ok && fused_gate && mc_chain_enabled(2) && mc_chain_enabled(4) && (c->N % 2 == 0) &&
+                      c->rb.tie_xor == 0xFFFFFFFFu;   // (the dedupe relies on a twin ranking right behind its original: stable tie order)
     if (fused_gate) {
         GateArgs ga;
         ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
@@ -729,6 +730,14 @@ void mc_ctx_destroy(mc_ctx* c) {
 }
 
 int64_t mc_ctx_workspace_bytes(const mc_ctx* c) { return c ? c->bytes : 0; }
+
+int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy) {
+    MC_REQUIRE(c, "null context");
+    MC_REQUIRE(policy == MC_TIE_STABLE || policy == MC_TIE_REVERSE, "tie policy %d (MC_TIE_STABLE or MC_TIE_REVERSE)", policy);
+    c->rb.tie_xor = policy == MC_TIE_STABLE ? 0xFFFFFFFFu : 0u;
+    c->have_cond = false;      // the hoisted text K/V were routed under the previous policy: set the condition again
+    return MC_OK;
+}
 
 int mc_ctx_enable_capture(mc_ctx* c) {
     MC_REQUIRE(c, "null context");

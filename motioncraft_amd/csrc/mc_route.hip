@@ -43,8 +43,11 @@ enum {
     ST_TOTAL = ST_HIST + MAXP * 256
 };
 
-__device__ __forceinline__ unsigned long long composite(uint32_t key, uint32_t tok) {
-    return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tok);
+// tie_xor = 0xFFFFFFFF: among tokens of EQUAL importance the lower token index ranks first (a stable sort by descending
+// score, what oracle/tutel_restated.py restates); tie_xor = 0: the higher index ranks first (the mirror order an
+// implementation-defined, non-stable argsort could produce) -- RouteBufs::tie_xor, mc_ctx_set_tie_policy
+__device__ __forceinline__ unsigned long long composite(uint32_t key, uint32_t tok, uint32_t tie_xor) {
+    return ((unsigned long long)key << 32) | (unsigned long long)(tok ^ tie_xor);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -134,7 +137,7 @@ __global__ void route_init_k(int* __restrict__ state, int E, int capacity, int c
 // one radix pass (byte `pass` from the top of the 64-bit composite key)
 // (idx / gate / key hold the first Nsrc tokens; token tok >= Nsrc is the twin of tok - Nsrc: same scores, own index)
 __global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx, const uint32_t* __restrict__ key,
-                                                    long N, long Nsrc, int* __restrict__ state, int pass) {
+                                                    long N, long Nsrc, int* __restrict__ state, int pass, uint32_t tie_xor) {
     if (state[ST_ANY] == 0) return;
     __shared__ int h[MAXP * 256];
     __shared__ int s_act[MAXP];
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void route_hist_k(const int* __restrict__ idx,
         const long ts = tok >= Nsrc ? tok - Nsrc : tok;
         const int p = (int)(a & 1) * MAXE + idx[2 * ts + (a & 1)];
         if (s_act[p] != 1) continue;
-        const unsigned long long V = composite(key[ts], (uint32_t)tok);
+        const unsigned long long V = composite(key[ts], (uint32_t)tok, tie_xor);
         if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
         atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
     }
@@ -244,7 +247,7 @@ __global__ void route_plan_k(int* __restrict__ state, int E, int* __restrict__ t
 // keep/drop + combine weights + per-expert kept counts
 __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                     const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
-                                                    float* __restrict__ comb_w, int* __restrict__ state) {
+                                                    float* __restrict__ comb_w, int* __restrict__ state, uint32_t tie_xor) {
     __shared__ int s_act[MAXP];
     __shared__ unsigned long long s_thr[MAXP];
     __shared__ int s_kept[2 * MAXE];
@@ -263,10 +266,10 @@ __global__ __launch_bounds__(256) void route_keep_k(const int* __restrict__ idx,
         const int p = (int)(a & 1) * MAXE + e;
         bool keep = true;
         if (s_act[p] == -1) keep = false;
-        else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok) >= s_thr[p];
+        else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok, tie_xor) >= s_thr[p];
         comb_w[a] = keep ? gate[as] : 0.f;
         if (tok >= Nsrc && s_act[p] == 1) {          // twin mode: would the original (same key, smaller index) decide differently?
-            const bool keep_orig = composite(key[ts], (uint32_t)ts) >= s_thr[p];
+            const bool keep_orig = composite(key[ts], (uint32_t)ts, tie_xor) >= s_thr[p];
             if (keep_orig != keep) state[ST_SPLIT] = 1;
         }
         if (keep && tok < Nsrc) atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + e], 1);   // expert slots exist for the first Nsrc tokens only
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
                                                               int E, int capacity, int cnt_mul, float* __restrict__ comb_w,
                                                               int* __restrict__ state, int* __restrict__ src_row,
                                                               int* __restrict__ dst_row, int* __restrict__ tile_group,
-                                                              int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles) {
+                                                              int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles,
+                                                              uint32_t tie_xor) {
     __shared__ int h[MAXP * 256];
     __shared__ int s_act[MAXP], s_rank[MAXP];
     __shared__ unsigned long long s_pre[MAXP];
@@ -350,9 +354,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
     if (s_any) {
         for (int pass = 0; pass < 8; ++pass) {                   // radix select, one byte per pass (route_hist_k + pick)
             if (pass == 4 || pass == 5) {
-                // token indices are < 2^16 here (<= 32768 pairs), so the two upper bytes of ~token are 0xFF for every key:
-                // the pass cannot split the candidates, append the byte and go on (rank unchanged)
-                if (tid < MAXP && s_act[tid] == 1) s_pre[tid] = (s_pre[tid] << 8) | 0xFFull;
+                // token indices are < 2^16 here (<= 32768 pairs), so the two upper bytes of (token ^ tie_xor) are those of
+                // tie_xor for every key: the pass cannot split the candidates, append the byte and go on (rank unchanged)
+                if (tid < MAXP && s_act[tid] == 1) s_pre[tid] = (s_pre[tid] << 8) | (unsigned long long)((tie_xor >> (pass == 4 ? 24 : 16)) & 0xFFu);
                 __syncthreads();
                 continue;
             }
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
                 const long ts = tok >= Nsrc ? tok - Nsrc : tok;
                 const int p = (int)(a & 1) * MAXE + idx[2 * ts + (a & 1)];
                 if (s_act[p] != 1) continue;
-                const unsigned long long V = composite(key[ts], (uint32_t)tok);
+                const unsigned long long V = composite(key[ts], (uint32_t)tok, tie_xor);
                 if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
                 atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
             }
@@ -404,10 +408,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
         const int p = (int)(a & 1) * MAXE + e;
         bool keep = true;
         if (s_act[p] == -1) keep = false;
-        else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok) >= s_pre[p];
+        else if (s_act[p] == 1) keep = composite(key[ts], (uint32_t)tok, tie_xor) >= s_pre[p];
         comb_w[a] = keep ? gate[as] : 0.f;
         if (tok >= Nsrc && s_act[p] == 1) {
-            const bool keep_orig = composite(key[ts], (uint32_t)ts) >= s_pre[p];
+            const bool keep_orig = composite(key[ts], (uint32_t)ts, tie_xor) >= s_pre[p];
             if (keep_orig != keep) s_split = 1;
         }
         if (keep && tok < Nsrc) atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + e], 1);
@@ -484,10 +488,11 @@ int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* lo
 // gsplit: tokens >= gsplit form slot group 1 (own slot ranges and tile map at [max_tiles, 2 max_tiles)); >= N: one group.
 int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBufs rb, hipStream_t s) {
     MC_REQUIRE(Nsrc == N || 2 * Nsrc == N, "route: Nsrc=%ld must be N or N/2 (N=%ld)", Nsrc, N);
+    MC_REQUIRE(Nsrc == N || rb.tie_xor == 0xFFFFFFFFu, "route: the twin mode needs the stable tie order (a twin must rank right behind its original)");
     if (2 * N <= route_small_pairs()) {
         hipLaunchKernelGGL(route_small_k, dim3(1), dim3(SMALL_THREADS), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity,
                            (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,
-                           rb.max_tiles);
+                           rb.max_tiles, rb.tie_xor);
         MC_LAUNCH_CHECK();
         return MC_OK;
     }
@@ -496,9 +501,9 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, Nsrc, rb.state, pass);
+        hipLaunchKernelGGL(route_hist_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.key, N, Nsrc, rb.state, pass, rb.tie_xor);
     }
-    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state);
+    hipLaunchKernelGGL(route_keep_k, dim3(blocks), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, rb.comb_w, rb.state, rb.tie_xor);
     // (planning inside the keep kernel's last workgroup was measured slower: 39 us vs 10 + 14 for the two launches)
     hipLaunchKernelGGL(route_plan_k, dim3(1), dim3(256), 0, s, rb.state, E, rb.tile_group, rb.tile_row0, rb.tile_nrows,
                        rb.max_tiles);

@@ -44,15 +44,19 @@ def _bcast(t, src):
         dist.broadcast(t, src=src)
 
 
-def broadcast_condition(xf_out, motion_mask, src=0):
-    """Rank `src` holds the condition of the GLOBAL batch; every rank returns its own slice.
-    Tensors on other ranks only need the right shape/dtype/device (contents are overwritten)."""
-    if not is_dist():
-        return xf_out, motion_mask
-    _bcast(xf_out, src)
-    _bcast(motion_mask, src)
-    lo, hi = shard_range(xf_out.shape[0])
-    return xf_out[lo:hi].contiguous(), motion_mask[lo:hi].contiguous()
+def broadcast_condition(xf_out, motion_mask, src=0, c=None):
+    """Rank `src` holds the frozen condition embeddings of the GLOBAL batch; every rank returns its own slice.
+    Tensors on other ranks only need the right shape/dtype/device (contents are overwritten).
+    ``c``: the control condition of the S2G / M2D / mixed configs (encoded audio [B, Tc, D] = 1.2 MB per sample at 196
+    frames, or the raw music features [B, Tc, 35]); with it the return value is (xf, mask, c)."""
+    if is_dist():
+        for t in (xf_out, motion_mask) + ((c,) if c is not None else ()):
+            _bcast(t, src)
+        lo, hi = shard_range(xf_out.shape[0])
+        xf_out, motion_mask = xf_out[lo:hi].contiguous(), motion_mask[lo:hi].contiguous()
+        if c is not None:
+            c = c[lo:hi].contiguous()
+    return (xf_out, motion_mask) if c is None else (xf_out, motion_mask, c)
 
 
 def gather_results(local):
@@ -70,13 +74,15 @@ def gather_results(local):
     return out.to(local.device)
 
 
-def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, **kwargs):
+def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, c=None, **kwargs):
     """Shard a global batch over the ranks, sample each shard through `arch` (MotionDiffusion
     mirror) and all-gather the poses.  `noise` / `step_noise` are GLOBAL tensors / callables
     returning global tensors (parity definition of SURVEY.md section 8e: each rank must match the
-    oracle run on its shard alone)."""
+    oracle run on its shard alone).  `c` = GLOBAL control condition (ControlT2MHalf), sharded like the batch."""
     lo, hi = shard_range(motion.shape[0])
     sl = slice(lo, hi)
+    if c is not None:
+        kwargs['c'] = c[sl]
     inf = dict(kwargs.pop('inference_kwargs', {}))
     if noise is not None:
         inf['noise'] = noise[sl]

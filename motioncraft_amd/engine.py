@@ -86,6 +86,12 @@ class NativeContext:
         """Keep every layer's routing decisions of the last denoise call (tests)."""
         _lib.check(self.lib.mc_ctx_enable_capture(self.handle), 'mc_ctx_enable_capture')
 
+    def set_tie_policy(self, policy):
+        """'stable' (default) or 'reverse': order of equal-importance tokens at a capacity cut (tutel boundary, a16).
+        Call before set_condition."""
+        code = {'stable': 0, 'reverse': 1}[policy]
+        _lib.check(self.lib.mc_ctx_set_tie_policy(self.handle, code), 'mc_ctx_set_tie_policy')
+
     def routing(self, layer):
         """(expert ids [N,2] long, keep [N,2] bool) of `layer` from the last denoise call, on CPU."""
         idx = self.buffer('cap_idx', layer, dtype=torch.int32).view(-1, 2).cpu().long()

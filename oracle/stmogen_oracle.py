@@ -213,9 +213,11 @@ def control_forward_c(p, c, T):
     return c_new
 
 
-def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_num, condition_cfg=True, cap=None):
+def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_num, condition_cfg=True, cap=None,
+                    forced_routing=None):
     """ControlT2MHalf.forward + forward_test (controlnet.py:201-266, 340-424) with a condition `c`
-    [B, Tc, cond_feats]; `p` uses the wrapper's key names (base_model.* / controlnet.* / control_cond_input.*)."""
+    [B, Tc, cond_feats]; `p` uses the wrapper's key names (base_model.* / controlnet.* / control_cond_input.*).
+    ``forced_routing`` / ``cap['routing'][slot]``: per layer slot, base layers 0..NL-1 first, control copy j at NL + j."""
     B, T, C = x_t.shape
     L, H, NL = dims['L'], dims['H'], dims['NL']
     D = L * H
@@ -230,11 +232,18 @@ def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_nu
     xf2, emb2 = xf_out.repeat(2, 1, 1), emb.repeat(2, 1)
     mask2 = motion_mask.reshape(B, T).repeat(2, 1)
 
-    def layer(pp, pre, x):
-        x = stma(pp, pre + 'ca_block.', x, xf2, emb2, mask2, cond, dims)
+    if cap is not None:
+        cap['routing'] = {}
+
+    def layer(pp, pre, x, slot):
+        lcap = {} if cap is not None else None
+        x = stma(pp, pre + 'ca_block.', x, xf2, emb2, mask2, cond, dims, cap=lcap,
+                 forced=None if forced_routing is None else forced_routing[slot])
+        if cap is not None:
+            cap['routing'][slot] = lcap['routing']
         return sffn(pp, pre + 'ffn.', x, emb2, dims)
 
-    h = layer(pb, 'temporal_decoder_blocks.0.', h)
+    h = layer(pb, 'temporal_decoder_blocks.0.', h, 0)
     cc = cc.repeat(2, 1, 1)
     if condition_cfg:
         cc = cc * cond
@@ -243,15 +252,15 @@ def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_nu
         pre = f'controlnet.{j}.'
         if j == 0:                                                      # ControlT2MBlock.forward (controlnet.py:53-88)
             cc = F.linear(cc, p[pre + 'before_proj.weight'], p[pre + 'before_proj.bias'])
-            cc = layer(p, pre + 'copied_block.', h + cc)
+            cc = layer(p, pre + 'copied_block.', h + cc, NL + j)
         else:
-            cc = layer(p, pre + 'copied_block.', cc)
+            cc = layer(p, pre + 'copied_block.', cc, NL + j)
         c_skip = F.linear(cc, p[pre + 'after_proj.weight'], p[pre + 'after_proj.bias'])
         if cap is not None:
             cap[f'c_skip{j}'] = c_skip
-        h = layer(pb, f'temporal_decoder_blocks.{index}.', h + c_skip)
+        h = layer(pb, f'temporal_decoder_blocks.{index}.', h + c_skip, index)
     for index in range(copy_blocks_num + 1, NL):
-        h = layer(pb, f'temporal_decoder_blocks.{index}.', h)
+        h = layer(pb, f'temporal_decoder_blocks.{index}.', h, index)
     out = pose_decoder(pb, h, L, C, dims.get('dataset', 'motionx')).view(2 * B, T, -1)
     if cap is not None:
         cap['out2'] = out

@@ -59,6 +59,22 @@ def capacity_of(num_tokens, num_experts, top_k, capacity_factor):
     return top_k * int(capacity_factor * ((num_tokens + num_experts - 1) // num_experts))
 
 
+# Order of tokens with EXACTLY equal importance in the batch-prioritised ranking.  tutel calls
+# ``importance_scores.argsort(dim=0)`` (not stable: the order of ties is implementation-defined).  'stable' = lower token
+# index first (what torch's CPU sort and the CUDA radix sort produce in practice); 'reverse' = higher index first.
+# The HIP path has the same switch (mc_ctx_set_tie_policy); tests run both.
+TIE_POLICY = 'stable'
+
+
+def _importance_order(importance):
+    if TIE_POLICY == 'stable':
+        return torch.argsort(importance, dim=0, stable=True)
+    if TIE_POLICY == 'reverse':
+        n = importance.shape[0]
+        return (n - 1) - torch.argsort(importance.flip(0), dim=0, stable=True)
+    raise ValueError(f'unknown TIE_POLICY {TIE_POLICY!r}')
+
+
 def extract_critical(scores, top_k, capacity_factor, batch_prioritized_routing=True):
     """indices_s, locations_s, gates_s, capacity  (tutel fast_dispatch.extract_critical,
     normalize_gate=True)."""
@@ -72,7 +88,7 @@ def extract_critical(scores, top_k, capacity_factor, batch_prioritized_routing=T
 
     if batch_prioritized_routing:
         importance = -1 * scores.max(dim=1)[0]
-        order = torch.argsort(importance, dim=0, stable=True)
+        order = _importance_order(importance)
         inv = torch.argsort(order, dim=0, stable=True)
         compute_location = lambda m: (torch.cumsum(m[order], dim=0) - 1)[inv]
     else:

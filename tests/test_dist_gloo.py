@@ -24,11 +24,13 @@ def _free_port():
 class FakeArch:
     """Stands in for MotionDiffusion: pred = f(noise, xf, mask) per sample (no cross-sample coupling)."""
 
-    def __call__(self, motion, motion_mask, motion_length, xf_out, inference_kwargs, **kw):
+    def __call__(self, motion, motion_mask, motion_length, xf_out, inference_kwargs, c=None, **kw):
         x = inference_kwargs['noise']
         for n in inference_kwargs.get('step_noise', []):
             x = 0.5 * x + 0.1 * n
         pred = x * motion_mask.unsqueeze(-1) + xf_out.mean(dim=(1, 2)).view(-1, 1, 1)
+        if c is not None:
+            pred = pred + c.mean(dim=(1, 2)).view(-1, 1, 1)
         return [{'pred_motion': pred[i]} for i in range(pred.shape[0])]
 
 
@@ -42,15 +44,17 @@ def _worker(rank, ws, port, q):
         steps = [torch.randn(B, T, C, generator=g) for _ in range(3)]
         xf_src = torch.randn(B, 4, 3, generator=g)
         mask_src = (torch.rand(B, T, generator=g) > 0.3).float()
+        c_src = torch.randn(B, 5, 7, generator=g)          # control condition (S2G / M2D / mixed configs)
         # rank 0 owns the condition; other ranks start from garbage and must receive it
         xf = xf_src.clone() if rank == 0 else torch.full_like(xf_src, float('nan'))
         mask = mask_src.clone() if rank == 0 else torch.zeros_like(mask_src)
+        c = c_src.clone() if rank == 0 else torch.full_like(c_src, float('nan'))
         lo, hi = mcd.shard_range(B)
         assert (lo, hi) == (rank * B // ws, (rank + 1) * B // ws)
-        xs, ms = mcd.broadcast_condition(xf, mask, src=0)
-        assert torch.equal(xs, xf_src[lo:hi]) and torch.equal(ms, mask_src[lo:hi])
-        out = mcd.sample_sharded(FakeArch(), torch.zeros(B, T, C), mask, xf, noise=noise, step_noise=steps)
-        ref = FakeArch()(None, mask_src, None, xf_src, dict(noise=noise, step_noise=steps))
+        xs, ms, cs = mcd.broadcast_condition(xf, mask, src=0, c=c)
+        assert torch.equal(xs, xf_src[lo:hi]) and torch.equal(ms, mask_src[lo:hi]) and torch.equal(cs, c_src[lo:hi])
+        out = mcd.sample_sharded(FakeArch(), torch.zeros(B, T, C), mask, xf, noise=noise, step_noise=steps, c=c)
+        ref = FakeArch()(None, mask_src, None, xf_src, dict(noise=noise, step_noise=steps), c=c_src)
         ref = torch.stack([r['pred_motion'] for r in ref])
         q.put((rank, bool(torch.equal(out, ref)), tuple(out.shape)))
     finally:

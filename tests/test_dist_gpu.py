@@ -1,0 +1,101 @@
+"""GPU (one MI355X), world_size 2: the REAL sampling path under two ranks.
+
+Both ranks run on device 0 (a lease has one GPU; collectives go through gloo with host staging, exactly the code path
+`bench.py --backend gloo` takes), each with its own NativeModel / context, through `motioncraft_amd.dist.sample_sharded`
+-> MotionDiffusion.forward -> ddim_sample_loop -> libmotioncraft_amd.so.  Parity definition for W > 1: every rank equals
+the CPU oracle run on ITS shard alone (the MoE capacity couples the samples of a rank's batch only, like the
+reference's DDP evaluation, tools/test.py:107-113), and the all-gather equals the concatenation of the shards.
+The control condition `c` travels with the broadcast (BASELINE configs[2]-[4])."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NSTEPS = 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    try:
+        import motioncraft_amd as mc
+        from motioncraft_amd import dist as mcd
+        from helpers import CTRL, CTRL_COPY, CTRL_FEATS, SMALL_SEED
+        from oracle import stmogen_oracle as O, weights as W
+        dims, B, T, Tc = CTRL, 4, 24, 20
+        sd = W.make_state_dict(dims, SMALL_SEED, shapes=W.control_param_shapes(dims, CTRL_COPY, CTRL_FEATS))
+        cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+        cfg.model.model.num_layers = 3
+        cfg.merge_from_dict({'condition_encode_cfg': dict(dataset_name='nothing', condition_pre_encode=False,
+                                                          condition_pre_encode_type='nothing', control_cond_feats=CTRL_FEATS,
+                                                          condition_latent_dim=dims['L'] * dims['H'], condition_cfg=True)})
+        arch = mc.build_architecture(cfg.model)
+        arch.model = mc.ControlT2MHalf(arch.model, copy_blocks_num=CTRL_COPY, control_cond_feats=CTRL_FEATS, cfg=cfg)
+        arch.load_state_dict({'model.' + k: v for k, v in sd.items()})
+        g = torch.Generator().manual_seed(3)
+        x_T = torch.randn(B, T, dims['input_feats'], generator=g)
+        steps = [torch.randn(B, T, dims['input_feats'], generator=g) for _ in range(NSTEPS)]
+        xf_src = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],))
+        mask_src = torch.ones(B, T)
+        mask_src[1, 19:] = 0
+        mask_src[2, 15:] = 0
+        c_src = torch.randn(B, Tc, CTRL_FEATS, generator=g)
+        # rank 0 owns the conditions (HBM); the other rank starts from garbage and must receive them
+        dev = torch.device('cuda', 0)
+        own = rank == 0
+        xf = (xf_src if own else torch.full_like(xf_src, float('nan'))).to(dev)
+        mask = (mask_src if own else torch.zeros_like(mask_src)).to(dev)
+        c = (c_src if own else torch.full_like(c_src, float('nan'))).to(dev)
+        lo, hi = mcd.shard_range(B)
+        xs, ms, cs = mcd.broadcast_condition(xf, mask, src=0, c=c)
+        assert torch.equal(xs.cpu(), xf_src[lo:hi]) and torch.equal(ms.cpu(), mask_src[lo:hi]) and torch.equal(cs.cpu(), c_src[lo:hi])
+        S = 50
+        out = mcd.sample_sharded(arch, torch.zeros(B, T, dims['input_feats']), mask.cpu(), xf.cpu(), noise=x_T,
+                                 step_noise=lambda i: steps[S - 1 - i], c=c.cpu(),
+                                 motion_metas=[{'text': ''}] * (hi - lo), inference_kwargs=dict(num_steps=NSTEPS))
+        # the oracle on this rank's shard alone
+        sched = O.Schedule(1000, '15,15,8,6,6')
+        x = x_T[lo:hi]
+        for n in range(NSTEPS):
+            i = S - 1 - n
+            x0 = O.denoise_control(sd, dims, x, sched.timestep_map[i], xf_src[lo:hi], mask_src[lo:hi], c_src[lo:hi], CTRL_COPY)
+            x = O.ddim_step(sched, i, x, x0, steps[n][lo:hi])
+        err = float((out[lo:hi].cpu() - x).abs().max())
+        arch.model.release()
+        q.put((rank, err, tuple(out.shape), out.cpu().double().sum().item(), (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_real_path_on_one_gpu():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort()
+    print('2 ranks on one GPU: per-shard |hip - oracle|', [f'{r[1]:.2e}' for r in res])
+    assert [r[0] for r in res] == [0, 1] and [r[4] for r in res] == [(0, 2), (2, 4)]
+    assert all(r[1] <= 1e-3 for r in res)                       # each rank == the oracle on its shard
+    assert all(r[2] == (4, 24, 322) for r in res)
+    assert res[0][3] == res[1][3]                               # both ranks hold the same gathered tensor

@@ -4,6 +4,7 @@ Tolerances: the north star asks <= 1e-3 abs fp32 on the final pose tensor; singl
 and short trajectories are held to 2e-4 (observed ~1e-5)."""
 import ctypes
 import os
+import time
 
 import numpy as np
 import pytest
@@ -289,10 +290,10 @@ def test_full_size_50_step_ddim_vs_reference_golden(full_model):
     on the HIP path's own x_t with the HIP path's discrete routing decisions and must reproduce
     x_{t-1} within 1e-3 (observed ~5e-6), and the discrete decisions are compared with what the
     oracle would have chosen freely on the same input.  The distance of the final sample to the
-    committed reference golden is reported, not asserted: it is ~6e-6 when the two trajectories
-    never take different routing decisions (most kernel versions) and O(0.5) as soon as the ~1e-5
-    difference between them moves a single token across a capacity boundary at any of the 200
-    routings of the loop."""
+    committed reference golden is asserted (<= 1e-3, observed ~6e-6) whenever the two trajectories
+    never take different routing decisions (every recorded run); it would be O(0.5) as soon as the
+    ~1e-5 difference between them moved a single token across a capacity boundary at any of the
+    200 routings of the loop, which the flip count would show."""
     from motioncraft_amd.diffusion import build_diffusion
     from oracle import stmogen_oracle as O
     sd, nm = full_model
@@ -326,7 +327,9 @@ def test_full_size_50_step_ddim_vs_reference_golden(full_model):
     print(f'50-step DDIM lockstep: worst per-step |hip - oracle| {worst:.2e}; routing flips {flips}; '
           f'final vs reference golden {final_err:.2e}')
     assert worst <= TOL_FINAL
-    assert flips <= 16
+    assert flips <= 2                      # observed: 0 in every recorded run
+    if flips == 0:                         # the north-star assertion: <= 1e-3 on the final 322-d pose tensor vs the reference
+        assert final_err <= TOL_FINAL, final_err
     ctx.close()
 
 
@@ -369,8 +372,139 @@ def test_baseline_batch_64_single_step_vs_oracle(full_model):
         keep_diff = int(((fkeep != forced[i][1]) & (fidx == forced[i][0])).sum())
         dropped = int((~fkeep).sum())
         print(f'layer {i}: dropped {dropped}, expert-id flips {idx_diff}, keep flips {keep_diff} of {npairs} pairs')
-        assert idx_diff <= 1e-4 * npairs and keep_diff <= max(8, 0.02 * dropped)
+        assert idx_diff <= 8 and keep_diff <= 8            # observed 0-4 of 602 112 pairs per layer
     ctx.close()
+
+
+def _routing_flips(free, forced):
+    """(expert-id flips, keep flips among equal ids, dropped pairs) of the free-running oracle vs the HIP decisions."""
+    fidx, fkeep = torch.stack(free['indices'], 1), torch.stack(free['keeps'], 1)
+    idx_diff = int((fidx != forced[0]).sum())
+    keep_diff = int(((fkeep != forced[1]) & (fidx == forced[0])).sum())
+    return idx_diff, keep_diff, int((~fkeep).sum())
+
+
+def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model):
+    """BASELINE.json configs[1] (B=64, T=196, 1000-step DDPM) as a LOOP: the complete 1000-step p_sample loop runs on the
+    device (what bench.py extrapolates from its timed steps), and the CPU oracle walks beside it in lockstep -- from the
+    HIP path's own x_t, with the same noise, teacher-forced to the HIP path's routing decisions:
+
+      * the first 24 consecutive steps and every 100th step down to t = 0, on 8 of the 64 samples (with the discrete
+        decisions forced every token is an independent row, so a sub-batch reproduces the full-batch arithmetic exactly
+        at 1/8 of the CPU time): every x_{t-1} within 1e-3 (north-star tolerance);
+      * at t = 999, 500 and 0 on the FULL batch, where the free-running oracle's own decisions are compared too: at
+        N = 301 056 tokens the scores next to a capacity boundary / the two best experts of a token are ~1e-6 apart, so a
+        handful of the 602 112 (token, choice) pairs per routing legitimately differ (DESIGN.md section 2);
+      * every x_t finite, the statistics of x_t following the oracle's at each full-batch checkpoint."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from oracle import stmogen_oracle as O
+    sd, nm = full_model
+    B, T, S, H = 64, 196, 1000, FULL['H']
+    g = torch.Generator().manual_seed(5)
+    lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(FULL, B, T, seed=41, lengths=lengths)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=S, model_mean_type='start_x', model_var_type='fixed_large'))
+    sched = O.Schedule(S, None)
+    ctx = nm.context(B, T, max_steps=S)
+    ctx.enable_capture()
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    torch.set_num_threads(min(32, os.cpu_count()))
+    sub = torch.arange(0, B, 8)                                   # 8 samples, mixed lengths
+    tf_full = O.precompute_text(sd, xf, FULL)
+    # the text K/V hoist is routed over the whole CFG-doubled condition batch: slice the full-batch result
+    tf_sub = [t.view(2, B, *t.shape[1:])[:, sub].reshape(2 * len(sub), *t.shape[1:]) for t in tf_full]
+    gen = torch.Generator(device='cuda').manual_seed(77)
+    x = x_T.cuda()
+    nxt = torch.empty_like(x)
+    sub_steps = set(range(S - 1, S - 25, -1)) | set(range(0, S, 100))
+    full_steps = {S - 1, 500, 0}
+    worst_sub, worst_full, flips_idx, flips_keep, npairs = 0.0, 0.0, 0, 0, 2 * 2 * B * T * H
+    t0 = time.time()
+    for i in range(S - 1, -1, -1):
+        eps = torch.randn(B, T, 322, device='cuda', generator=gen)
+        chk = i in sub_steps or i in full_steps
+        if chk:
+            x_in = x.cpu()
+        ctx.sample_step(x, i, d.step_coefs(i, 'ddpm', FULL['scale']), eps, x_prev=nxt)
+        x, nxt = nxt, x
+        if i % 50 == 0:
+            assert bool(torch.isfinite(x).all()), i
+        if not chk:
+            continue
+        forced = [ctx.routing(l) for l in range(FULL['NL'])]
+        eps_c, x_c = eps.cpu(), x.cpu()
+        if i in full_steps:
+            cap = {}
+            x0 = O.denoise(sd, FULL, x_in, sched.timestep_map[i], xf, mask, text_feats=tf_full, forced_routing=forced, cap=cap)
+            ref = O.ddpm_step(sched, i, x_in, x0, eps_c)
+            e = maxabs(x_c, ref)
+            worst_full = max(worst_full, e)
+            for l in range(FULL['NL']):
+                a, b, dropped = _routing_flips(cap[f'layer{l}']['routing']['free'], forced[l])
+                flips_idx, flips_keep = flips_idx + a, flips_keep + b
+                assert a <= 8 and b <= 8, (i, l, a, b)               # observed 0-4 of 602 112 pairs
+            assert abs(float(x_c.std()) - float(ref.std())) <= 1e-3 and abs(float(x_c.mean()) - float(ref.mean())) <= 1e-3
+            assert e <= TOL_FINAL, (i, e)
+        else:
+            fsub = [tuple(v.view(2, B, T * H, 2)[:, sub].reshape(-1, 2) for v in f) for f in forced]
+            x0 = O.denoise(sd, FULL, x_in[sub], sched.timestep_map[i], xf[sub], mask[sub], text_feats=tf_sub, forced_routing=fsub)
+            ref = O.ddpm_step(sched, i, x_in[sub], x0, eps_c[sub])
+            e = maxabs(x_c[sub], ref)
+            worst_sub = max(worst_sub, e)
+            assert e <= TOL_FINAL, (i, e)
+    print(f'B=64 complete 1000-step DDPM loop ({time.time() - t0:.0f} s): lockstep |hip - oracle| worst {worst_sub:.2e} over '
+          f'{len(sub_steps - full_steps)} steps x {len(sub)} samples, {worst_full:.2e} over {len(full_steps)} full-batch steps; free-running '
+          f'oracle: expert-id flips {flips_idx}, keep flips {flips_keep} over {len(full_steps) * FULL["NL"]} routings of {npairs} pairs; '
+          f'final x std {float(x.std()):.3f}')
+    assert bool(torch.isfinite(x).all())
+    ctx.close()
+
+
+@pytest.mark.parametrize('case', ['s2g_b32', 'm2d_160_windows'])
+def test_baseline_control_configs_at_their_per_gpu_batches_vs_oracle(case):
+    """BASELINE configs[2] / [3] at the batches one GPU sees, where the MoE capacity actually couples the samples: S2G 0.25b
+    (L=128, 8 layers + 2 control copies) at 256 / 8 = 32 samples x 196 frames with a pre-encoded audio condition, and M2D
+    (L=64, 4 layers + 3 copies, 35-d music features) at 128 sequences x 5 windows / 4 GPUs = 160 windows x 120 frames.
+    One denoiser call through the control branch: teacher-forced oracle within 1e-3, routing flips of the free-running
+    oracle reported and bounded (same two-part parity as the B=64 text-to-motion test)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    if case == 's2g_b32':
+        dims, copy, feats, B, T, Tc = W.default_dims(NL=8), 2, 1536, 32, 196, 196
+    else:
+        dims, copy, feats, B, T, Tc = W.default_dims(L=64, F=256), 3, 35, 160, 120, 120
+    sd = W.make_state_dict(dims, 0, shapes=W.control_param_shapes(dims, copy, feats))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    g = torch.Generator().manual_seed(73)
+    lengths = [int(v) for v in torch.randint(T // 2, T + 1, (B,), generator=g)]
+    x, xf, mask = synth_inputs(dims, B, T, seed=74, lengths=lengths)
+    c = torch.randn(B, Tc, feats, generator=g)
+    ctx = nm.context(B, T, max_steps=1)
+    ctx.enable_capture()
+    ctx.set_timesteps([480])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    ctx.set_control(c.cuda())
+    out2 = ctx.denoise(x.cuda(), 0)
+    assert torch.equal(out2, ctx.denoise(x.cuda(), 0))                 # deterministic
+    w = (1 - (1000 - 480) / 1000) * dims['scale'] + 1
+    got = out2[:B] * w + out2[B:] * (1 - w)
+    NL = dims['NL']
+    forced = {slot: ctx.routing(slot) for slot in range(NL + copy)}
+    torch.set_num_threads(min(32, os.cpu_count()))
+    cap = {}
+    ref = O.denoise_control(sd, dims, x, 480, xf, mask, c, copy, cap=cap, forced_routing=forced)
+    err = maxabs(got, ref)
+    tot_i = tot_k = 0
+    for slot in range(NL + copy):
+        a, b, dropped = _routing_flips(cap['routing'][slot]['free'], forced[slot])
+        tot_i, tot_k = tot_i + a, tot_k + b
+        assert a <= 8 and b <= 8, (slot, a, b)
+    print(f'{case}: B={B} T={T} NL={NL}+{copy}: |hip - oracle (teacher-forced)| {err:.2e}; expert-id flips {tot_i}, keep flips '
+          f'{tot_k} over {NL + copy} routings of {2 * 2 * B * T * dims["H"]} pairs')
+    assert err <= TOL_FINAL
+    ctx.close()
+    nm.close()
 
 
 def test_control_branch_vs_reference_golden():
@@ -855,6 +989,30 @@ def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
     err = maxabs(got, ref)
     print(f'exact ties ({which}): |hip - oracle| {err:.2e}')
     assert err <= TOL_STEP
+    # the other tie policy (a16: tutel's argsort is not stable, the order of equal-importance tokens is implementation-
+    # defined): ONE switch in the kernel (mc_ctx_set_tie_policy) and one in the oracle (TIE_POLICY) -- the higher token
+    # index now ranks first, so the capacity cut keeps the SECOND-half twins and drops the originals
+    from oracle import tutel_restated as TR
+    ctx.set_tie_policy('reverse')
+    with pytest.raises(RuntimeError):          # the hoisted text K/V were routed under the old policy
+        ctx.denoise(x.cuda(), 0)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    out2r = ctx.denoise(x.cuda(), 0)
+    gotr = out2r[:2] * w + out2r[2:] * (1 - w)
+    TR.TIE_POLICY = 'reverse'
+    try:
+        capr = {}
+        refr = O.denoise(sd, dims, x, 333, xf, mask, cap=capr)
+    finally:
+        TR.TIE_POLICY = 'stable'
+    for l in layers:
+        idx, keep = ctx.routing(l)
+        free = capr[f'layer{l}']['routing']['free']
+        assert torch.equal(idx, torch.stack(free['indices'], 1)) and torch.equal(keep, torch.stack(free['keeps'], 1)), l
+        assert bool(keep[N // 2:, 0].any()) and not bool(keep[:N // 2, 0].any())
+    errr = maxabs(gotr, refr)
+    print(f'exact ties ({which}), reverse tie policy: |hip - oracle| {errr:.2e}; |stable - reverse| {maxabs(got, gotr):.2e}')
+    assert errr <= TOL_STEP and maxabs(got, gotr) > 1e-3
     ctx.close()
     nm.close()
 

@@ -1,6 +1,9 @@
 """CPU: the oracle restatement against the committed golden vectors (generated from the
 reference's own modules by tests/golden/make_golden.py)."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import stmogen_oracle as O, tutel_restated as TR, weights as W
@@ -91,6 +94,70 @@ def test_pre_seq_and_transl_req_seeding_against_reference_golden():
     torch.manual_seed(int(g['ddim_seed']))
     out = O.sample_loop(sd, SMALL, O.Schedule(1000, '15,15,8,6,6'), 'ddim', x_T, xf, mask, pre_seq=pre)
     assert float((out - T_(g['ddim_final'])).abs().max()) <= 1e-5
+
+
+def test_moe_tie_policy_switch():
+    """a16: tutel ranks tokens with `importance_scores.argsort(dim=0)` (not stable).  Both orders of exactly tied tokens
+    sit behind one switch; away from ties the policies agree."""
+    torch.manual_seed(1)
+    E, D, N = 4, 8, 64
+    x = torch.randn(N // 2, D).repeat(2, 1)                       # exact duplicates: every token is tied with its twin
+    pw, pb, sim, temp = torch.randn(256, D), torch.randn(256) * 0.1, torch.randn(256, E), torch.tensor([0.7])
+    w1, b1 = torch.randn(E, 4 * D, D) * 0.3, torch.randn(E, 4 * D) * 0.1
+    w2, b2 = torch.randn(E, 4 * D, D) * 0.3, torch.randn(E, D) * 0.1
+    _, rs = TR.moe_forward(x, pw, pb, sim, temp, w1, b1, w2, b2, return_routing=True)
+    TR.TIE_POLICY = 'reverse'
+    try:
+        _, rr = TR.moe_forward(x, pw, pb, sim, temp, w1, b1, w2, b2, return_routing=True)
+        xu = torch.randn(N, D)                                    # no ties: same routing under both policies
+        yu_r, ru_r = TR.moe_forward(xu, pw, pb, sim, temp, w1, b1, w2, b2, return_routing=True)
+    finally:
+        TR.TIE_POLICY = 'stable'
+    yu_s, ru_s = TR.moe_forward(xu, pw, pb, sim, temp, w1, b1, w2, b2, return_routing=True)
+    for i in range(N // 2):
+        assert int(rs['locations'][0][i]) < int(rs['locations'][0][i + N // 2])
+        assert int(rr['locations'][0][i]) > int(rr['locations'][0][i + N // 2])
+    assert all(torch.equal(a, b) for a, b in zip(ru_s['locations'], ru_r['locations'])) and torch.equal(yu_s, yu_r)
+    with pytest.raises(ValueError):
+        TR.TIE_POLICY = 'nope'
+        try:
+            TR.moe_forward(xu, pw, pb, sim, temp, w1, b1, w2, b2)
+        finally:
+            TR.TIE_POLICY = 'stable'
+
+
+def _tutel_dumps():
+    import glob
+    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'tutel_dump_*.npz')))
+
+
+@pytest.mark.parametrize('path', _tutel_dumps(), ids=os.path.basename)
+def test_tutel_moe_dump_fixture(path):
+    """a16 pin, ready for a REAL tutel dump: tools/dump_tutel_moe.py (run where tutel is installed) writes
+    {x, weights, scores, indices, locations, gates, y, capacity, source} of one moe_layer call into
+    tests/golden/tutel_dump_<name>.npz; this test replays it through oracle/tutel_restated.py and reports which tie
+    policy matches.  `tutel_dump_restated.npz` (source='oracle/tutel_restated.py', NOT tutel) only exercises the
+    loader; with it alone the boundary stays PARITY UNPINNED."""
+    g = np.load(path)
+    t = lambda k: torch.from_numpy(np.asarray(g[k]))
+    args = (t('x'), t('proj_w'), t('proj_b'), t('sim_matrix'), t('temperature'), t('fc1_w'), t('fc1_b'), t('fc2_w'), t('fc2_b'))
+    kw = dict(top_k=int(g['top_k']), capacity_factor=float(g['capacity_factor']), batch_prioritized_routing=bool(g['bpr']))
+    matched = []
+    for pol in ('stable', 'reverse'):
+        TR.TIE_POLICY = pol
+        try:
+            y, r = TR.moe_forward(*args, return_routing=True, **kw)
+        finally:
+            TR.TIE_POLICY = 'stable'
+        assert int(r['capacity']) == int(g['capacity'])
+        assert float((r['scores'] - t('scores')).abs().max()) <= 1e-5
+        ok_idx = all(torch.equal(a, b.long()) for a, b in zip(r['indices'], t('indices')))
+        keep_ref = t('locations') < int(g['capacity'])
+        ok_keep = all(torch.equal(a, b) for a, b in zip(r['keeps'], keep_ref))
+        if ok_idx and ok_keep and float((y - t('y')).abs().max()) <= 1e-4:
+            matched.append(pol)
+    print(f'{os.path.basename(path)} (source: {str(g["source"])}): matching tie policies {matched}')
+    assert matched, 'the restated tutel semantics do not reproduce this dump under either tie policy'
 
 
 def test_full_size_denoise_against_golden():
