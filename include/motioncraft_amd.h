@@ -123,6 +123,17 @@ int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
 /* tests: keep the routing decisions (expert ids, combine weights; 0 = dropped) of every layer of the
  * last mc_denoise call in buffers "cap_idx" / "cap_w" */
 int mc_ctx_enable_capture(mc_ctx* c);
+/* MFMA operand precision of the per-step GEMM-shaped kernels of this context (FiLM out_layers GEMMs, expert and SFFN MLPs,
+ * control after_proj): the "fp16 MFMA" mode of BASELINE.json configs[4]; the reference hook is mmcv's wrap_fp16_model
+ * (tools/test.py:95-97).  MC_PREC_F32 (default): exact fp32 MFMA.  MC_PREC_F16: operands rounded to fp16, fp32
+ * accumulate (~2e-4 relative per GEMM stage).  MC_PREC_F16X3: operands split x = hi + lo in fp16, three products
+ * hi*hi + hi*lo + lo*hi accumulated in fp32 -- fp32-class results at 3/16 of the fp32 MFMA time.  The gate, routing,
+ * LayerNorm statistics, softmaxes and all elementwise work stay fp32 in every mode (tutel forces fp32_gate,
+ * st_attention.py:31).  The fp16 weight planes are built once per model on the first call. */
+#define MC_PREC_F32 0
+#define MC_PREC_F16 1
+#define MC_PREC_F16X3 2
+int mc_ctx_set_precision(mc_ctx* c, int32_t precision);
 /* tutel boundary (parity unpinned): order of tokens with EXACTLY equal importance (max gate score) at an
  * expert's capacity cut.  tutel ranks by `importance_scores.argsort(dim=0)` -- not a stable sort, so the order of ties is
  * implementation-defined there.  MC_TIE_STABLE (default): lower token index first (what a stable sort / radix sort
@@ -167,6 +178,9 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
 /* op-level entry points (kernel parity tests call these through the same ABI) */
 int mc_op_gemm(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                float* c_dev, int32_t M, int32_t N, int32_t K, int32_t ldw, int32_t act, void* stream);
+/* C = A W^T + bias + res on the fp16 MFMA (split != 0: hi/lo three-product form); N % 128 == 0, K % 32 == 0; synchronises */
+int mc_op_gemm_f16(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* c_dev,
+                   int32_t M, int32_t N, int32_t K, int32_t split, void* stream);
 int mc_op_ln_rows(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev,
                   const float* add_dev, int32_t add_mod, float* y_dev, int64_t rows, int32_t L, void* stream);
 int mc_op_sampler_update(const float* x_t_dev, const float* out_text_dev, const float* out_none_dev,

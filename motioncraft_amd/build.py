@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmotioncraft_amd.so')
-SOURCES = ['mc_error.cpp', 'mc_gemm.hip', 'mc_kernels.hip', 'mc_route.hip', 'mc_attn.hip', 'mc_chain.hip', 'mc_post.hip', 'mc_wavenc.hip', 'mc_textenc.hip', 'mc_evalenc.hip', 'mc_t2meval.hip', 'mc_model.hip']
+SOURCES = ['mc_error.cpp', 'mc_gemm.hip', 'mc_kernels.hip', 'mc_route.hip', 'mc_attn.hip', 'mc_chain.hip', 'mc_half.hip', 'mc_post.hip', 'mc_wavenc.hip', 'mc_textenc.hip', 'mc_evalenc.hip', 'mc_t2meval.hip', 'mc_model.hip']
 
 
 def _hipcc():

@@ -1,0 +1,396 @@
+// fp16-MFMA variants of the GEMM-shaped kernels (gfx950: v_mfma_f32_32x32x16_f16, fp32 accumulate) -- the reduced-precision
+// mode of BASELINE.json configs[4]; modes and error model in mc_half.h.
+//
+// Fragment layout of v_mfma_f32_32x32x16_f16 (guide section 3): the A operand of lane l is 8 consecutive-k halves of
+// row (l & 31), k = 8 (l >> 5) + 0..7; the B operand the same for column (l & 31); C/D as for every 32x32 MFMA:
+// lane l holds D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r = 0..15.  As in the fp32 kernels the WEIGHT tile is the
+// "A" operand and the activation rows the "B" operand, so a lane owns one output row and 4 consecutive columns per
+// accumulator quad (float4 epilogues), and an accumulator fragment can be chained as the next B operand: its 16
+// values are the k-slots (hf, i), i = 0..7, of two 16-wide k-blocks in the order  k = 16 blk + 4 hf + (i & 3) + 8 (i >> 2)
+// -- a permutation inside each 32-chunk that the second weight matrix is stored in (mc_launch_split_f16_chainperm).
+//
+// LDS tiles are [rows][K + 8] halves: a row stride of 80 / 144 / 272 bytes (20 / 36 / 68 banks) makes the ds_read_b128
+// fragment reads of any 16 distinct rows and the ds_write_b128 staging writes bank-conflict free.
+#include "mc_common.h"
+#include "mc_half.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)a[i];
+        lo[i] = (_Float16)(a[i] - (float)hi[i]);
+        hi[4 + i] = (_Float16)b[i];
+        lo[4 + i] = (_Float16)(b[i] - (float)hi[4 + i]);
+    }
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ f32x16 mma3(const f16x8& wh, const f16x8& wl, const f16x8& xh, const f16x8& xl, f32x16 acc) {
+    if constexpr (SPLIT) {      // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void split_f16_k(const float* __restrict__ x, mc_half* __restrict__ hi, mc_half* __restrict__ lo,
+                                                   long n, int K, int perm) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long src = i;
+        if (perm) {     // position p of a 32-chunk <- source column 16 blk + 4 hf + (i & 3) + 8 (i >> 2)
+            const long r = i / K;
+            const int c = (int)(i % K), q = c & 31, blk = q >> 4, hf = (q >> 3) & 1, j = q & 7;
+            src = r * K + (c - q) + 16 * blk + 4 * hf + (j & 3) + 8 * (j >> 2);
+        }
+        const float v = x[src];
+        const _Float16 h = (_Float16)v;
+        hi[i] = h;
+        if (lo) lo[i] = (_Float16)(v - (float)h);
+    }
+}
+
+// =================================================================================================
+// C = act(A W^T + bias) + R,  128 x 128 x 32 tiles, 4 waves x (2 x 2) MFMA tiles, double-buffered LDS, one barrier per
+// k-tile; A is fp32 in HBM and split while staging (registers -> LDS), W comes pre-split
+// =================================================================================================
+constexpr int HLD = 40;                 // halves per LDS row: 32 + 8 pad
+constexpr int HTILE = 128 * HLD;        // halves per plane tile
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_h_k(GemmHArgs g) {
+    constexpr int P = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 2 * P * HTILE];     // [buf][A | W][plane][128][HLD]: 80 / 40 KB
+    auto tile = [&](int buf, int op, int p) { return smem + ((buf * 2 + op) * P + p) * HTILE; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, frow = lane & 31, hf = lane >> 5;
+    const int ntn = g.N / 128;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * 128, nrows = min(128, g.M - row0);
+    // staging: thread -> 8-column piece sq of rows srow and srow + 64 (A: 8 floats, W: 8 halves per plane)
+    const int sq = tid & 3, srow = tid >> 2;
+    const float* pa[2];
+    const mc_half* pw[P][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int r = min(row0 + srow + 64 * c, g.M - 1);          // rows past M re-read the last row (never stored)
+        pa[c] = g.A + (long)r * g.lda + sq * 8;
+        const long wo = (long)(tn * 128 + srow + 64 * c) * g.K + sq * 8;
+        pw[0][c] = g.Wh + wo;
+        if constexpr (SPLIT) pw[1][c] = g.Wl + wo;
+    }
+    f32x4 ra[2][2];
+    u32x4 rw[P][2];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ra[c][0] = *reinterpret_cast<const f32x4*>(pa[c] + kt * 32);
+            ra[c][1] = *reinterpret_cast<const f32x4*>(pa[c] + kt * 32 + 4);
+#pragma unroll
+            for (int p = 0; p < P; ++p) rw[p][c] = *reinterpret_cast<const u32x4*>(pw[p][c] + kt * 32);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int o = (srow + 64 * c) * HLD + sq * 8;
+            f16x8 hi, lo;
+            split8(ra[c][0], ra[c][1], hi, lo);
+            *reinterpret_cast<f16x8*>(tile(buf, 0, 0) + o) = hi;
+            if constexpr (SPLIT) *reinterpret_cast<f16x8*>(tile(buf, 0, 1) + o) = lo;
+#pragma unroll
+            for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(tile(buf, 1, p) + o) = rw[p][c];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int nk = g.K / 32;
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    const int fo_a = (wm * 64 + frow) * HLD + hf * 8, fo_w = (wn * 64 + frow) * HLD + hf * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        auto kstep = [&](int s) {
+            f16x8 fa[2][P], fw[2][P];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    fa[i][p] = *reinterpret_cast<const f16x8*>(tile(buf, 0, p) + fo_a + i * 32 * HLD + s * 16);
+                    fw[i][p] = *reinterpret_cast<const f16x8*>(tile(buf, 1, p) + fo_w + i * 32 * HLD + s * 16);
+                }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = mma3<SPLIT>(fw[ni][0], fw[ni][P - 1], fa[mi][0], fa[mi][P - 1], acc[mi][ni]);
+        };
+        kstep(0);
+        // staging in the middle of the MFMA stream (as gemm_k): tile kt+1 (requested one iteration ago) -> other buffer,
+        // then tile kt+2 is requested into the same registers
+        if (kt + 1 < nk) store(buf ^ 1);
+        if (kt + 2 < nk) load(kt + 2);
+        kstep(1);
+        __syncthreads();
+    }
+    // epilogue: lane owns row m and 4 consecutive columns per accumulator quad
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = wm * 64 + mi * 32 + frow;
+        if (m >= nrows) continue;
+        float* crow = g.C + (long)(row0 + m) * g.ldc;
+        const float* rrow = g.R ? g.R + (long)(row0 + m) * g.ldr : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tn * 128 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (g.act != ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], g.act);
+                }
+                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+                *reinterpret_cast<f32x4*>(crow + n) = v;
+            }
+    }
+}
+
+// =================================================================================================
+// Fused 2-layer MLP on the fp16 MFMA (structure of mlp2_k, mc_chain.hip): X fragment in VGPRs, hidden in 32-wide chunks
+// whose FC1 accumulator -- bias + exact GELU in fp32, then split -- is directly the B operand of FC2
+// =================================================================================================
+template <int L, int MODE, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void mlp2_h_k(MlpArgs g, const mc_half* __restrict__ W1h, const mc_half* __restrict__ W1l,
+                                                   const mc_half* __restrict__ W2h, const mc_half* __restrict__ W2l) {
+    constexpr int P = SPLIT ? 2 : 1, NKB = L / 16, NT = L / 32, HC = 32;
+    constexpr int LD1 = L + 8, LD2 = HC + 8;            // halves per LDS row of the W1 chunk [32][L] / W2^T chunk [L][32]
+    constexpr int S1 = HC * LD1, S2 = L * LD2, BUF = P * (S1 + S2);
+    constexpr int MAXHID = 1024;
+    constexpr int PC1 = HC * L / 8, PC2 = L * HC / 8;    // 16-byte pieces per plane chunk
+    constexpr int N1 = (PC1 + 255) / 256, N2 = (PC2 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BUF + 2 * MAXHID];
+    float* s_b1 = reinterpret_cast<float*>(smem + 2 * BUF);
+    auto W1s = [&](int b, int p) { return smem + b * BUF + p * S1; };
+    auto W2s = [&](int b, int p) { return smem + b * BUF + P * S1 + p * S2; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5;
+    int grp, row0, nrows;
+    if constexpr (MODE == MLP_EXPERT) {
+        const int real = *g.num_tiles;
+        if ((int)blockIdx.x >= real) return;
+        const int t = xcd_remap(blockIdx.x, real);
+        grp = g.tile_group[t];
+        row0 = g.tile_row0[t];
+        nrows = g.tile_nrows[t];
+    } else {
+        grp = blockIdx.y;
+        row0 = blockIdx.x * 128;
+        nrows = min(128, g.M - row0);
+    }
+    const mc_half* w1p[P];
+    const mc_half* w2p[P];
+    w1p[0] = W1h + (long)grp * g.hidden * L;
+    w2p[0] = W2h + (long)grp * L * g.hidden;
+    if constexpr (SPLIT) {
+        w1p[1] = W1l + (long)grp * g.hidden * L;
+        w2p[1] = W2l + (long)grp * L * g.hidden;
+    }
+    const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
+    const float* __restrict__ b2 = g.b2 + (long)grp * L;
+    for (int i = tid; i < g.hidden; i += 256) s_b1[i] = b1[i];
+
+    u32x4 r1[P][N1], r2[P][N2];
+    auto fetch = [&](int hc) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int i = 0; i < N1; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC1 % 256 == 0 || idx < PC1)
+                    r1[p][i] = *reinterpret_cast<const u32x4*>(w1p[p] + (long)(hc * HC + idx / (L / 8)) * L + (idx % (L / 8)) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < N2; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC2 % 256 == 0 || idx < PC2)
+                    r2[p][i] = *reinterpret_cast<const u32x4*>(w2p[p] + (long)(idx >> 2) * g.hidden + hc * HC + (idx & 3) * 8);
+            }
+        }
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int i = 0; i < N1; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC1 % 256 == 0 || idx < PC1)
+                    *reinterpret_cast<u32x4*>(W1s(b, p) + (idx / (L / 8)) * LD1 + (idx % (L / 8)) * 8) = r1[p][i];
+            }
+#pragma unroll
+            for (int i = 0; i < N2; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC2 % 256 == 0 || idx < PC2) *reinterpret_cast<u32x4*>(W2s(b, p) + (idx >> 2) * LD2 + (idx & 3) * 8) = r2[p][i];
+            }
+        }
+    };
+
+    const int r = wave * 32 + (lane & 31);
+    const bool rok = r < nrows;
+    f16x8 xh[NKB], xl[NKB];
+    {
+        long srow = rok ? row0 + r : row0;
+        if constexpr (MODE == MLP_EXPERT) srow = rok ? g.src_row[row0 + r] : 0;
+        const float* xp = g.X + (long)grp * g.x_gstride + srow * g.ldx + hf * 8;
+        // (rows past nrows read a valid row and are never stored)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * kb), b = *reinterpret_cast<const f32x4*>(xp + 16 * kb + 4);
+            split8(a, b, xh[kb], xl[kb]);
+        }
+    }
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[t][q] = 0.f;
+
+    const int nch = g.hidden / HC;
+    fetch(0);
+    commit(0);
+    if (1 < nch) fetch(1);
+    __syncthreads();
+    const int fo1 = (lane & 31) * LD1 + hf * 8, fo2 = (lane & 31) * LD2 + hf * 8;
+    for (int hc = 0; hc < nch; ++hc) {
+        const int buf = hc & 1;
+        if (hc + 1 < nch) commit(buf ^ 1);
+        if (hc + 2 < nch) fetch(hc + 2);
+        // FC1 chunk: 32 hidden units of this wave's 32 rows
+        f32x16 a1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(W1s(buf, 0) + fo1 + 16 * kb);
+            const f16x8 wl = SPLIT ? *reinterpret_cast<const f16x8*>(W1s(buf, P - 1) + fo1 + 16 * kb) : wh;
+            a1 = mma3<SPLIT>(wh, wl, xh[kb], xl[kb], a1);
+        }
+        // bias + exact GELU in fp32; accumulator registers 0..7 / 8..15 are the two k-blocks of the FC2 B operand
+        f16x8 hh[2], hl[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x4 v[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * blk + qq;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + hc * HC + 8 * q + 4 * hf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[qq][i] = gelu_exact(a1[4 * q + i] + bb[i]);
+            }
+            split8(v[0], v[1], hh[blk], hl[blk]);
+        }
+        // FC2 partial: out[L] += W2t[:, chunk] h
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(W2s(buf, 0) + fo2 + t * 32 * LD2 + 16 * blk);
+                const f16x8 wl = SPLIT ? *reinterpret_cast<const f16x8*>(W2s(buf, P - 1) + fo2 + t * 32 * LD2 + 16 * blk) : wh;
+                acc2[t] = mma3<SPLIT>(wh, wl, hh[blk], hl[blk], acc2[t]);
+            }
+        __syncthreads();
+    }
+    if (!rok) return;
+    long drow = row0 + r;
+    if constexpr (MODE == MLP_EXPERT) drow = g.dst_row[row0 + r];
+    float* yrow = g.Y + (long)grp * g.y_gstride + drow * g.ldy;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = t * 32 + 8 * q + 4 * hf;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + n);
+            const f32x4 v = {acc2[t][4 * q] + bb[0], acc2[t][4 * q + 1] + bb[1], acc2[t][4 * q + 2] + bb[2], acc2[t][4 * q + 3] + bb[3]};
+            *reinterpret_cast<f32x4*>(yrow + n) = v;
+        }
+}
+
+}  // namespace
+
+int mc_launch_split_f16(const float* x, mc_half* hi, mc_half* lo, long n, hipStream_t s) {
+    if (n <= 0) return MC_OK;
+    int blocks = cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_f16_k, dim3(blocks), dim3(256), 0, s, x, hi, lo, n, 1, 0);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_split_f16_chainperm(const float* x, mc_half* hi, mc_half* lo, long rows, int K, hipStream_t s) {
+    MC_REQUIRE(K % 32 == 0, "chain-permuted split: K=%d is not a multiple of 32", K);
+    const long n = rows * K;
+    if (n <= 0) return MC_OK;
+    int blocks = cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_f16_k, dim3(blocks), dim3(256), 0, s, x, hi, lo, n, K, 1);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
+    MC_REQUIRE(g.A && g.Wh && g.C && (!split || g.Wl), "fp16 gemm: null operand");
+    MC_REQUIRE(g.N % 128 == 0 && g.K % 32 == 0 && g.lda % 4 == 0 && g.ldc % 4 == 0 && (!g.R || g.ldr % 4 == 0),
+               "fp16 gemm: unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    if (g.M <= 0) return MC_OK;
+    dim3 grid(cdiv(g.M, 128) * (g.N / 128));
+    if (split) hipLaunchKernelGGL(gemm_h_k<true>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_h_k<false>, grid, dim3(256), 0, s, g);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+bool mc_mlp_h_supported(int L, int hidden) { return (L == 32 || L == 64 || L == 128) && hidden % 32 == 0 && hidden >= 32 && hidden <= 1024; }
+
+int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_half* W1l, const mc_half* W2h, const mc_half* W2l,
+                    bool split, int groups, int max_tiles, hipStream_t s) {
+    MC_REQUIRE(mc_mlp_h_supported(g.L, g.hidden), "fp16 fused mlp: L=%d hidden=%d unsupported", g.L, g.hidden);
+    MC_REQUIRE(g.ldx % 4 == 0 && g.ldy % 4 == 0 && g.x_gstride % 4 == 0 && g.y_gstride % 4 == 0 && g.nsplit == 1, "fp16 fused mlp: strides / nsplit");
+    MC_REQUIRE(W1h && W2h && (!split || (W1l && W2l)), "fp16 fused mlp: null weight plane");
+    dim3 grid;
+    if (mode == MLP_EXPERT) {
+        if (max_tiles <= 0) return MC_OK;
+        grid = dim3(max_tiles, 1, 1);
+    } else {
+        if (g.M <= 0) return MC_OK;
+        grid = dim3(cdiv(g.M, 128), groups, 1);
+    }
+#define MC_MLPH(LL, MM, SS) hipLaunchKernelGGL((mlp2_h_k<LL, MM, SS>), grid, dim3(256), 0, s, g, W1h, W1l, W2h, W2l)
+#define MC_MLPH_CASE(LL)                                                       \
+    case LL:                                                                   \
+        if (mode == MLP_EXPERT) { if (split) MC_MLPH(LL, MLP_EXPERT, true); else MC_MLPH(LL, MLP_EXPERT, false); } \
+        else { if (split) MC_MLPH(LL, MLP_PARTS, true); else MC_MLPH(LL, MLP_PARTS, false); }                      \
+        break;
+    switch (g.L) {
+        MC_MLPH_CASE(128)
+        MC_MLPH_CASE(64)
+        MC_MLPH_CASE(32)
+        default: mc_set_error("fp16 fused mlp: L=%d unsupported", g.L); return MC_ERR_ARG;
+    }
+#undef MC_MLPH_CASE
+#undef MC_MLPH
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

@@ -18,10 +18,17 @@
 #include "mc_gemm.h"
 #include "mc_kernels.h"
 #include "mc_chain.h"
+#include "mc_half.h"
+
+struct HalfW {              // fp16 hi / lo planes of one weight (mc_half.h); lo directly behind hi in one allocation
+    mc_half* hi = nullptr;
+    mc_half* lo = nullptr;
+};
 
 struct mc_model {
     mc_model_config cfg;
     std::map<std::string, std::pair<float*, int64_t>> params;
+    std::map<std::string, HalfW> half;     // built on the first mc_ctx_set_precision(.., MC_PREC_F16*) (shared by all contexts)
     bool finalized = false;
     int Cp = 0;  // input_feats padded to a multiple of 32 (row stride of enc.w and of the padded pose rows)
 };
@@ -40,6 +47,8 @@ struct LayerW {
     const float *ffn_film_w, *ffn_film_b, *ffn_ln_g, *ffn_ln_b, *ffn_out_w, *ffn_out_b;
     // control-branch copies only (ControlT2MBlock): zero-init projections around the copied DecoderLayer
     const float *before_w = nullptr, *before_b = nullptr, *after_w = nullptr, *after_b = nullptr;
+    // fp16 planes of the per-step GEMM weights (reduced-precision mode; null until mc_ctx_set_precision builds them)
+    HalfW h_ca_out, h_ffn_out, h_fc1, h_fc2, h_w1, h_w2, h_after;
 };
 
 struct mc_ctx {
@@ -75,6 +84,7 @@ struct mc_ctx {
     hipStream_t parts[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
     int nparts = 2;
+    int prec = MC_PREC_F32;      // MFMA operand precision of the per-step GEMM-shaped kernels (mc_ctx_set_precision)
     int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
     float* cap_w = nullptr;      // ... and combine weights (0 = dropped) of every layer
 };
@@ -216,6 +226,51 @@ int build_ctx_weights(mc_ctx* c) {
     return MC_OK;
 }
 
+// fp16 hi / lo planes of weight `name` ([rows][K] fp32 on the device), built once per model; chain = K axis stored in the
+// chain-permuted order of mc_half.h (second GEMM of the fused MLP)
+int half_weight(mc_model* m, const std::string& name, long rows, int K, bool chain, HalfW* out) {
+    auto it = m->half.find(name);
+    if (it != m->half.end()) { *out = it->second; return MC_OK; }
+    const float* src = nullptr;
+    int r = get_param(m, name, (int64_t)rows * K, &src);
+    if (r != MC_OK) return r;
+    HalfW h;
+    MC_HIP(hipMalloc((void**)&h.hi, sizeof(mc_half) * 2 * (size_t)rows * K));
+    h.lo = h.hi + (size_t)rows * K;
+    r = chain ? mc_launch_split_f16_chainperm(src, h.hi, h.lo, rows, K, nullptr) : mc_launch_split_f16(src, h.hi, h.lo, rows * K, nullptr);
+    if (r != MC_OK) { (void)hipFree(h.hi); return r; }
+    MC_HIP(hipStreamSynchronize(nullptr));
+    m->half[name] = h;
+    *out = h;
+    return MC_OK;
+}
+
+int bind_half_weights(mc_ctx* c) {
+    mc_model* m = c->m;
+    const mc_model_config& g = m->cfg;
+    const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim, E = g.num_experts;
+    int r;
+    for (int i = 0; i < c->NLA; ++i) {
+        LayerW& w = c->lw[i];
+        const bool is_ctrl = i >= g.num_layers;
+        const std::string p = (is_ctrl ? "c" + std::to_string(i - g.num_layers) : "l" + std::to_string(i)) + ".";
+        if (D % 128 == 0) {
+            if ((r = half_weight(m, p + "ca.out_w", D, D, false, &w.h_ca_out))) return r;
+            if ((r = half_weight(m, p + "ffn.out_w", D, D, false, &w.h_ffn_out))) return r;
+            if (is_ctrl && (r = half_weight(m, p + "after_w", D, D, false, &w.h_after))) return r;
+        }
+        if (mc_mlp_h_supported(L, 4 * L)) {
+            if ((r = half_weight(m, p + "mm.fc1_w", (long)E * 4 * L, L, false, &w.h_fc1))) return r;
+            if ((r = half_weight(m, p + "mm.fc2_wt", (long)E * L, 4 * L, true, &w.h_fc2))) return r;
+        }
+        if (mc_mlp_h_supported(L, F)) {
+            if ((r = half_weight(m, p + "ffn.w1", (long)H * F, L, false, &w.h_w1))) return r;
+            if ((r = half_weight(m, p + "ffn.w2", (long)H * L, F, true, &w.h_w2))) return r;
+        }
+    }
+    return MC_OK;
+}
+
 static long small_gemm_rows() {
     static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 6400L; }();
     return v;
@@ -229,6 +284,15 @@ int dense(const float* A, long lda, const float* W, long ldw, const float* bias,
     if (M <= small_gemm_rows() && act == ACT_NONE && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0)
         return mc_launch_gemm_small(g, s);          // latency-bound sizes: 64 x 64 tiles (see gemm_small_k)
     return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
+}
+
+// C = A W^T + bias + R on the fp16 MFMA (reduced-precision mode); `hw` = the weight's fp16 planes
+int dense_h(const mc_ctx* c, const float* A, const HalfW& hw, const float* bias, const float* R, float* C, long M, int N, int K,
+            hipStream_t s) {
+    GemmHArgs g;
+    g.A = A; g.lda = K; g.Wh = hw.hi; g.Wl = hw.lo; g.bias = bias; g.R = R; g.ldr = N; g.C = C; g.ldc = N;
+    g.M = (int)M; g.N = N; g.K = K;
+    return mc_launch_gemm_h(g, c->prec == MC_PREC_F16X3, s);
 }
 
 // Small batches: a [M x K] x [K x N] GEMM with fewer than ~128 output tiles leaves most of the 256 CUs idle while each
@@ -255,7 +319,8 @@ int dense_splitk(const float* A, const float* W, const float* bias, const float*
 // gate/expert input `z` ([Ntok, din], embedding already added) is in HBM.
 // `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
 // expert FFN over the slots of one slot group (mc_route.hip): y2[dst_row] = FC2(gelu(FC1(z[src_row])))
-int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, hipStream_t s) {
+int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, hipStream_t s, const HalfW* hw = nullptr,
+                const HalfW* hw2 = nullptr) {
     const int E = c->m->cfg.num_experts, din = w.din, hid = 4 * w.din;
     const int max_tiles = cdiv(2 * Ntok, 128) + E;
     const long to = (long)group * c->rb.max_tiles;
@@ -267,6 +332,8 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
         m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
         m.num_tiles = mc_route_num_tiles_ptr(c->rb, group); m.src_row = c->rb.src_row; m.dst_row = c->rb.dst_row;
+        if (hw && hw->hi && hw2 && hw2->hi && c->prec != MC_PREC_F32)      // reduced-precision mode: the same fused MLP on the fp16 MFMA
+            return mc_launch_mlp_h(MLP_EXPERT, m, hw->hi, hw->lo, hw2->hi, hw2->lo, c->prec == MC_PREC_F16X3, 1, max_tiles, s);
         // small batches (a few dozen tiles, each walking all hidden chunks serially): split the hidden dimension 4 ways,
         // partial FC2 sums in hbuf, reduced in a fixed order (rows of dropped pairs stay unwritten garbage: never read)
         const int S = 4;
@@ -298,7 +365,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
 // `gated`: idx/gate/key/counts were already produced (fused gate_k); otherwise run projector + gate finish here.
 // `gsplit` < Ntok: two slot groups; then only the routing runs here and the caller launches moe_experts per group.
 int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, long ldout, bool gated, bool twin, long gsplit,
-            hipStream_t s) {
+            hipStream_t s, const HalfW* hw = nullptr, const HalfW* hw2 = nullptr) {
     const mc_model_config& g = c->m->cfg;
     const int E = g.num_experts, din = w.din;
     int r;
@@ -310,7 +377,7 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
     if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, gsplit, E, capacity, c->rb, s))) return r;
     if (gsplit < Ntok) return MC_OK;
-    if ((r = moe_experts(c, w, z, Ntok, 0, s))) return r;
+    if ((r = moe_experts(c, w, z, Ntok, 0, s, hw, hw2))) return r;
     if (!out) return MC_OK;                        // the caller launches the projection itself (row ranges)
     if (mc_chain_enabled(2) && mc_mlp_supported(din, 32) && w.dout % 32 == 0) {
         RowChainArgs p;
@@ -329,13 +396,15 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
-               bool prologue_only = false, TwinAlias y1_alias = TwinAlias()) {
+               bool prologue_only = false, TwinAlias y1_alias = TwinAlias(), const HalfW* hw = nullptr) {
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     const long o = row0 * D;
     int r;
     if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
+    if (hw && hw->hi && c->prec != MC_PREC_F32)
+        return dense_h(c, c->a + o, *hw, out_b, hs + o, hs + o, nrows, D, D, s);
     if (nrows <= small_gemm_rows() && D % 64 == 0) {     // up to a few thousand rows: 64 x 64 tiles, short MFMA chains, no K split (B=8: -11 % per step)
         GemmArgs q;
         q.A = c->a + o; q.lda = D; q.W = out_w; q.ldw = D; q.bias = out_b; q.R = hs + o; q.ldr = D; q.C = hs + o; q.ldc = D;
@@ -426,7 +495,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
     const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
     TwinAlias ys_alias;
     if (twin && mc_chain_enabled(8) && !c->no_alias) { ys_alias.split_flag = mc_route_split_flag_ptr(c->rb); ys_alias.from = c->rows / 2; }
-    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias))) return r;
+    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias, &w.h_ca_out))) return r;
     // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
     const long o = row0 * D;
     if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
@@ -435,6 +504,9 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
         m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;
         const int S = 4;
+        if (c->prec != MC_PREC_F32 && w.h_w1.hi && w.h_w2.hi) {
+            if ((r = mc_launch_mlp_h(MLP_PARTS, m, w.h_w1.hi, w.h_w1.lo, w.h_w2.hi, w.h_w2.lo, c->prec == MC_PREC_F16X3, H, 0, s))) return r;
+        } else
         if (nrows <= 2048 && (F / 32) % S == 0 && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = nrows * D;
             if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
@@ -458,7 +530,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
     }
     const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
     return film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, row0, nrows, s,
-                      c->defer_last_gemm && i == g.num_layers - 1);
+                      c->defer_last_gemm && i == g.num_layers - 1, TwinAlias(), &w.h_ffn_out);
 }
 
 // groups of whole samples for the multi-stream schedule: group k = rows [part_row0(k), part_row0(k + 1))
@@ -519,7 +591,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     // two slot groups when the two sample groups run on two streams: each group's expert MLP joins its own chain
     const bool grouped = split == 2 && c->nparts == 2 && mc_chain_enabled(6);
     const long gsplit = grouped ? part_row0(c, 1) * H : c->N;
-    if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, gsplit, s))) return r;   // routing (+ experts if one group)
+    if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, gsplit, s, &w.h_fc1, &w.h_fc2))) return r;   // routing (+ experts if one group)
     if (c->cap_idx) {
         if (twin) {     // expert ids exist for the first half only: the twins have the same ones
             MC_HIP(hipMemcpyAsync(c->cap_idx + (long)i * 2 * c->N, c->rb.idx, sizeof(int) * c->N, hipMemcpyDeviceToDevice, s));
@@ -536,13 +608,13 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         // workgroups at B=64, so ~8 % of every launch is a tail on a partly idle chip; with two independent chains in
         // flight the next kernel of one half starts inside the tail of the other (same effect as two batches in flight).
         if (grouped && twin) {         // group 1 combines group 0's expert rows (its own tokens have no slots): fork after them
-            if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s))) return r;
+            if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s, &w.h_fc1, &w.h_fc2))) return r;
             if ((r = parts_fork(c, s))) return r;
         } else {
             if ((r = parts_fork(c, s))) return r;
             if (grouped) {
-                if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s))) return r;
-                if ((r = moe_experts(c, w.mm, c->z, c->N, 1, c->parts[0]))) return r;
+                if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s, &w.h_fc1, &w.h_fc2))) return r;
+                if ((r = moe_experts(c, w.mm, c->z, c->N, 1, c->parts[0], &w.h_fc1, &w.h_fc2))) return r;
             }
         }
         for (int k = 0; k < c->nparts; ++k) {
@@ -602,6 +674,7 @@ int mc_model_create(const mc_model_config* cfg, mc_model** out) {
 void mc_model_destroy(mc_model* m) {
     if (!m) return;
     for (auto& kv : m->params) (void)hipFree(kv.second.first);
+    for (auto& kv : m->half) (void)hipFree(kv.second.hi);
     delete m;
 }
 
@@ -736,6 +809,17 @@ int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy) {
     MC_REQUIRE(policy == MC_TIE_STABLE || policy == MC_TIE_REVERSE, "tie policy %d (MC_TIE_STABLE or MC_TIE_REVERSE)", policy);
     c->rb.tie_xor = policy == MC_TIE_STABLE ? 0xFFFFFFFFu : 0u;
     c->have_cond = false;      // the hoisted text K/V were routed under the previous policy: set the condition again
+    return MC_OK;
+}
+
+int mc_ctx_set_precision(mc_ctx* c, int32_t precision) {
+    MC_REQUIRE(c, "null context");
+    MC_REQUIRE(precision == MC_PREC_F32 || precision == MC_PREC_F16 || precision == MC_PREC_F16X3, "precision %d", precision);
+    if (precision != MC_PREC_F32) {
+        int r = bind_half_weights(c);
+        if (r != MC_OK) return r;
+    }
+    c->prec = precision;
     return MC_OK;
 }
 
@@ -890,6 +974,8 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
             if ((r = run_layer(c, slot, c->hc, step, false, split, s))) return r;                       // copied_block
             const LayerW& cw = c->lw[slot];
             if ((r = by_group([&](long r0, long n, hipStream_t sk) {                                   // h += after_proj(c)
+                     if (c->prec != MC_PREC_F32 && cw.h_after.hi)
+                         return dense_h(c, c->hc + r0 * D, cw.h_after, cw.after_b, c->h + r0 * D, c->h + r0 * D, n, D, D, sk);
                      return dense(c->hc + r0 * D, D, cw.after_w, D, cw.after_b, c->h + r0 * D, D, c->h + r0 * D, D, n, D, D, ACT_NONE, sk); })))
                 return r;
         }
@@ -1077,6 +1163,24 @@ int mc_op_gemm(const float* a, const float* w, const float* bias, const float* r
                int32_t K, int32_t ldw, int32_t act, void* stream) {
     MC_REQUIRE(a && w && cdev && M > 0 && N > 0 && K > 0 && K % 4 == 0 && ldw % 4 == 0 && ldw >= K, "bad gemm args");
     return dense(a, K, w, ldw, bias, res, N, cdev, N, M, N, K, act, (hipStream_t)stream);
+}
+
+int mc_op_gemm_f16(const float* a, const float* w, const float* bias, const float* res, float* cdev, int32_t M, int32_t N,
+                   int32_t K, int32_t split, void* stream) {
+    MC_REQUIRE(a && w && cdev && M > 0 && N > 0 && K > 0, "bad gemm args");
+    hipStream_t s = (hipStream_t)stream;
+    mc_half* planes = nullptr;
+    MC_HIP(hipMalloc((void**)&planes, sizeof(mc_half) * 2 * (size_t)N * K));
+    int r = mc_launch_split_f16(w, planes, planes + (size_t)N * K, (long)N * K, s);
+    if (r == MC_OK) {
+        GemmHArgs g;
+        g.A = a; g.lda = K; g.Wh = planes; g.Wl = planes + (size_t)N * K; g.bias = bias; g.R = res; g.ldr = N; g.C = cdev; g.ldc = N;
+        g.M = M; g.N = N; g.K = K;
+        r = mc_launch_gemm_h(g, split != 0, s);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(planes);
+    return r;
 }
 
 int mc_op_ln_rows(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* add, int32_t add_mod,

@@ -86,6 +86,13 @@ class NativeContext:
         """Keep every layer's routing decisions of the last denoise call (tests)."""
         _lib.check(self.lib.mc_ctx_enable_capture(self.handle), 'mc_ctx_enable_capture')
 
+    def set_precision(self, precision):
+        """'f32' (default, exact fp32 MFMA), 'f16' (fp16 operands, fp32 accumulate) or 'f16x3' (fp16 hi/lo split, three
+        products: fp32-class) for the per-step GEMM-shaped kernels; gate / routing / normalisations stay fp32."""
+        code = {'f32': 0, 'f16': 1, 'f16x3': 2}[precision]
+        _lib.check(self.lib.mc_ctx_set_precision(self.handle, code), 'mc_ctx_set_precision')
+        self.precision = precision
+
     def set_tie_policy(self, policy):
         """'stable' (default) or 'reverse': order of equal-importance tokens at a capacity cut (tutel boundary, a16).
         Call before set_condition."""

@@ -507,6 +507,92 @@ def test_baseline_control_configs_at_their_per_gpu_batches_vs_oracle(case):
     nm.close()
 
 
+def test_fp16_mfma_gemm_op_vs_fp64():
+    """mc_half.hip gemm_h_k through the C-ABI: C = A W^T + bias + R with fp16 MFMA operands / fp32 accumulate.  The split form
+    (x = hi + lo, three products) must be fp32-class, the single-rounding form fp16-class; ragged M (row guard), K = 32."""
+    from motioncraft_amd import lib as L_
+    lib = L_.load(require_gpu=True)
+    _ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(9)
+    for M, N, K in ((300, 128, 32), (1000, 384, 384), (12544, 1536, 1536)):
+        a = torch.randn(M, K, generator=g)
+        a[:, ::7] *= 1e-3                       # columns of small magnitude: the lo plane must not lose them
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ref = a.double() @ w.double().T + b.double() + r.double()
+        scale = float(ref.abs().max())
+        ad, wd, bd, rd = a.cuda(), w.cuda(), b.cuda(), r.cuda()          # (kept alive: the ABI takes raw pointers)
+        for split, tol in ((1, 4e-6), (0, 4e-3)):
+            c = torch.full((M, N), float('nan'), device='cuda')
+            L_.check(lib.mc_op_gemm_f16(_ptr(ad), _ptr(wd), _ptr(bd), _ptr(rd), _ptr(c), M, N, K, split, st))
+            torch.cuda.synchronize()
+            err = float((c.cpu().double() - ref).abs().max()) / scale
+            print(f'fp16 MFMA gemm {M}x{N}x{K} split={split}: max rel err {err:.2e}')
+            assert err <= tol, (M, N, K, split, err)
+    c32 = torch.empty(M, N, device='cuda')          # the exact fp32 MFMA path on the same operands for comparison
+    L_.check(lib.mc_op_gemm(_ptr(ad), _ptr(wd), _ptr(bd), _ptr(rd), _ptr(c32), M, N, K, K, 0, st))
+    torch.cuda.synchronize()
+    print(f'fp32 MFMA gemm {M}x{N}x{K}: max rel err {float((c32.cpu().double() - ref).abs().max()) / scale:.2e}')
+
+
+@pytest.mark.parametrize('size', ['small', 'full_width'])
+def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
+    """BASELINE.json configs[4]: mixed text + audio plug-and-play control (text `xf_out` AND control condition `c` through
+    ControlT2MHalf, controlnet.py:340-424), reduced-precision MFMA, 50-step DDIM.  Precision 'f16x3' (fp16 hi/lo split,
+    fp32 accumulate; gate / routing / LayerNorm statistics stay fp32) walks the whole loop in lockstep with the fp32 CPU
+    oracle -- teacher-forced to the HIP path's routing decisions, from the HIP path's own x_t: every x_{t-1} within
+    1e-3, routing flips of the free-running oracle reported.  Plain 'f16' (one rounding to fp16 per operand, what
+    mmcv's wrap_fp16_model does to the reference, tools/test.py:95-97) is measured on the first steps and held to the
+    fp16-class bound it can meet."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    if size == 'small':
+        dims, copy, feats, B, T, Tc = CTRL, CTRL_COPY, CTRL_FEATS, 2, 24, 20
+        sd = W.make_state_dict(dims, SMALL_SEED, shapes=W.control_param_shapes(dims, copy, feats))
+    else:       # the 0.125b architecture (L=128, 12 parts, 4 layers) + 2 control copies, pre-encoded audio of width D
+        dims, copy, feats, B, T, Tc = FULL, 2, 1536, 4, 196, 196
+        sd = W.make_state_dict(dims, 0, shapes=W.control_param_shapes(dims, copy, feats))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    g = torch.Generator().manual_seed(91)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=92, lengths=[T, T - 5] + [T - 40] * (B - 2))
+    c = torch.randn(B, Tc, feats, generator=g)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    sched = O.Schedule(1000, '15,15,8,6,6')
+    NL = dims['NL']
+    torch.set_num_threads(min(32, os.cpu_count()))
+    noises = step_noise_from_seed(93, (B, T, dims['input_feats']), 50)
+    for prec, nsteps, tol in (('f16x3', 50, TOL_FINAL), ('f16', 6, 3e-2)):
+        ctx = nm.context(B, T, max_steps=50)
+        ctx.set_precision(prec)
+        ctx.enable_capture()
+        ctx.set_timesteps(d.timestep_map)
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        ctx.set_control(c.cuda())
+        x = x_T.cuda()
+        worst, fi, fk = 0.0, 0, 0
+        for n, i in enumerate(range(49, 49 - nsteps, -1)):
+            x_in = x.cpu()
+            x = ctx.sample_step(x, i, d.step_coefs(i, 'ddim', dims['scale']), noises[n].cuda())
+            forced = {slot: ctx.routing(slot) for slot in range(NL + copy)}
+            cap = {}
+            x0 = O.denoise_control(sd, dims, x_in, sched.timestep_map[i], xf, mask, c, copy, cap=cap, forced_routing=forced)
+            ref = O.ddim_step(sched, i, x_in, x0, noises[n])
+            worst = max(worst, maxabs(x, ref))
+            for slot in range(NL + copy):
+                a, b, _ = _routing_flips(cap['routing'][slot]['free'], forced[slot])
+                fi, fk = fi + a, fk + b
+        print(f'configs[4] {size} precision {prec}: {nsteps} DDIM steps in lockstep, worst |hip - fp32 oracle| {worst:.2e}; '
+              f'routing flips vs the free-running oracle: expert-id {fi}, keep {fk} over {nsteps * (NL + copy)} routings')
+        assert worst <= tol, (prec, worst)
+        if prec == 'f16x3':
+            assert fi + fk <= 4 * nsteps        # the gate is fp32 in every mode: flips stay at the fp32 path's level
+        ctx.close()
+    nm.close()
+
+
 def test_control_branch_vs_reference_golden():
     """ControlT2MHalf (a15; BASELINE configs 3-5 form): copied DecoderLayers + zero-init projections + condition
     padding/CFG masking, through the reference-style wrapper API and through the raw context."""

@@ -11,6 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dims = default_dims()
 nm = NativeModel(dims, make_state_dict(dims, 0), cfg_scale=6.5)
 ctx = nm.context(B, 196, max_steps=4)
+PREC = os.environ.get('MC_PREC', 'f32')      # f32 | f16 | f16x3 (mc_ctx_set_precision)
+ctx.set_precision(PREC)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, 196, 322, generator=g).cuda()
 xf = torch.nn.functional.layer_norm(torch.randn(B, 77, 256, generator=g), (256,)).cuda()
@@ -27,5 +29,5 @@ for r in range(5):
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 4)
 ts.sort()
-print(f'B={B} MC_GEMM_TUNE={os.environ.get("MC_GEMM_TUNE","default")}: median {ts[2]:.3f} ms/step  min {ts[0]:.3f}  '
+print(f'B={B} precision={PREC} MC_GEMM_TUNE={os.environ.get("MC_GEMM_TUNE","default")}: median {ts[2]:.3f} ms/step  min {ts[0]:.3f}  '
       f'-> {37.08e9*B/ts[2]/1e9:.1f} TFLOP/s, {B*196/ts[2]:.1f} frames/s @1000 steps')
