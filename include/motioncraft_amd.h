@@ -160,6 +160,18 @@ int mc_denoise(mc_ctx* c, const float* x_t_dev, int32_t step_index, float* out2_
 int mc_sample_step(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
                    const float* noise_dev, float* x_prev_dev, float* x0_dev, void* stream);
 
+/* hipGraph replay of mc_sample_step (BASELINE.json configs[4] "hipGraph-captured 50-step DDIM"): ONE graph serves every step
+ * of the schedule -- the step index is a device-side integer, the FiLM tables and the sampler coefficients are addressed
+ * with it inside the kernels, no host sync or per-step H2D copy (SURVEY.md section 3.1 lists the reference's per-step
+ * host syncs).  capture: coefs_host[num_steps] = the mc_step_coefs of every schedule index (num_steps must equal the
+ * schedule of mc_ctx_set_timesteps); x_dev [B,T,C] is updated IN PLACE by every replay, noise_dev [B,T,C] is read by
+ * every replay (the caller refills it between steps); both pointers are baked into the graph.  `stream` must be a
+ * non-default stream.  step: runs schedule index step_index on `stream` (bit-identical to mc_sample_step). */
+int mc_ctx_graph_capture(mc_ctx* c, float* x_dev, const float* noise_dev, const mc_step_coefs* coefs_host, int32_t num_steps,
+                         void* stream);
+int mc_ctx_graph_step(mc_ctx* c, int32_t step_index, void* stream);
+int mc_ctx_graph_release(mc_ctx* c);
+
 /* mc_sample_step with the seeding above; x_t_dev is MODIFIED IN PLACE on the seeded elements (the reference writes
  * into `img`) before the denoiser and the sampler update read it */
 int mc_sample_step_seeded(mc_ctx* c, float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,

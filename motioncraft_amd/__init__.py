@@ -5,9 +5,9 @@ from .builder import (ARCHITECTURES, ATTENTIONS, LOSSES, MODELS, SUBMODULES, bui
 from .config import Config, ConfigDict
 from .registry import Registry, build_from_cfg
 from . import models as _models  # registers MotionDiffusion / STMoGenTransformer / STMA / MSELoss
-from .models import ControlT2MHalf
+from .models import ControlT2MHalf, wrap_fp16_model
 from .checkpoint import load_checkpoint
 
 __all__ = ['ARCHITECTURES', 'ATTENTIONS', 'LOSSES', 'MODELS', 'SUBMODULES', 'build_architecture',
            'build_attention', 'build_loss', 'build_submodule', 'Config', 'ConfigDict', 'Registry', 'build_from_cfg', 'ControlT2MHalf',
-           'load_checkpoint']
+           'load_checkpoint', 'wrap_fp16_model']

@@ -16,8 +16,15 @@ int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, c
                       const float* add, int add_mod, float* Y, long ldy, long rows, int L, hipStream_t s);
 // A[r][0:D] = silu( LN_D(Y1[r] (+ Y2[r])) * gamma + beta ) * (1 + ss[0:D]) + ss[D:2D] ) -- StylizationBlock prologue
 // y1_alias: Y1 rows (global row index row0 + r) >= from are read from row - from while the flag is clear
+// Step index read on the device (hipGraph replay, mc_ctx_graph_*): while `ptr` is set, per-step tables are addressed with
+// *ptr inside the kernel instead of through host-computed pointers / by-value scalars, so ONE captured graph serves all steps.
+struct StepRef {
+    const int* ptr = nullptr;
+    long stride = 0;             // floats per step of the table behind the pointer argument
+};
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
-                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias = TwinAlias(), long row0 = 0);
+                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias = TwinAlias(), long row0 = 0,
+                        StepRef step = StepRef());
 // te[s][0:D] = cat(cos(t_s f), sin(t_s f))
 int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s);
 int mc_launch_silu(const float* X, float* Y, long n, hipStream_t s);
@@ -35,9 +42,14 @@ struct SamplerCoefs {
     float nonzero;     // 0 at i == 0
 };
 // x_prev = sampler(x_t, x0 = text_coef*out_text + none_coef*out_none, noise); optionally also writes x0
+// table != nullptr (graph replay): the step's coefficients are table[*step_ptr]; only text_coef / none_coef of `c` are used
 int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none,
                              const float* noise, float* x_prev, float* x0_out, long n,
-                             SamplerCoefs c, hipStream_t s);
+                             SamplerCoefs c, hipStream_t s, const SamplerCoefs* table = nullptr, const int* step_ptr = nullptr);
+// out = table[*step].text_coef * x + table[*step].none_coef * y   (CFG combine of the two halves under graph replay)
+int mc_launch_cfg_combine_tab(const float* x, const float* y, const SamplerCoefs* table, const int* step_ptr, float* out, long n,
+                              hipStream_t s);
+int mc_launch_set_int(int* dst, int value, hipStream_t s);
 
 // RePaint / outpainting (gaussian_diffusion.py:492-501, 855-877)
 struct InpaintArgs {

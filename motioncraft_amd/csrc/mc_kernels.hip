@@ -51,7 +51,8 @@ constexpr int FILM_MAXC = 8;  // 8 float4 chunks x 64 lanes = 2048 channels
 __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ Y1, const float* __restrict__ Y2,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ ss, float* __restrict__ A,
-                                                   long rows, int D, TwinAlias y1_alias, long row0) {
+                                                   long rows, int D, TwinAlias y1_alias, long row0, StepRef step) {
+    if (step.ptr) ss += (long)(*step.ptr) * step.stride;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -156,7 +157,14 @@ __global__ void softmax_rows_small_k(const float* __restrict__ W, float* __restr
 __global__ __launch_bounds__(256) void sampler_update_k(const float* __restrict__ x_t, const float* __restrict__ o_text,
                                                         const float* __restrict__ o_none, const float* __restrict__ noise,
                                                         float* __restrict__ x_prev, float* __restrict__ x0_out, long n,
-                                                        SamplerCoefs c) {
+                                                        SamplerCoefs c, const SamplerCoefs* __restrict__ table,
+                                                        const int* __restrict__ step_ptr) {
+    if (table) {          // graph replay: this step's schedule coefficients from the device table
+        const float tc = c.text_coef, nc = c.none_coef;
+        c = table[*step_ptr];
+        c.text_coef = tc;
+        c.none_coef = nc;
+    }
     const float sigma_ddpm = c.nonzero * expf(0.5f * c.log_var);
     float sq_abp = 0.f, dir = 0.f, sigma = 0.f;
     if (c.mode == 1) {
@@ -291,6 +299,16 @@ __global__ __launch_bounds__(256) void axpby_k(const float* __restrict__ x, cons
         out[i] = a * x[i] + b * y[i];
 }
 
+__global__ __launch_bounds__(256) void cfg_combine_tab_k(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const SamplerCoefs* __restrict__ table, const int* __restrict__ step_ptr,
+                                                         float* __restrict__ out, long n) {
+    const float a = table[*step_ptr].text_coef, b = table[*step_ptr].none_coef;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i];
+}
+
+__global__ void set_int_k(int* dst, int value) { *dst = value; }
+
 }  // namespace
 
 int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, const float* beta,
@@ -306,10 +324,10 @@ int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, c
 }
 
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
-                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0) {
+                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0, StepRef step) {
     MC_REQUIRE(D % 4 == 0 && D <= FILM_MAXC * 256, "film_rows: unsupported D=%d", D);
     if (rows <= 0) return MC_OK;
-    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0);
+    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -344,11 +362,27 @@ int mc_launch_softmax_rows_small(const float* W, float* out, int rows, int cols,
 
 int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none,
                              const float* noise, float* x_prev, float* x0_out, long n,
-                             SamplerCoefs c, hipStream_t s) {
+                             SamplerCoefs c, hipStream_t s, const SamplerCoefs* table, const int* step_ptr) {
     int blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sampler_update_k, dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev,
-                       x0_out, n, c);
+                       x0_out, n, c, table, step_ptr);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_cfg_combine_tab(const float* x, const float* y, const SamplerCoefs* table, const int* step_ptr, float* out, long n,
+                              hipStream_t s) {
+    if (n <= 0) return MC_OK;
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cfg_combine_tab_k, dim3(blocks), dim3(256), 0, s, x, y, table, step_ptr, out, n);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_set_int(int* dst, int value, hipStream_t s) {
+    hipLaunchKernelGGL(set_int_k, dim3(1), dim3(1), 0, s, dst, value);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

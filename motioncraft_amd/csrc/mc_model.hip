@@ -84,6 +84,14 @@ struct mc_ctx {
     hipStream_t parts[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
     int nparts = 2;
+    // hipGraph replay of the sampler step (mc_ctx_graph_capture / _step): ONE graph for all steps of the schedule; the step
+    // index lives in device memory (gstep) and the per-step tables are addressed inside the kernels (StepRef)
+    int* gstep = nullptr;
+    SamplerCoefs* gcoefs = nullptr;     // [S] schedule coefficients of every step
+    bool graph_mode = false;            // set while capturing: launch with device-indexed step parameters
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_steps = 0;
     int prec = MC_PREC_F32;      // MFMA operand precision of the per-step GEMM-shaped kernels (mc_ctx_set_precision)
     int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
     float* cap_w = nullptr;      // ... and combine weights (0 = dropped) of every layer
@@ -400,7 +408,9 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     const long o = row0 * D;
     int r;
-    if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0))) return r;
+    StepRef sref;
+    if (c->graph_mode) { sref.ptr = c->gstep; sref.stride = 2L * D; }     // `ss` then is the table's row of step 0
+    if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0, sref))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
     if (hw && hw->hi && c->prec != MC_PREC_F32)
@@ -789,8 +799,11 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     return MC_OK;
 }
 
+static void graph_release(mc_ctx* c);
+
 void mc_ctx_destroy(mc_ctx* c) {
     if (!c) return;
+    graph_release(c);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (int k = 1; k < 3; ++k)
         if (c->parts[k]) { (void)hipStreamSynchronize(c->parts[k]); (void)hipStreamDestroy(c->parts[k]); }
@@ -926,6 +939,7 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
     MC_REQUIRE(c && x_t, "null argument");
     MC_REQUIRE(c->have_cond, "mc_ctx_set_condition not called");
     MC_REQUIRE(step >= 0 && step < c->S, "step_index %d outside the %d-step schedule", step, c->S);
+    if (c->graph_mode) step = 0;       // host-side table pointers address step 0; the kernels add *gstep rows
     hipStream_t s = (hipStream_t)stream;
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, H = g.num_parts, D = L * H, C = g.input_feats;
@@ -1015,14 +1029,18 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
     const long BT = (long)c->B * c->T;
     const LayerW& w = c->lw[g.num_layers - 1];
     *x0b = nullptr;
-    if ((r = mc_launch_axpby(c->h, c->h + BT * D, k->text_coef, k->none_coef, c->z2, BT * D, s))) return r;     // h_c
+    auto combine = [&](const float* x, const float* y, float* out) -> int {      // w x + (1 - w) y, w = this step's CFG weight
+        if (c->graph_mode) return mc_launch_cfg_combine_tab(x, y, c->gcoefs, c->gstep, out, BT * D, s);
+        return mc_launch_axpby(x, y, k->text_coef, k->none_coef, out, BT * D, s);
+    };
+    if ((r = combine(c->h, c->h + BT * D, c->z2))) return r;     // h_c
     if (defer) {
         if (c->dec_cat_w && mc_chain_enabled(11)) {
             // ... and that Linear composed with the decoder is one [C, D] matrix (folded at pack time):
             //   x0 = [dec(h_c) + Wd b] + [a_c (Wd W)^T]
             // the two skinny products (N = C = 322: 294 tiles each, half a chip) are the two groups of ONE grouped GEMM
             // over (h_c | a_c) x (Wd | Wd W); the sampler kernel adds the two partial outputs
-            if ((r = mc_launch_axpby(c->a, c->a + BT * D, k->text_coef, k->none_coef, c->z2 + BT * D, BT * D, s))) return r;      // a_c
+            if ((r = combine(c->a, c->a + BT * D, c->z2 + BT * D))) return r;      // a_c
             GemmArgs t;
             t.A = c->z2; t.lda = D; t.a_gstride = BT * D; t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D;
             t.bias = c->dec_cat_b; t.b_gstride = C; t.C = c->out2; t.ldc = C; t.c_gstride = BT * C;
@@ -1033,7 +1051,7 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
             *x0b = c->out2 + BT * C;
             return MC_OK;
         }
-        if ((r = mc_launch_axpby(c->a, c->a + BT * D, k->text_coef, k->none_coef, c->a, BT * D, s))) return r;      // a_c
+        if ((r = combine(c->a, c->a + BT * D, c->a))) return r;      // a_c
         if (c->dec_wf) {
             if ((r = dense(c->z2, D, c->dec_w, D, c->dec_bf, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
             if ((r = dense(c->a, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
@@ -1061,7 +1079,63 @@ int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coef
     int r = denoise_combined(c, x_t, step, k, stream, &x0a, &x0b);
     if (r != MC_OK) return r;
     const long n = (long)c->B * c->T * c->m->cfg.input_feats;
-    return mc_launch_sampler_update(x_t, x0a, x0b ? x0b : x0a, noise, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream);
+    return mc_launch_sampler_update(x_t, x0a, x0b ? x0b : x0a, noise, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream,
+                                    c->graph_mode ? c->gcoefs : nullptr, c->graph_mode ? c->gstep : nullptr);
+}
+
+// ---- hipGraph replay of mc_sample_step -------------------------------------------------------------------------------
+static void graph_release(mc_ctx* c) {
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    c->graph_steps = 0;
+}
+
+int mc_ctx_graph_capture(mc_ctx* c, float* x_dev, const float* noise_dev, const mc_step_coefs* coefs_host, int32_t num_steps,
+                         void* stream) {
+    MC_REQUIRE(c && x_dev && noise_dev && coefs_host, "null argument");
+    MC_REQUIRE(c->have_cond, "mc_ctx_set_condition not called");
+    MC_REQUIRE(num_steps >= 1 && num_steps == c->S, "num_steps=%d must equal the schedule set by mc_ctx_set_timesteps (%d)", num_steps, c->S);
+    MC_REQUIRE(!c->cap_idx, "routing capture (tests) and graph replay are mutually exclusive");
+    hipStream_t s = (hipStream_t)stream;
+    MC_REQUIRE(s != nullptr, "graph capture needs a non-default stream");
+    graph_release(c);
+    int r;
+    if (!c->gstep && (r = ws_alloc(c, &c->gstep, 1)) != MC_OK) return r;
+    if (!c->gcoefs && (r = ws_alloc(c, &c->gcoefs, (size_t)c->maxS)) != MC_OK) return r;
+    std::vector<SamplerCoefs> tab(num_steps);
+    for (int i = 0; i < num_steps; ++i) tab[i] = to_coefs(&coefs_host[i]);
+    MC_HIP(hipMemcpyAsync(c->gcoefs, tab.data(), sizeof(SamplerCoefs) * num_steps, hipMemcpyHostToDevice, s));
+    MC_HIP(hipMemsetAsync(c->gstep, 0, sizeof(int), s));
+    MC_HIP(hipStreamSynchronize(s));                 // (`tab` is a temporary)
+    MC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    c->graph_mode = true;
+    r = mc_sample_step(c, x_dev, 0, &coefs_host[0], noise_dev, x_dev, nullptr, stream);     // in place: x_prev aliases x_t
+    c->graph_mode = false;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (r != MC_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (e != hipSuccess || !g) { mc_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return MC_ERR_HIP; }
+    c->graph = g;
+    const hipError_t ei = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { mc_set_error("hipGraphInstantiate: %s", hipGetErrorString(ei)); graph_release(c); return MC_ERR_HIP; }
+    c->graph_steps = num_steps;
+    return MC_OK;
+}
+
+int mc_ctx_graph_step(mc_ctx* c, int32_t step, void* stream) {
+    MC_REQUIRE(c && c->graph_exec, "no captured graph (mc_ctx_graph_capture)");
+    MC_REQUIRE(step >= 0 && step < c->graph_steps, "step_index %d outside the %d captured steps", step, c->graph_steps);
+    hipStream_t s = (hipStream_t)stream;
+    int r = mc_launch_set_int(c->gstep, step, s);
+    if (r != MC_OK) return r;
+    MC_HIP(hipGraphLaunch(c->graph_exec, s));
+    return MC_OK;
+}
+
+int mc_ctx_graph_release(mc_ctx* c) {
+    MC_REQUIRE(c, "null context");
+    graph_release(c);
+    return MC_OK;
 }
 
 int mc_sample_step_seeded(mc_ctx* c, float* x_t, int32_t step, const mc_step_coefs* k, const float* noise,

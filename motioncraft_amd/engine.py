@@ -152,6 +152,26 @@ class NativeContext:
                                            _ptr(x_prev), _ptr(x0), _stream()), 'mc_sample_step')
         return x_prev
 
+    def graph_capture(self, x, noise, coefs):
+        """Capture mc_sample_step into ONE hipGraph for the whole schedule.  ``x`` [B,T,C] is updated in place by every
+        ``graph_step``, ``noise`` [B,T,C] is read by every replay (refill it in place between steps); both tensors must stay
+        alive and keep their addresses.  ``coefs``: list of StepCoefs for every schedule index.  Call on a non-default
+        torch stream (``with torch.cuda.stream(s):``)."""
+        x, noise = _dev_f32(x, 'x'), _dev_f32(noise, 'noise')
+        if tuple(x.shape) != (self.B, self.T, self.C) or noise.shape != x.shape:
+            raise ValueError(f'x / noise shape {tuple(x.shape)} != {(self.B, self.T, self.C)}')
+        arr = (_lib.StepCoefs * len(coefs))(*coefs)
+        self._graph_keep = (x, noise)
+        _lib.check(self.lib.mc_ctx_graph_capture(self.handle, _ptr(x), _ptr(noise), arr, len(coefs), _stream()),
+                   'mc_ctx_graph_capture')
+
+    def graph_step(self, step_index):
+        _lib.check(self.lib.mc_ctx_graph_step(self.handle, int(step_index), _stream()), 'mc_ctx_graph_step')
+
+    def graph_release(self):
+        _lib.check(self.lib.mc_ctx_graph_release(self.handle), 'mc_ctx_graph_release')
+        self._graph_keep = None
+
     def sample_step_seeded(self, x_t, step_index, coefs, noise, sqrt_ab, sqrt_1mab, pre_seq=None, pre_noise=None,
                            transl=(), x_prev=None, x0=None):
         """One step with the reference's pre_seq / transl_req seeding: ``x_t`` is overwritten IN PLACE on its first

@@ -80,6 +80,9 @@ _SIGNATURES = {
     'mc_ctx_set_control': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'mc_denoise': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
     'mc_sample_step': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, _P, _P, _P]),
+    'mc_ctx_graph_capture': (ctypes.c_int, [_P, _P, _P, ctypes.POINTER(StepCoefs), ctypes.c_int32, _P]),
+    'mc_ctx_graph_step': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'mc_ctx_graph_release': (ctypes.c_int, [_P]),
     'mc_sample_step_seeded': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, ctypes.POINTER(Seed), _P, _P, _P]),
     'mc_sample_step_inpaint': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P,
                                               ctypes.POINTER(Inpaint), _P, _P, _P]),

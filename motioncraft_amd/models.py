@@ -84,6 +84,7 @@ class STMoGenTransformer:
         self._control = None            # set by ControlT2MHalf: dict(copy_blocks_num, cond_feats, raw_feats, condition_cfg, pre_encode)
         self._wavenc = None
         self._textenc = None
+        self.precision = 'f32'          # 'f32' | 'f16' | 'f16x3': MFMA operand precision of the per-step GEMMs (wrap_fp16_model)
 
     # ---- nn.Module-ish surface used by the tools ---------------------------------------------
     def eval(self):
@@ -180,6 +181,8 @@ class STMoGenTransformer:
             ctx = self.native.context(B, T, max_steps=max(len(timestep_map), 50))
             ctx.max_steps = max(len(timestep_map), 50)
             self._ctx[key] = ctx
+        if getattr(ctx, 'precision', 'f32') != self.precision:
+            ctx.set_precision(self.precision)
         if ctx.timesteps != [int(t) for t in timestep_map]:
             ctx.set_timesteps(timestep_map)
         c = model_kwargs.get('c', None)
@@ -328,6 +331,20 @@ class ControlT2MHalf:
                                        num_intervals=num_intervals, c=c, **kwargs)
 
     __call__ = forward
+
+
+def wrap_fp16_model(model, split=True):
+    """Mirror of mmcv.runner.wrap_fp16_model as the reference tools call it (``tools/test.py:95-97``: ``if cfg.get('fp16')
+    is not None: wrap_fp16_model(model)``): switches the per-step GEMM-shaped kernels of the denoiser to the fp16 MFMA.
+    ``split=True`` (default) keeps fp32-class results (operands split hi + lo, three products, fp32 accumulate:
+    'f16x3'); ``split=False`` is the single-rounding fp16 form mmcv's wrapper produces ('f16').  The gate, routing and
+    every normalisation stay fp32 either way.  Accepts a MotionDiffusion, a STMoGenTransformer or a ControlT2MHalf."""
+    target = getattr(model, 'model', model)
+    target = getattr(target, 'base_model', target)
+    if not hasattr(target, 'precision'):
+        raise TypeError(f'wrap_fp16_model: {type(model).__name__} has no MI355X denoiser inside')
+    target.precision = 'f16x3' if split else 'f16'
+    return model
 
 
 def to_cpu(x):

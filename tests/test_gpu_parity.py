@@ -593,6 +593,57 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     nm.close()
 
 
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+def test_hipgraph_replay_of_the_sampler_step_is_bit_identical(prec):
+    """BASELINE.json configs[4] "hipGraph-captured 50-step DDIM": ONE captured graph of mc_sample_step (step index in device
+    memory, FiLM tables / sampler coefficients addressed inside the kernels) replayed for all 50 steps must reproduce the
+    eager launch sequence bit for bit -- mixed text + audio control config, small size and the 0.125b width."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    S = d.num_timesteps
+    for dims, copy, feats, B, T, seed in ((CTRL, CTRL_COPY, CTRL_FEATS, 2, 24, SMALL_SEED), (FULL, 2, 35, 3, 196, 0)):
+        sd = W.make_state_dict(dims, seed, shapes=W.control_param_shapes(dims, copy, feats))
+        nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+        x_T, xf, mask = synth_inputs(dims, B, T, seed=51, lengths=[T - 3] + [T] * (B - 1))
+        c = torch.randn(B, T, feats, generator=torch.Generator().manual_seed(52))
+        noises = [n.cuda() for n in step_noise_from_seed(53, tuple(x_T.shape), S)]
+        coefs = [d.step_coefs(i, 'ddim', dims['scale']) for i in range(S)]
+        outs = {}
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for arm in ('eager', 'graph'):
+                ctx = nm.context(B, T, max_steps=S)
+                ctx.set_precision(prec)
+                ctx.set_timesteps(d.timestep_map)
+                ctx.set_condition(xf.cuda(), mask.cuda())
+                ctx.set_control(c.cuda())
+                x, noise = x_T.cuda(), torch.empty(B, T, dims['input_feats'], device='cuda')
+                if arm == 'graph':
+                    ctx.graph_capture(x, noise, coefs)
+                    x.copy_(x_T)                       # (the capture pass itself does not execute anything)
+                for n, i in enumerate(range(S - 1, -1, -1)):
+                    noise.copy_(noises[n])
+                    if arm == 'graph':
+                        ctx.graph_step(i)
+                    else:
+                        ctx.sample_step(x, i, coefs[i], noise, x_prev=x)
+                stream.synchronize()
+                outs[arm] = x.cpu()
+                if arm == 'graph':
+                    with pytest.raises(RuntimeError):
+                        ctx.graph_step(S)
+                    ctx.graph_release()
+                    with pytest.raises(RuntimeError):
+                        ctx.graph_step(0)
+                ctx.close()
+        assert bool(torch.isfinite(outs['eager']).all())
+        assert torch.equal(outs['eager'], outs['graph']), (prec, dims['L'], maxabs(outs['eager'], outs['graph']))
+        nm.close()
+
+
 def test_control_branch_vs_reference_golden():
     """ControlT2MHalf (a15; BASELINE configs 3-5 form): copied DecoderLayers + zero-init projections + condition
     padding/CFG masking, through the reference-style wrapper API and through the raw context."""
