@@ -263,7 +263,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / nrep * 1e3
         tf = 2.0 * rows * D * D / (us * 1e-6) / 1e12
-        dom = {'kernel': f'gemm_dma_k (fp32 MFMA, LDS-DMA staging): FiLM out_layers GEMM {rows}x{D}x{D} + bias + residual (8 of the ~125 launches, 35 % of a step)',
+        dom = {'kernel': f'gemm_wp_k (fp32 MFMA, persistent wave-private LDS-DMA pipeline): FiLM out_layers GEMM {rows}x{D}x{D} + bias + residual (8 of the ~125 launches, 35 % of a step)',
                'avg_us': round(us, 1), 'achieved': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
     # ---- side measurement (NOT `value`): two independent batches of B in flight on this GPU, one HIP stream and one
@@ -338,7 +338,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic_gb if (B, T) == (64, 196) else None,
                          'traffic_unit': f'GB per step, read from {traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction)',
-                         'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_dma_k fp32 MFMA GEMMs)',
+                         'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_wp_k fp32 MFMA GEMMs)',
                          'algorithmic_gflop_per_sample_step': round(algorithmic_flops_per_sample_step(DIMS, T) / 1e9, 3),
                          'event_ms_per_step': round(ev_ms, 4), 'dominant_kernel': dom},
         }

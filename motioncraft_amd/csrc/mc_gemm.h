@@ -39,7 +39,7 @@ struct GemmArgs {
     const int* src_row = nullptr;
     const int* dst_row = nullptr;
     const float* comb_w = nullptr;  // [M][2]
-    int tune = 0;                   // bit0: 2-deep prefetch + mid-loop staging writes (set by the launcher; MC_GEMM_TUNE=0 disables)
+    int tune = 0;                   // MC_GEMM_TUNE bits (set by the launcher): 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k
 };
 
 int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream);

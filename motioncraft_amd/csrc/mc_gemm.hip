@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_k(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = g.N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = (g.tune & 64) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid / ntn, tn = bid % ntn;
     const int row0 = tm * BM;
     const float* __restrict__ Ab = g.A + g.a_col;
@@ -403,6 +403,150 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_k(GemmArgs g) {
     else if (g.act == ACT_SILU) epilogue_vec<GM_PLAIN, false, ACT_SILU>(g, 0, row0, BM, tn, wm, wn, lane, acc);
     else if (g.act == ACT_NONE) epilogue_vec<GM_PLAIN, false, ACT_NONE>(g, 0, row0, BM, tn, wm, wn, lane, acc);
     else epilogue_vec<GM_PLAIN, false, ACT_LRELU>(g, 0, row0, BM, tn, wm, wn, lane, acc);
+}
+
+// ---------------------------------------------------------------------------------------
+// Wave-private pipeline variant of the plain full-tile GEMM: NO workgroup barrier in the k-loop.
+// The 128 x 128 block tile is still four 64 x 64 wave tiles, but every wave streams its OWN operand rows (64 rows of A and
+// 64 rows of W, 16 k-columns per stage) into a private LDS ring with LDS-DMA and orders itself with its own counted
+// `s_waitcnt vmcnt` -- the DMA instructions are inline asm, so the compiler neither counts them nor drains them in front
+// of LDS reads (guide section 5.7).  Cost: every operand row is fetched by two waves of the workgroup (L1/L2 hits);
+// gain: a wave never waits for another wave, the two waves that share a SIMD (one of each co-resident workgroup) drift
+// freely and fill each other's issue gaps, and the per-k-tile barrier + its vmcnt(0) drain are gone.
+// LDS image of a stage: [A rows 0..63 | W rows 0..63][16 floats], 16-byte chunk c of row r at position c ^ ((r >> 2) & 3)
+// (conflict-free ds_read_b128 of any aligned 16-lane group: 4 rows share a 256-byte bank row, rows 4 apart differ in the XOR).
+// ---------------------------------------------------------------------------------------
+constexpr int WBK = 16, WSTAGE = 128 * WBK;     // floats per stage of one wave: (64 + 64) rows x 16
+
+__device__ __forceinline__ void dma16(unsigned voff, const float* sbase, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+// Persistent form: gridDim.x <= 2 workgroups per CU walk the tile list (tile = blockIdx.x, += gridDim.x); a wave goes from the
+// stores of one tile straight into the first DMAs of the next, and the residual / bias rows of a tile are requested two
+// k-tiles before its k-loop ends, so neither the operand prologue nor the epilogue reads sit exposed between two k-loops
+// and the waves of the chip drift out of the launch-synchronised rounds in which every tile's epilogue traffic bursts at once.
+__global__ __launch_bounds__(256, 2) void gemm_wp_k(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * WSTAGE];      // 4 waves x 2 stages x 8 KB = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* wbase = smem + wave_u * 2 * WSTAGE;
+    const unsigned lds0 = (unsigned)(size_t)wbase;                            // LDS byte offset of this wave's ring
+    // DMA piece q (16 rows x 64 bytes per wave-instruction): lane -> row 16 q + (lane >> 2), LDS position lane & 3,
+    // global chunk (lane & 3) ^ ((row >> 2) & 3)   (16 q is a multiple of 4: the XOR term does not depend on q)
+    const int dr = lane >> 2, dc = ((lane & 3) ^ ((dr >> 2) & 3)) * 4;
+    const int frow = lane & 31, hf = lane >> 5, sw = (frow >> 2) & 3;
+    const float* Ab = g.A + g.a_col;
+    const float* Wb = g.W;
+    const float* __restrict__ Rb = g.R ? g.R + g.c_col : nullptr;
+    float* __restrict__ Cb = g.C + g.c_col;
+    const int nk = g.K / WBK;
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto ld_frag = [&](int st, int j) {          // k-group j (8 columns) of the stage: rows frow and frow + 32 share the XOR term
+        const float* S = wbase + st * WSTAGE + frow * WBK + ((2 * j + hf) ^ sw) * 4;
+        Frag f;
+        f.a0 = *reinterpret_cast<const f32x4*>(S);
+        f.a1 = *reinterpret_cast<const f32x4*>(S + 32 * WBK);
+        f.b0 = *reinterpret_cast<const f32x4*>(S + 64 * WBK);
+        f.b1 = *reinterpret_cast<const f32x4*>(S + 96 * WBK);
+        return f;
+    };
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int bid = xcd_remap(t, ntiles);
+        const int tm = bid / ntn, tn = bid % ntn;
+        const int row0 = tm * BM;
+        unsigned voa[4], vow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            voa[q] = (unsigned)(((long)(row0 + wm * 64 + 16 * q + dr) * g.lda + dc) * 4);
+            vow[q] = (unsigned)(((long)(tn * BN + wn * 64 + 16 * q + dr) * g.ldw + dc) * 4);
+        }
+        auto issue_q = [&](int kt, int st, int q) {
+            const unsigned l = lds0 + st * WSTAGE * 4;
+            dma16(voa[q], Ab + kt * WBK, l + q * 1024);
+            dma16(vow[q], Wb + kt * WBK, l + 4096 + q * 1024);
+        };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        auto mma2 = [&](const Frag& f, int i0) {     // two of the four k-steps of a fragment: 8 MFMAs
+#pragma unroll
+            for (int i = i0; i < i0 + 2; ++i) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a0[i], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a0[i], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a1[i], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a1[i], acc[1][1], 0, 0, 0);
+            }
+        };
+        // (the stage buffers were last read by MFMAs of the previous tile that have issued: free)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_q(0, 0, q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (also drains the previous tile's stores)
+        Frag f0 = ld_frag(0, 0);
+        auto ktile = [&](int kt) {
+            const int st = kt & 1;
+            const bool more = kt + 1 < nk;
+            Frag f1 = ld_frag(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f0, 0);
+            // the next k-tile's 8 DMAs are spread over the first two MFMA groups (one issue slot each behind an MFMA)
+            if (more) { issue_q(kt + 1, st ^ 1, 0); issue_q(kt + 1, st ^ 1, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f0, 2);
+            if (more) { issue_q(kt + 1, st ^ 1, 2); issue_q(kt + 1, st ^ 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f1, 0);
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                f0 = ld_frag(st ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f1, 2);
+        };
+        const int npre = nk > 2 ? nk - 2 : 0;
+        for (int kt = 0; kt < npre; ++kt) ktile(kt);
+        // epilogue operands requested under the last two k-tiles: residual rows + bias (C^T fragment layout: lane = row)
+        f32x4 rv[2][2][4], bv[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tn * BN + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                bv[ni][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const long m = row0 + wm * 64 + mi * 32 + frow;
+                    rv[mi][ni][q] = Rb ? *reinterpret_cast<const f32x4*>(Rb + m * g.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        for (int kt = npre; kt < nk; ++kt) ktile(kt);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            float* crow = Cb + (long)(row0 + wm * 64 + mi * 32 + frow) * g.ldc;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = tn * BN + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                    f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                    v += bv[ni][q];
+                    if (g.act != ACT_NONE) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[jj] = apply_act(v[jj], g.act);
+                    }
+                    v += rv[mi][ni][q];
+                    *reinterpret_cast<f32x4*>(crow + n) = v;
+                }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -499,7 +643,7 @@ static int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_GEMM_TUNE");
-        v = e ? atoi(e) : 17;
+        v = e ? atoi(e) : 49;
     }
     return v;
 }
@@ -529,7 +673,12 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
     const bool vec_out = (g.ldc % 4 == 0) && (g.c_col % 4 == 0) && (!g.R || g.ldr % 4 == 0);
     if ((g.tune & 16) && mode == GM_PLAIN && groups <= 1 && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
         g.lda % 4 == 0 && g.ldw % 4 == 0 && g.a_col % 4 == 0 && vec_out && g.act != ACT_QUICKGELU && !g.act_after_res) {
-        hipLaunchKernelGGL(gemm_dma_k, grid, dim3(256), 0, stream, g);
+        // bit 5: wave-private pipeline variant (no k-loop barrier); needs 32-bit byte offsets into A and W
+        if ((g.tune & 32) && g.K % WBK == 0 && (long)g.M * g.lda * 4 < (1L << 32) && (long)g.N * g.ldw * 4 < (1L << 32)) {
+            const int persistent = 2 * 256;          // 2 workgroups per CU (64 KB of LDS each) on 256 CUs
+            hipLaunchKernelGGL(gemm_wp_k, dim3(grid.x < persistent ? grid.x : persistent), dim3(256), 0, stream, g);
+        } else
+            hipLaunchKernelGGL(gemm_dma_k, grid, dim3(256), 0, stream, g);
         MC_LAUNCH_CHECK();
         return MC_OK;
     }
