@@ -42,3 +42,8 @@ int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s);
 int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_half* W1l, const mc_half* W2h, const mc_half* W2l,
                     bool split, int groups, int max_tiles, hipStream_t s);
 bool mc_mlp_h_supported(int L, int hidden);
+
+// projqkv_k (mc_chain.hip) on the fp16 MFMA: Wph/Wpl [4L][L] planes of MOE.proj, Wqh/Wql [3L][L] planes of the q/k/v weight with
+// the K axis chain-permuted; combine + GELU + LayerNorm stay fp32
+int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
+                        hipStream_t s);

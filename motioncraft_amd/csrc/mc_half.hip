@@ -19,13 +19,23 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi).  The operand is first pinned as a materialised fp32 value: with
+// -ffp-contract=fast hipcc otherwise folds the producer's last multiply into the conversion (v_fma_mix*_f16 = ONE
+// rounding of the exact product) for `hi` while `x - hi` still sees the fp32-rounded product converted separately -- near an
+// fp16 rounding tie the two disagree by one fp16 ulp and hi + lo is off by 2^-11 |x| (seen as 3e-4 errors in 0.16 % of rows).
+__device__ __forceinline__ float pinned(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = (_Float16)a[i];
-        lo[i] = (_Float16)(a[i] - (float)hi[i]);
-        hi[4 + i] = (_Float16)b[i];
-        lo[4 + i] = (_Float16)(b[i] - (float)hi[4 + i]);
+        const float x = pinned(a[i]), y = pinned(b[i]);
+        const _Float16 hx = (_Float16)x, hy = (_Float16)y;
+        hi[i] = hx;
+        lo[i] = (_Float16)(x - pinned((float)hx));
+        hi[4 + i] = hy;
+        lo[4 + i] = (_Float16)(y - pinned((float)hy));
     }
 }
 
@@ -328,6 +338,145 @@ __global__ __launch_bounds__(256, 2) void mlp2_h_k(MlpArgs g, const mc_half* __r
         }
 }
 
+// per-row LayerNorm of a fragment-distributed row (lane l and lane l ^ 32 hold the two halves; column of x[j][i] = 8 j + 4 hf + i)
+template <int NJ>
+__device__ __forceinline__ void frag_layernorm_h(f32x4 (&x)[NJ], const float* __restrict__ gamma, const float* __restrict__ beta, int kq) {
+    constexpr int L = 8 * NJ;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += x[j][0] + x[j][1] + x[j][2] + x[j][3];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)L;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[j][i] -= mean;
+            q += x[j][i] * x[j][i];
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q / (float)L + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 8 * j + kq);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 8 * j + kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[j][i] = x[j][i] * rstd * g[i] + b[i];
+    }
+}
+
+// =================================================================================================
+// projqkv_k (mc_chain.hip) on the fp16 MFMA: a = GELU(w0 y0 + w1 y1);  mf = a Wproj^T + b;  q|k|v = LN(mf[:, :L]) Wqkv^T + b2.
+// The combine / GELU / LayerNorm arithmetic is fp32; only the two weight streams and the row fragments are fp16 (split).
+// The kept body_value accumulators (output chunks c < L/32) become the B operand of the second GEMM in chain order, so
+// Wqkv is stored chain-permuted along K (mc_launch_split_f16_chainperm).
+// =================================================================================================
+template <int L, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void projqkv_h_k(RowChainArgs g, const mc_half* __restrict__ Wph, const mc_half* __restrict__ Wpl,
+                                                      const mc_half* __restrict__ Wqh, const mc_half* __restrict__ Wql) {
+    constexpr int P = SPLIT ? 2 : 1, NKB = L / 16, NJ = L / 8, NC0 = 4 * L / 32, NC1 = 3 * L / 32, NKEEP = L / 32;
+    constexpr int LD1 = L + 8, S1 = 32 * LD1;             // weight chunk [32 out rows][L] per plane
+    constexpr int PC = 32 * L / 8, NP = (PC + 255) / 256;  // 16-byte pieces per plane chunk
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * P * S1 + 2 * 7 * L];
+    float* s_bias = reinterpret_cast<float*>(smem + 2 * P * S1);      // proj bias [4L] | qkv bias [3L]
+    auto Ws = [&](int b, int p) { return smem + (b * P + p) * S1; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, kq = hf * 4;
+    for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
+    for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
+    const long tok = g.tok0 + (long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
+    if (aliasing && g.tok0 + (long)blockIdx.x * 128 >= g.alias.from) return;
+    const bool rok = tok < g.N && !(aliasing && tok >= g.alias.from);
+    u32x4 rw[P][NP];
+    auto fetch = [&](int cg) {           // chunk cg: 0 .. NC0-1 = projection rows, then the q/k/v rows
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const mc_half* src = cg < NC0 ? (p ? Wpl : Wph) + (long)cg * 32 * L : (p ? Wql : Wqh) + (long)(cg - NC0) * 32 * L;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC % 256 == 0 || idx < PC) rw[p][i] = *reinterpret_cast<const u32x4*>(src + (long)(idx / (L / 8)) * L + (idx % (L / 8)) * 8);
+            }
+        }
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC % 256 == 0 || idx < PC) *reinterpret_cast<u32x4*>(Ws(b, p) + (idx / (L / 8)) * LD1 + (idx % (L / 8)) * 8) = rw[p][i];
+            }
+    };
+    fetch(0);
+    f16x8 xh[NKB], xl[NKB];
+    {
+        const long tk = tok < g.N ? tok : 0;
+        const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
+        const long ty = (g.twin_from > 0 && tk >= g.twin_from) ? tk - g.twin_from : tk;
+        const float* y0 = g.X + 2 * ty * L + hf * 8;
+        const bool k0 = w0 != 0.f, k1 = w1 != 0.f;
+        // rows of dropped choices were never written: discarded by a select, not multiplied by 0 (see rowchain_k)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x4 v[2];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const f32x4 ya = *reinterpret_cast<const f32x4*>(y0 + 16 * kb + 4 * hq);
+                const f32x4 yb = *reinterpret_cast<const f32x4*>(y0 + L + 16 * kb + 4 * hq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[hq][i] = gelu_exact((k0 ? w0 * ya[i] : 0.f) + (k1 ? w1 * yb[i] : 0.f));
+            }
+            split8(v[0], v[1], xh[kb], xl[kb]);
+        }
+    }
+    commit(0);
+    fetch(1);
+    __syncthreads();
+    const int fo = (lane & 31) * LD1 + hf * 8;
+    float* orow = g.Y + tok * g.ldy + kq;
+    float* qrow = g.Y2 + tok * g.ldy2 + kq;
+    f32x4 bvf[NJ];                    // body_value row fragment (fp32) for the shared LayerNorm
+    f16x8 bh[NKB], bl[NKB];
+    auto chunk = [&](int cg, const f16x8 (&fh)[NKB], const f16x8 (&fl)[NKB]) {
+        f32x16 a;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(Ws(cg & 1, 0) + fo + 16 * kb);
+            const f16x8 wl = SPLIT ? *reinterpret_cast<const f16x8*>(Ws(cg & 1, P - 1) + fo + 16 * kb) : wh;
+            a = mma3<SPLIT>(wh, wl, fh[kb], fl[kb], a);
+        }
+        return a;
+    };
+    // one chunk: MFMAs -> commit(next) -> bias + stores -> fetch(next + 1)   (order: see rowchain_k)
+#define MC_PQH_CHUNK(cg, FH, FL, OUT, KEEP)                                                                 \
+    {                                                                                                       \
+        const f32x16 a = chunk((cg), FH, FL);                                                               \
+        if ((cg) + 1 < NC0 + NC1) commit(((cg) & 1) ^ 1);                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + (cg) * 32 + 8 * q + kq);              \
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]}; \
+            if (rok) *reinterpret_cast<f32x4*>((OUT) + 8 * q) = v;                                          \
+            KEEP                                                                                            \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if ((cg) + 2 < NC0 + NC1) fetch((cg) + 2);                                                          \
+        __syncthreads();                                                                                    \
+    }
+    // (the qkv bias sits behind the 4L proj biases in s_bias, so chunk cg of either stream reads s_bias + 32 cg)
+#pragma unroll
+    for (int c = 0; c < NKEEP; ++c) MC_PQH_CHUNK(c, xh, xl, orow + c * 32, bvf[4 * c + q] = v;)
+    for (int c = NKEEP; c < NC0; ++c) MC_PQH_CHUNK(c, xh, xl, orow + c * 32, )
+    frag_layernorm_h<NJ>(bvf, g.gamma, g.beta, kq);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) split8(bvf[2 * kb], bvf[2 * kb + 1], bh[kb], bl[kb]);
+    for (int c = 0; c < NC1; ++c) MC_PQH_CHUNK(NC0 + c, bh, bl, qrow + c * 32, )
+#undef MC_PQH_CHUNK
+}
+
 }  // namespace
 
 int mc_launch_split_f16(const float* x, mc_half* hi, mc_half* lo, long n, hipStream_t s) {
@@ -391,6 +540,25 @@ int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_hal
     }
 #undef MC_MLPH_CASE
 #undef MC_MLPH
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
+                        hipStream_t s) {
+    MC_REQUIRE(g.Nout == 4 * g.L && g.ldy % 4 == 0 && g.ldy2 % 4 == 0 && g.bias && g.bias2 && g.Y2 && Wph && Wqh && (!split || (Wpl && Wql)),
+               "fp16 projqkv: bad arguments");
+    if (g.N <= g.tok0) return MC_OK;
+    dim3 grid(cdiv(g.N - g.tok0, 128));
+#define MC_PQH(LL) case LL: if (split) hipLaunchKernelGGL((projqkv_h_k<LL, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql); \
+                            else hipLaunchKernelGGL((projqkv_h_k<LL, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql); break;
+    switch (g.L) {
+        MC_PQH(128)
+        MC_PQH(64)
+        MC_PQH(32)
+        default: mc_set_error("fp16 projqkv: L=%d unsupported", g.L); return MC_ERR_ARG;
+    }
+#undef MC_PQH
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

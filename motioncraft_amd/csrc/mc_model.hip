@@ -48,7 +48,7 @@ struct LayerW {
     // control-branch copies only (ControlT2MBlock): zero-init projections around the copied DecoderLayer
     const float *before_w = nullptr, *before_b = nullptr, *after_w = nullptr, *after_b = nullptr;
     // fp16 planes of the per-step GEMM weights (reduced-precision mode; null until mc_ctx_set_precision builds them)
-    HalfW h_ca_out, h_ffn_out, h_fc1, h_fc2, h_w1, h_w2, h_after;
+    HalfW h_ca_out, h_ffn_out, h_fc1, h_fc2, h_w1, h_w2, h_after, h_proj, h_qkv;
 };
 
 struct mc_ctx {
@@ -268,6 +268,8 @@ int bind_half_weights(mc_ctx* c) {
             if (is_ctrl && (r = half_weight(m, p + "after_w", D, D, false, &w.h_after))) return r;
         }
         if (mc_mlp_h_supported(L, 4 * L)) {
+            if ((r = half_weight(m, p + "mm.proj_w", 4 * L, L, false, &w.h_proj))) return r;
+            if ((r = half_weight(m, p + "dyn.qkv_w", 3 * L, L, true, &w.h_qkv))) return r;
             if ((r = half_weight(m, p + "mm.fc1_w", (long)E * 4 * L, L, false, &w.h_fc1))) return r;
             if ((r = half_weight(m, p + "mm.fc2_wt", (long)E * L, 4 * L, true, &w.h_fc2))) return r;
         }
@@ -456,7 +458,9 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         p.alias = tok_alias;
         if (pq_fused) {       // + the dynamic body topology's shared LayerNorm and q/k/v on the body_value columns
             p.gamma = w.dyn_g; p.beta = w.dyn_b; p.W2 = w.qkv_w; p.bias2 = w.qkv_b; p.Y2 = c->qkv; p.ldy2 = 3 * L;
-            if ((r = mc_launch_projqkv(p, s))) return r;
+            if (c->prec != MC_PREC_F32 && w.h_proj.hi && w.h_qkv.hi) {
+                if ((r = mc_launch_projqkv_h(p, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
+            } else if ((r = mc_launch_projqkv(p, s))) return r;
         } else if ((r = mc_launch_rowchain(0, p, s))) return r;
     } else {
         GemmArgs p;
@@ -1211,6 +1215,7 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
     else if (n == "proj") { p = c->proj; cnt = c->N * 256; }
     else if (n == "mf") { p = c->mf; cnt = c->N * 4 * L; }
     else if (n == "qkv") { p = c->qkv; cnt = c->N * 3 * L; }
+    else if (n == "y2") { p = c->y2; cnt = c->N * 2 * L; }
     else if (n == "ys") { p = c->ys; cnt = c->rows * D; }
     else if (n == "yt") { p = c->yt; cnt = c->rows * D; }
     else if (n == "a") { p = c->a; cnt = c->rows * D; }

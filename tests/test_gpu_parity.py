@@ -593,6 +593,35 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     nm.close()
 
 
+def test_fp16_mfma_large_batch_kernels_single_step_vs_oracle(full_model):
+    """The large-batch kernel selection of the reduced-precision mode (N > 65 536 tokens: proj + body LayerNorm + q/k/v in
+    one chained fp16-MFMA kernel, two sample groups on two streams, twin dedupe in layer 0): one denoiser call at B=16,
+    196 frames, mixed lengths, against the fp32 oracle teacher-forced to the HIP path's routing."""
+    from oracle import stmogen_oracle as O
+    sd, nm = full_model
+    B, T = 16, 196
+    g = torch.Generator().manual_seed(15)
+    lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(FULL, B, T, seed=34, lengths=lengths)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    tf = O.precompute_text(sd, xf, FULL)
+    w = (1 - (1000 - 640) / 1000) * FULL['scale'] + 1
+    for prec, tol in (('f16x3', TOL_STEP), ('f16', 3e-2)):
+        ctx = nm.context(B, T, max_steps=1)
+        ctx.set_precision(prec)
+        ctx.enable_capture()
+        ctx.set_timesteps([640])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out2 = ctx.denoise(x_T.cuda(), 0)
+        assert torch.equal(out2, ctx.denoise(x_T.cuda(), 0))
+        forced = [ctx.routing(i) for i in range(FULL['NL'])]
+        ref = O.denoise(sd, FULL, x_T, 640, xf, mask, text_feats=tf, forced_routing=forced)
+        err = maxabs(out2[:B] * w + out2[B:] * (1 - w), ref)
+        print(f'B=16 single step, precision {prec}: |hip - fp32 oracle (teacher-forced)| {err:.2e}')
+        assert err <= tol, (prec, err)
+        ctx.close()
+
+
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])
 def test_hipgraph_replay_of_the_sampler_step_is_bit_identical(prec):
     """BASELINE.json configs[4] "hipGraph-captured 50-step DDIM": ONE captured graph of mc_sample_step (step index in device
