@@ -300,6 +300,34 @@ def main():
         c2[0].close()
         c2[1].close()
 
+    # ---- side measurement (NOT `value`): the reduced-precision MFMA modes of BASELINE configs[4] on the same workload:
+    # 'f16x3' = fp16 hi/lo split operands, three products, fp32 accumulate (fp32-class results: tests hold it to the same
+    # 1e-3 lockstep bound, observed 1.3e-5); 'f16' = one fp16 rounding per operand.  Gate / routing / normalisations fp32. ----
+    reduced = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        reduced = {}
+        for prec in ('f16x3', 'f16'):
+            cj = nm.context(B, T, max_steps=8)
+            cj.set_precision(prec)
+            cj.set_timesteps(diff.timestep_map[-8:])
+            cj.set_condition(xf, mask)
+            xa, xb = torch.randn(B, T, C, device=dev, generator=gen), torch.empty(B, T, C, device=dev)
+            e_ = torch.randn(B, T, C, device=dev, generator=gen)
+            for _ in range(3):
+                cj.sample_step(xa, 5, coefs[5], e_, x_prev=xb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nrep = 20
+            for _ in range(nrep):
+                cj.sample_step(xa, 5, coefs[5], e_, x_prev=xb)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / nrep
+            reduced[prec] = {'ms_per_step': round(dtp * 1e3, 3),
+                             'frames_per_s': round(B * T / (t_setup + TOTAL_DDPM_STEPS * dtp + t_gather), 1)}
+            cj.close()
+        reduced['note'] = ('side measurement, not `value`: mc_ctx_set_precision modes (include/motioncraft_amd.h); the headline '
+                           'stays the exact fp32 MFMA path')
+
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms, t_full or 0.0], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,7 +357,7 @@ def main():
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
-                       'full_loop': full_loop,
+                       'full_loop': full_loop, 'reduced_precision_modes': reduced,
                        'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
                        'exact_reductions': 'results equal the unreduced computation (tests/test_gpu_parity.py): CFG twins of base layer 0 '
                                            'share gate / expert / proj / qkv / body work (identical inputs); the last StylizationBlock '
