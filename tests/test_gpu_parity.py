@@ -673,6 +673,37 @@ def test_hipgraph_replay_of_the_sampler_step_is_bit_identical(prec):
         nm.close()
 
 
+def test_wrap_fp16_model_and_graph_replay_through_the_reference_api(small_model):
+    """The reference tools' fp16 hook (`if cfg.get('fp16') is not None: wrap_fp16_model(model)`, tools/test.py:95-97) and the
+    replay option, through configs -> build_architecture -> MotionDiffusion.forward: fp16-split + hipGraph replay must
+    reproduce the plain fp32 eager result of the same call within the north-star tolerance, replay itself bit for bit."""
+    import motioncraft_amd as mc
+    sd, _ = small_model
+    g = load('small_ddim.npz')
+    B, T = 2, 24
+    noises = step_noise_from_seed(int(g['noise_seed']), (B, T, 322), 50)
+    mask = T_(g['motion_mask'])
+    call = lambda arch, **inf: torch.stack([r['pred_motion'] for r in arch(
+        motion=torch.zeros(B, T, 322), motion_mask=mask, motion_length=mask.sum(1, keepdim=True).long(),
+        motion_metas=[{'text': 'a'}, {'text': 'b'}], xf_out=T_(g['xf_out']),
+        inference_kwargs=dict(noise=T_(g['x_T']), step_noise=lambda i: noises[49 - i], **inf))])
+    cfg, arch = _arch_small(sd)
+    ref32 = call(arch)
+    assert maxabs(ref32, T_(g['final'])) <= TOL_FINAL
+    assert torch.equal(call(arch, graph=True), ref32)                      # replay of the fp32 step: bit-identical
+    assert mc.wrap_fp16_model(arch) is arch and arch.model.precision == 'f16x3'
+    h3 = call(arch)
+    assert torch.equal(call(arch, graph=True), h3)
+    e3 = maxabs(h3, T_(g['final']))
+    mc.wrap_fp16_model(arch, split=False)
+    e1 = maxabs(call(arch), T_(g['final']))
+    print(f'wrap_fp16_model through the API, 50-step DDIM final vs reference golden: f16x3 {e3:.2e}, f16 {e1:.2e}')
+    assert e3 <= TOL_FINAL
+    with pytest.raises(TypeError):
+        mc.wrap_fp16_model(object())
+    arch.model.release()
+
+
 def test_control_branch_vs_reference_golden():
     """ControlT2MHalf (a15; BASELINE configs 3-5 form): copied DecoderLayers + zero-init projections + condition
     padding/CFG masking, through the reference-style wrapper API and through the raw context."""
