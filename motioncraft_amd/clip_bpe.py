@@ -2,7 +2,9 @@
 
 The reference calls ``clip.tokenize(text, truncate=True)`` (``mogen/models/transformers/diffusion_transformer.py:145``)
 of the un-vendored ``clip`` package (openai/CLIP, ``clip/simple_tokenizer.py``).  Its vocabulary file
-(``bpe_simple_vocab_16e6.txt.gz``) ships inside that package, so it is not available offline: PARITY UNPINNED.  When the
+(``bpe_simple_vocab_16e6.txt.gz``) ships inside that package, so it is not available offline: the VOCABULARY is
+unpinned; the algorithm is pinned against ``transformers.CLIPTokenizer`` on a shared synthetic vocabulary
+(tests/test_host.py).  When the
 package is importable ``text_encoder.NativeTextEncoder.encode_text`` uses it directly; this module restates the
 published scheme for installations that only carry the vocabulary file:
 

@@ -5,8 +5,9 @@ pinned against the reference's own ``encode_text(text, clip_feat)`` by tests/gol
 tests/golden/text_encoder.npz.
 
 Stage B (the CLIP ViT-B/32 text transformer the reference calls at diffusion_transformer.py:144-151) lives in the
-un-vendored ``clip`` package (openai/CLIP, no version pin in the reference's requirements).  PARITY UNPINNED for stage
-B: the published architecture is restated here (clip/model.py: ``ResidualAttentionBlock`` = x + attn(ln_1(x), causal
+un-vendored ``clip`` package (openai/CLIP, no version pin in the reference's requirements), so it cannot be pinned to the
+reference's own dependency; it IS pinned (bit-equal, tests/golden/clip_tower_hf.npz) to the installed independent
+implementation of the same published architecture, ``transformers.CLIPTextModel``.  The published architecture is restated here (clip/model.py: ``ResidualAttentionBlock`` = x + attn(ln_1(x), causal
 mask); x + c_proj(QuickGELU(c_fc(ln_2(x)))); ``QuickGELU`` = x * sigmoid(1.702 x); ``ln_final``), built from the same
 torch primitives (``F.multi_head_attention_forward``, ``F.layer_norm``) that stage A pins.
 """

@@ -25,6 +25,8 @@ Fixtures
   repaint_small.npz     RePaint / outpainting DDIM mode (reduced config, first 6 frames kept): harmonize loop with
                         resampling (jump 3 x 5), without resampling, and no_repaint (plain 50 steps + blending)
   text_encoder.npz      encode_text(text, clip_feat): text_pre_proj + 2-layer nn.TransformerEncoder + text_ln (Dt=256)
+  clip_tower_hf.npz     CLIP text transformer (reduced: width 128, 2 layers) -> features of transformers.CLIPTextModel, the
+                        installed independent implementation of the un-vendored clip package's text tower
   wav_encoder.npz       WavEncoder(out_dim=64, audio_in=2), eval mode: 2 x 4000 samples -> reference output
   skeleton_parts.npz    8-part layouts: human_ml3d (263-d) and kit_ml (251-d) reduced configs (x0 at two t + 50-step
                         DDIM final), and the shipped T2M_humanml3d.py architecture (L=64, H=8) x0 at t=500
@@ -337,6 +339,53 @@ def text_encoder():
 
 
 WAV_DIM, WAV_IN, WAV_SAMPLES = 64, 2, 4000
+
+
+def clip_tower():
+    """The CLIP text transformer (stage B of encode_text, diffusion_transformer.py:144-151) lives in the un-vendored `clip`
+    package.  Its published architecture is pinned here against a SECOND independent implementation that is installed:
+    transformers.CLIPTextModel (hidden_act='quick_gelu', causal mask, pre-LN blocks, final_layer_norm) -- the class the
+    OpenAI checkpoints are served through on the HF hub.  The deterministic (seed, key) weights of oracle/weights.py are
+    loaded into it under the OpenAI -> HF key mapping; its last_hidden_state = ln_final(transformer(tok + pos))."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from oracle import text_encoder_oracle as TO
+    width, layers, heads, ff, vocab, seed = 128, 2, 2, 256, 300, 4
+    shapes = W.text_encoder_param_shapes(256, 2, 2048, clip_width=width, clip_layers=layers, clip_ff=ff, vocab=vocab)
+    sd = W.make_text_encoder_state(shapes, seed=seed)
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=width, intermediate_size=ff, num_hidden_layers=layers,
+                         num_attention_heads=heads, max_position_embeddings=77, hidden_act='quick_gelu',
+                         eos_token_id=vocab - 1, bos_token_id=vocab - 2, pad_token_id=0)
+    m = CLIPTextModel(cfg).eval()
+    hf = {'embeddings.token_embedding.weight': sd['clip.token_embedding.weight'],
+          'embeddings.position_embedding.weight': sd['clip.positional_embedding'],
+          'final_layer_norm.weight': sd['clip.ln_final.weight'], 'final_layer_norm.bias': sd['clip.ln_final.bias']}
+    for i in range(layers):
+        a, b = f'clip.transformer.resblocks.{i}.', f'encoder.layers.{i}.'
+        wq, bq = sd[a + 'attn.in_proj_weight'], sd[a + 'attn.in_proj_bias']
+        for j, n in enumerate(('q_proj', 'k_proj', 'v_proj')):
+            hf[b + f'self_attn.{n}.weight'], hf[b + f'self_attn.{n}.bias'] = wq[j * width:(j + 1) * width], bq[j * width:(j + 1) * width]
+        hf[b + 'self_attn.out_proj.weight'], hf[b + 'self_attn.out_proj.bias'] = sd[a + 'attn.out_proj.weight'], sd[a + 'attn.out_proj.bias']
+        hf[b + 'layer_norm1.weight'], hf[b + 'layer_norm1.bias'] = sd[a + 'ln_1.weight'], sd[a + 'ln_1.bias']
+        hf[b + 'layer_norm2.weight'], hf[b + 'layer_norm2.bias'] = sd[a + 'ln_2.weight'], sd[a + 'ln_2.bias']
+        hf[b + 'mlp.fc1.weight'], hf[b + 'mlp.fc1.bias'] = sd[a + 'mlp.c_fc.weight'], sd[a + 'mlp.c_fc.bias']
+        hf[b + 'mlp.fc2.weight'], hf[b + 'mlp.fc2.bias'] = sd[a + 'mlp.c_proj.weight'], sd[a + 'mlp.c_proj.bias']
+    inner = getattr(m, 'text_model', m)             # (transformers >= 5 keeps the layers on the model itself)
+    missing, unexpected = inner.load_state_dict(hf, strict=False)
+    assert not unexpected and all('position_ids' in k for k in missing), (missing, unexpected)
+    g = torch.Generator().manual_seed(5)
+    tokens = torch.randint(1, vocab - 2, (3, 77), generator=g)
+    tokens[:, 0] = vocab - 2
+    for b, n in enumerate((9, 30, 76)):                 # end token, then zero padding like clip.tokenize
+        tokens[b, n] = vocab - 1
+        tokens[b, n + 1:] = 0
+    with torch.no_grad():
+        ref = m(input_ids=tokens).last_hidden_state
+    ours = TO.clip_text_features(sd, tokens, layers, heads=heads)
+    e = maxabs(ours, ref)
+    print(f'clip_tower: oracle restatement vs transformers.CLIPTextModel: max {e:.2e}')
+    assert e <= 1e-5
+    np.savez_compressed(os.path.join(OUT, 'clip_tower_hf.npz'), tokens=tokens.numpy(), feat=ref.numpy(), seed=np.int64(seed),
+                        width=np.int64(width), layers=np.int64(layers), heads=np.int64(heads), ff=np.int64(ff), vocab=np.int64(vocab))
 
 
 def wav_encoder():
@@ -675,7 +724,7 @@ if __name__ == '__main__':
     a = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))   # torch-CPU degrades badly on >64 threads
     groups = dict(schedules=schedules, small_modules=small_modules, small_loops=small_loops, preseq=preseq, control=control,
-                  repaint=repaint, text_encoder=text_encoder, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, evaluator=evaluator, t2m_evaluator=t2m_evaluator, full=full)
+                  repaint=repaint, text_encoder=text_encoder, clip_tower=clip_tower, wav_encoder=wav_encoder, control_wav=control_wav, skeleton_parts=skeleton_parts, evaluator=evaluator, t2m_evaluator=t2m_evaluator, full=full)
     for name, fn in groups.items():
         if a.only is not None and name not in a.only.split(','):
             continue

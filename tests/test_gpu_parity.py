@@ -940,6 +940,17 @@ def test_text_encoder_vs_reference_golden_and_clip_tower_vs_oracle():
     e1, e2 = maxabs(feat, feat_ref), maxabs(xf, xf_ref)
     print(f'text encoder stage B (CLIP tower): |hip - oracle| features {e1:.2e}, xf_out {e2:.2e}')
     assert e1 <= 1e-4 and e2 <= 1e-4
+    # the tower against an independent implementation: features of transformers.CLIPTextModel (clip_tower_hf.npz)
+    gh = load('clip_tower_hf.npz')
+    shapes_h = W.text_encoder_param_shapes(256, 2, 2048, clip_width=int(gh['width']), clip_layers=int(gh['layers']),
+                                           clip_ff=int(gh['ff']), vocab=int(gh['vocab']))
+    ench = NativeTextEncoder(cfg, W.make_text_encoder_state(shapes_h, seed=int(gh['seed'])),
+                             clip=dict(width=int(gh['width']), layers=int(gh['layers']), heads=int(gh['heads']), ff=int(gh['ff'])))
+    _, feat_h = ench.encode_tokens(torch.from_numpy(gh['tokens']).cuda(), return_clip_feat=True)
+    e3 = maxabs(feat_h, T_(gh['feat']))
+    print(f'text encoder stage B (CLIP tower): |hip - transformers.CLIPTextModel| {e3:.2e}')
+    assert e3 <= 1e-4
+    ench.close()
     # causality: changing a later token must not change earlier positions of the CLIP features
     tokens2 = tokens.clone()
     tokens2[:, 40:] = (tokens2[:, 40:] + 1) % 1000

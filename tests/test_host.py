@@ -398,6 +398,59 @@ def test_clip_byte_pair_tokenizer_on_a_synthetic_merges_file(tmp_path):
         bpe.tokenize(['run ' * 100], context_length=8, truncate=False)
 
 
+def test_clip_bpe_vs_huggingface_tokenizer_on_a_learned_synthetic_vocabulary(tmp_path):
+    """Second, independent implementation of the CLIP byte-pair scheme: transformers.CLIPTokenizer (the Rust `tokenizers`
+    BPE model with the `</w>` suffix, ByteLevel alphabet and CLIP's split regex).  The real vocabulary file is
+    un-vendored, so both are driven by the SAME synthetic vocabulary: 60 merges learned greedily on a toy corpus, ids in
+    the layout clip/simple_tokenizer.py builds.  Ids must agree up to and including the end token (the pad id differs by
+    design: clip.tokenize pads with 0, the HF tokenizer with its pad token)."""
+    import gzip
+    transformers = pytest.importorskip('transformers')
+    from motioncraft_amd.clip_bpe import ClipBPE, byte_symbols
+    corpus = ("a person walks forward then turns left and waves both hands . the dancer jumps , spins & lands softly ; "
+              "it's running 12 times while they're clapping").split()
+    sym = byte_symbols()
+    words = [[sym[b] for b in w.encode()] for w in corpus]
+    words = [w[:-1] + [w[-1] + '</w>'] for w in words]
+    merges = []
+    for _ in range(60):
+        cnt = {}
+        for w in words:
+            for pr in zip(w[:-1], w[1:]):
+                cnt[pr] = cnt.get(pr, 0) + 1
+        if not cnt:
+            break
+        best = max(sorted(cnt), key=lambda pr: cnt[pr])
+        merges.append(best)
+        nw = []
+        for w in words:
+            o, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    o.append(w[i] + w[i + 1])
+                    i += 2
+                else:
+                    o.append(w[i])
+                    i += 1
+            nw.append(o)
+        words = nw
+    path = tmp_path / 'bpe.txt.gz'
+    with gzip.open(path, 'wb') as f:
+        f.write(('#version: test\n' + '\n'.join(' '.join(m) for m in merges)).encode('utf-8'))
+    bpe = ClipBPE(str(path), vocab_size=256 + 256 + len(merges) + 2)
+    hf = transformers.CLIPTokenizer(vocab=dict(bpe.ids), merges=[tuple(m) for m in merges])
+    texts = ['A person walks forward, then turns LEFT!', "the dancer's hands... wave   softly\n12 times", 'naïve café 3x — ¿qué?',
+             "they're running & it's   spinning;lands", 'x' * 300, 'walks ' * 90, '', '  ']
+    for t in texts:
+        a = bpe.tokenize([t], context_length=77)[0].tolist()
+        b = hf(t, padding='max_length', max_length=77, truncation=True)['input_ids']
+        n = a.index(bpe.eot) + 1
+        assert a[:n] == b[:n], t
+        assert all(v == 0 for v in a[n:])
+    # what clip.tokenize does and the HF tokenizer does not: html entities are unescaped (twice) first
+    assert bpe.encode('a &amp;amp; b') == bpe.encode('a & b') != hf('a &amp;amp; b')['input_ids'][1:-1]
+
+
 def test_t2m_token_vectorisation_layout():
     """T2MTextEncoder.forward's host part (t2m_bigru.py:131-165): sos / eos / unk padding and truncation at max_text_len."""
     from motioncraft_amd.evaluation import vectorize_tokens

@@ -160,6 +160,18 @@ def test_tutel_moe_dump_fixture(path):
     assert matched, 'the restated tutel semantics do not reproduce this dump under either tie policy'
 
 
+def test_clip_text_tower_against_the_huggingface_implementation_golden():
+    """Stage B of encode_text (the un-vendored `clip` package's text transformer): oracle/text_encoder_oracle.py vs the
+    features of transformers.CLIPTextModel on the same (seed, key) weights (clip_tower_hf.npz, made by make_golden.py)."""
+    from oracle import text_encoder_oracle as TO
+    g = load('clip_tower_hf.npz')
+    shapes = W.text_encoder_param_shapes(256, 2, 2048, clip_width=int(g['width']), clip_layers=int(g['layers']),
+                                         clip_ff=int(g['ff']), vocab=int(g['vocab']))
+    sd = W.make_text_encoder_state(shapes, seed=int(g['seed']))
+    feat = TO.clip_text_features(sd, torch.from_numpy(g['tokens']), int(g['layers']), heads=int(g['heads']))
+    assert float((feat - T_(g['feat'])).abs().max()) <= 1e-5
+
+
 def test_full_size_denoise_against_golden():
     g = load('full_denoise.npz')
     sd = W.make_state_dict(FULL, 0)
