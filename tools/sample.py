@@ -43,6 +43,9 @@ def parse_args():
     p.add_argument('--timestep_respacing', default='ddim50'), p.add_argument('--jump_n_sample', type=int, default=5)
     p.add_argument('--jump_length', type=int, default=3), p.add_argument('--addBlend', type=bool, default=True)
     p.add_argument('--no_repaint', action='store_true')
+    # MI355X options: fp16 MFMA (also switched on by a top-level `fp16 = dict(...)` in the config, tools/test.py:95-97), replay
+    p.add_argument('--fp16', choices=['split', 'plain'], default=None, help='fp16-MFMA mode: split = fp32-class hi/lo form')
+    p.add_argument('--graph', action='store_true', help='hipGraph replay of the sampler step')
     return p.parse_args()
 
 
@@ -58,6 +61,8 @@ def main():
     else:
         load_checkpoint(model, a.checkpoint, map_location='cpu')
     model.eval()
+    if a.fp16 or cfg.get('fp16', None) is not None:
+        mc.wrap_fp16_model(model, split=(a.fp16 != 'plain'))
     dims = model.model.dims
     n, T, C = len(a.text), max(a.motion_length), dims['input_feats']
     if not 1 <= T <= dims['max_seq_len']:
@@ -69,7 +74,7 @@ def main():
     kw = dict(motion=torch.zeros(n, T, C, device=dev), motion_mask=mask,
               motion_length=torch.tensor(a.motion_length, device=dev).long(), num_intervals=n,
               motion_metas=[{'text': t} for t in a.text],
-              inference_kwargs=dict(generator=torch.Generator(device=dev).manual_seed(a.seed)))
+              inference_kwargs=dict(generator=torch.Generator(device=dev).manual_seed(a.seed), **({'graph': True} if a.graph else {})))
     if a.xf_out:
         kw['xf_out'] = torch.from_numpy(np.load(a.xf_out)).float().to(dev)
     elif a.clip_feat:
