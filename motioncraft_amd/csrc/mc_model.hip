@@ -69,7 +69,8 @@ struct mc_ctx {
     float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2, *xpad;
     size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
     float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
-    const float* mask = nullptr;
+    const float* mask = nullptr;   // = mask_own after mc_ctx_set_condition (a private copy: the pointer is baked into captured graphs)
+    float* mask_own = nullptr;
     int* t_orig;
     float *te, *e1, *emb, *semb, *ss;   // ss: [NL][2][maxS][2D]
     RouteBufs rb;
@@ -775,6 +776,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->out2, c->rows * g.input_feats);
     WS(c->xpad, (long)batch * frames * m->Cp);
     WS(c->xfn, c->Ntxt * Dt);
+    WS(c->mask_own, (long)batch * frames);
     WS(c->tf, (long)c->NLA * c->Ntxt * 2 * L);
     WS(c->t_orig, max_steps);
     WS(c->te, (long)max_steps * D);
@@ -883,7 +885,8 @@ int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_d
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, Dt = g.text_latent_dim, Nt = g.max_text_len;
     const long half = (long)c->B * Nt;
-    c->mask = mask_dev;
+    MC_HIP(hipMemcpyAsync(c->mask_own, mask_dev, sizeof(float) * c->B * c->T, hipMemcpyDeviceToDevice, s));
+    c->mask = c->mask_own;
     int r;
     for (int i = 0; i < c->NLA; ++i) {
         const LayerW& w = c->lw[i];

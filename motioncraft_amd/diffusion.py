@@ -239,16 +239,26 @@ class GaussianDiffusion:
             # (profiles/r02_graph_vs_eager.txt)
             if inp is not None or seeded or trajectory is not None:
                 raise ValueError('graph replay covers the plain p_sample / ddim_sample step (no outpainting, seeding or trajectory)')
-            side = torch.cuda.Stream(device=device)
+            # the graph (and the x / noise buffers baked into it) lives on the context and is reused by later calls with the
+            # same schedule: capture + instantiate cost a few ms, more than one small-batch loop gains
+            key = (mode, float(eta), float(model.cfg_scale), tuple(int(t) for t in self.timestep_map))
+            st = getattr(ctx, '_graph_state', None)
+            if st is None or st['key'] != key:
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    gx, nbuf = torch.empty_like(img), torch.empty_like(img)
+                    coefs = [self.step_coefs(j, mode, model.cfg_scale, eta) for j in range(self.num_timesteps)]
+                    ctx.graph_capture(gx, nbuf, coefs)
+                st = ctx._graph_state = dict(key=key, stream=side, x=gx, noise=nbuf)
+            side = st['stream']
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
-                nbuf = torch.empty_like(img)
-                coefs = [self.step_coefs(j, mode, model.cfg_scale, eta) for j in range(self.num_timesteps)]
-                ctx.graph_capture(img, nbuf, coefs)
+                st['x'].copy_(img)
                 for i, _ in plan:
-                    nbuf.copy_(draw(i))
+                    st['noise'].copy_(draw(i))
                     ctx.graph_step(i)
-                ctx.graph_release()
+                img.copy_(st['x'])
             torch.cuda.current_stream(device).wait_stream(side)
             return img
         for i, denoise in plan:

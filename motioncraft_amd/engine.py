@@ -77,6 +77,7 @@ class NativeContext:
         self.handle = h
         self.timesteps = None
         self._keep = []
+        self._graph_state = None
 
     @property
     def workspace_bytes(self):
@@ -86,10 +87,16 @@ class NativeContext:
         """Keep every layer's routing decisions of the last denoise call (tests)."""
         _lib.check(self.lib.mc_ctx_enable_capture(self.handle), 'mc_ctx_enable_capture')
 
+    def _drop_graph(self):
+        # a captured graph bakes in the kernel selection and the condition buffers of the moment of capture
+        if getattr(self, '_graph_state', None) is not None:
+            self.graph_release()
+
     def set_precision(self, precision):
         """'f32' (default, exact fp32 MFMA), 'f16' (fp16 operands, fp32 accumulate) or 'f16x3' (fp16 hi/lo split, three
         products: fp32-class) for the per-step GEMM-shaped kernels; gate / routing / normalisations stay fp32."""
         code = {'f32': 0, 'f16': 1, 'f16x3': 2}[precision]
+        self._drop_graph()
         _lib.check(self.lib.mc_ctx_set_precision(self.handle, code), 'mc_ctx_set_precision')
         self.precision = precision
 
@@ -106,6 +113,7 @@ class NativeContext:
         return idx, keep
 
     def set_timesteps(self, t_orig):
+        self._drop_graph()
         t = np.ascontiguousarray(np.asarray(t_orig, dtype=np.int32))
         _lib.check(self.lib.mc_ctx_set_timesteps(self.handle, t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                                  len(t), _stream()), 'mc_ctx_set_timesteps')
@@ -119,11 +127,14 @@ class NativeContext:
             raise ValueError(f'xf_out shape {tuple(xf.shape)} != {(self.B, d["Nt"], d["Dt"])}')
         if mask.numel() != self.B * self.T:
             raise ValueError(f'motion_mask has {mask.numel()} elements, expected {self.B * self.T}')
-        self._keep = [xf, mask]        # the library reads the mask every step: keep it alive
+        self._keep = [xf, mask]        # (the library copies the mask; a captured graph stays valid across conditions)
         _lib.check(self.lib.mc_ctx_set_condition(self.handle, _ptr(xf), _ptr(mask), _stream()), 'mc_ctx_set_condition')
 
     def set_control(self, c_feat):
         """c_feat [B, Tc, control_cond_feats] (output of the step-invariant condition pre-encoder) or None."""
+        if (c_feat is None) != (not getattr(self, '_ctrl_on', False)):
+            self._drop_graph()         # control branch on / off changes the captured launch sequence
+        self._ctrl_on = c_feat is not None
         if c_feat is None:
             _lib.check(self.lib.mc_ctx_set_control(self.handle, None, 0, _stream()), 'mc_ctx_set_control')
             return
@@ -171,6 +182,7 @@ class NativeContext:
     def graph_release(self):
         _lib.check(self.lib.mc_ctx_graph_release(self.handle), 'mc_ctx_graph_release')
         self._graph_keep = None
+        self._graph_state = None
 
     def sample_step_seeded(self, x_t, step_index, coefs, noise, sqrt_ab, sqrt_1mab, pre_seq=None, pre_noise=None,
                            transl=(), x_prev=None, x0=None):
