@@ -7,6 +7,7 @@
 #include "mc_common.h"
 #include "mc_kernels.h"
 #include <utility>
+#include <stdlib.h>
 
 namespace {
 
@@ -131,7 +132,11 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
 // directly from registers (no A2 round trip through LDS).  K/V rows stream through one 32-row LDS
 // chunk, softmax_L(Q) rows through a [32][L+4] slab read as b128 A fragments.
 // ---------------------------------------------------------------------------------------
-template <int L>
+// LSPLIT (small batches: a few dozen workgroups, each bound by the serial MFMA chain of its 4 waves): the L output
+// columns are cut into 32-wide slices on blockIdx.y; inside a workgroup wave w then owns ONE 32 x 32 tile of A2 (d tile w
+// of the slice's columns) instead of all L/32 d tiles of its own columns, and the partial products of the second
+// contraction (one d tile per wave) are summed through LDS.  4x the workgroups, a quarter of the MFMA chain per wave.
+template <int L, bool LSPLIT>
 __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                      const float* __restrict__ mask, float* __restrict__ yt,
                                                      int b0, int B, int T, int Nt, int H, const int* twin_flag) {
@@ -139,7 +144,8 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
     constexpr int LP = L + 4;
     constexpr int C4 = L / 4;            // float4 columns per row
     constexpr int NSL = 256 / C4;        // row slices in the stats pass
-    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP];
+    constexpr int NACC = LSPLIT ? 1 : NT;
+    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP + (LSPLIT ? NT * 32 * 33 : 0)];
     float* s_m = sm;
     float* s_s = s_m + L;
     float* s_pm = s_s + L;               // [NSL][L]
@@ -147,6 +153,8 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
     float* Ks = s_ps + NSL * L;          // [32][LP]
     float* Vs = Ks + 32 * LP;            // [32][LP]
     float* Qs = Ks;                      // [32][LP]  phase 3 reuses the K slab (43 KB total -> 3 workgroups per CU)
+    float* Ps = Vs + 32 * LP;            // LSPLIT: [NT][32][33] partial y_t tiles of the waves
+    const int ls = LSPLIT ? (int)blockIdx.y : 0;      // output column slice (LSPLIT)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = b0 + blockIdx.x / H, h = blockIdx.x % H;
@@ -234,9 +242,9 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
 
     // ---- phase 2: A2[d][l] = sum_n softmaxK[n][d] V[n][l]  (st_attention.py:167) ----
     const bool mm_active = wave < NT;
-    f32x16 acc[NT];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int dt = 0; dt < NT; ++dt)
+    for (int dt = 0; dt < NACC; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const int nch = (Nseq + 31) / 32;
@@ -277,11 +285,17 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
 #pragma unroll 4
             for (int ks = 0; ks < 16; ++ks) {
                 const int n = 2 * ks + hf;
-                const float bb = Vs[n * LP + wave * 32 + (lane & 31)];
+                if constexpr (LSPLIT) {      // tile (d tile = wave, column slice ls)
+                    const float bb = Vs[n * LP + ls * 32 + (lane & 31)];
+                    const float a = Ks[n * LP + wave * 32 + (lane & 31)];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[0], 0, 0, 0);
+                } else {
+                    const float bb = Vs[n * LP + wave * 32 + (lane & 31)];
 #pragma unroll
-                for (int dt = 0; dt < NT; ++dt) {
-                    const float a = Ks[n * LP + dt * 32 + (lane & 31)];
-                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[dt], 0, 0, 0);
+                    for (int dt = 0; dt < NT; ++dt) {
+                        const float a = Ks[n * LP + dt * 32 + (lane & 31)];
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[dt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -337,21 +351,43 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
             const float* qp = Qs + (lane & 31) * LP + 4 * hf;
-#pragma unroll
-            for (int dt = 0; dt < NT; ++dt)
+            if constexpr (LSPLIT) {          // this wave's d tile only: a partial sum over d
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(qp + dt * 32 + 8 * q);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(qp + wave * 32 + 8 * q);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], acc[dt][4 * q + i], o, 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], acc[0][4 * q + i], o, 0, 0, 0);
                 }
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int t = tc * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
-                if (t < T) yt[((long)b * T + t) * (H * L) + h * L + wave * 32 + (lane & 31)] = o[reg];
+                for (int reg = 0; reg < 16; ++reg)
+                    Ps[(wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf) * 33 + (lane & 31)] = o[reg];
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(qp + dt * 32 + 8 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], acc[dt][4 * q + i], o, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int t = tc * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+                    if (t < T) yt[((long)b * T + t) * (H * L) + h * L + wave * 32 + (lane & 31)] = o[reg];
+                }
             }
         }
         __syncthreads();
+        if constexpr (LSPLIT) {              // y_t tile = sum of the waves' partials in d-tile order (fixed: deterministic)
+            for (int i = tid; i < 32 * 32; i += 256) {
+                const int tr = i >> 5, l = i & 31, t = tc * 32 + tr;
+                float v = Ps[tr * 33 + l];
+#pragma unroll
+                for (int w = 1; w < NT; ++w) v += Ps[(w * 32 + tr) * 33 + l];
+                if (t < T) yt[((long)b * T + t) * (H * L) + h * L + ls * 32 + l] = v;
+            }
+            // (Ps is rewritten only after the next chunk's barrier; Qs is rewritten before it, but no one reads Qs here)
+        }
     }
 }
 
@@ -379,9 +415,20 @@ int mc_launch_temporal(const float* mf, const float* tf, const float* mask, floa
                        int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag) {
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
-    if (L == 128) hipLaunchKernelGGL(temporal_k<128>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-    else if (L == 64) hipLaunchKernelGGL(temporal_k<64>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-    else if (L == 32) hipLaunchKernelGGL(temporal_k<32>, grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    // small batches: a few dozen (sample, part) workgroups, each bound by its waves' serial MFMA chain -> cut the L output
+    // columns into 32-wide slices on blockIdx.y (temporal_k<L, true>).  50-step DDIM, 196 frames: B=1 70.4 -> 66.4 ms, B=2 96.1 ->
+    // 92.3, B=4 128.3 -> 127.0; from B=8 (192 workgroups) the unsplit kernel is faster again
+    static const long lsplit_max = [] { const char* e = getenv("MC_TEMPORAL_SPLIT"); return e ? atol(e) : 96L; }();
+    if (L >= 64 && (long)nb * H <= lsplit_max) {
+        grid.y = L / 32;
+        if (L == 128) hipLaunchKernelGGL((temporal_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        else hipLaunchKernelGGL((temporal_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
+    if (L == 128) hipLaunchKernelGGL((temporal_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    else if (L == 64) hipLaunchKernelGGL((temporal_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    else if (L == 32) hipLaunchKernelGGL((temporal_k<32, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
     else { mc_set_error("temporal: latent_dim=%d unsupported (32, 64, 128)", L); return MC_ERR_ARG; }
     MC_LAUNCH_CHECK();
     return MC_OK;
