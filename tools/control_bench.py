@@ -27,6 +27,8 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(B, T, 322, generator=g).cuda()
 xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],)).cuda()
 ctx = nm.context(B, T, max_steps=50)
+PREC = os.environ.get('MC_PREC', 'f32')          # f32 | f16 | f16x3 (mc_ctx_set_precision; BASELINE configs[4] is the mixed control config in fp16)
+ctx.set_precision(PREC)
 ctx.set_timesteps(d.timestep_map)
 ctx.set_condition(xf, torch.ones(B, T).cuda())
 if case == 's2g':
@@ -51,5 +53,5 @@ def loop():
 
 loop(); torch.cuda.synchronize()
 t0 = time.perf_counter(); loop(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f'{case}: B={B} T={T} NL={dims["NL"]}+{copy} control copies: 50-step DDIM {dt * 1e3:.1f} ms ({dt * 20:.2f} ms/step) -> '
+print(f'{case}: precision {PREC} B={B} T={T} NL={dims["NL"]}+{copy} control copies: 50-step DDIM {dt * 1e3:.1f} ms ({dt * 20:.2f} ms/step) -> '
       f'{B * T / dt:.0f} sampled frames/s per GPU')
