@@ -384,7 +384,8 @@ def _routing_flips(free, forced):
     return idx_diff, keep_diff, int((~fkeep).sum())
 
 
-def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model):
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model, prec):
     """BASELINE.json configs[1] (B=64, T=196, 1000-step DDPM) as a LOOP: the complete 1000-step p_sample loop runs on the
     device (what bench.py extrapolates from its timed steps), and the CPU oracle walks beside it in lockstep -- from the
     HIP path's own x_t, with the same noise, teacher-forced to the HIP path's routing decisions:
@@ -395,7 +396,9 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model):
       * at t = 999, 500 and 0 on the FULL batch, where the free-running oracle's own decisions are compared too: at
         N = 301 056 tokens the scores next to a capacity boundary / the two best experts of a token are ~1e-6 apart, so a
         handful of the 602 112 (token, choice) pairs per routing legitimately differ (DESIGN.md section 2);
-      * every x_t finite, the statistics of x_t following the oracle's at each full-batch checkpoint."""
+      * every x_t finite, the statistics of x_t following the oracle's at each full-batch checkpoint.
+    prec = 'f16x3': the same loop in the fp16-MFMA split mode (mc_ctx_set_precision) against the SAME fp32 oracle and the same
+    1e-3 bound, with fewer sub-batch checkpoints (first 8 steps + every 100th)."""
     from motioncraft_amd.diffusion import build_diffusion
     from oracle import stmogen_oracle as O
     sd, nm = full_model
@@ -406,6 +409,7 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model):
     d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=S, model_mean_type='start_x', model_var_type='fixed_large'))
     sched = O.Schedule(S, None)
     ctx = nm.context(B, T, max_steps=S)
+    ctx.set_precision(prec)
     ctx.enable_capture()
     ctx.set_timesteps(d.timestep_map)
     ctx.set_condition(xf.cuda(), mask.cuda())
@@ -417,7 +421,7 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model):
     gen = torch.Generator(device='cuda').manual_seed(77)
     x = x_T.cuda()
     nxt = torch.empty_like(x)
-    sub_steps = set(range(S - 1, S - 25, -1)) | set(range(0, S, 100))
+    sub_steps = set(range(S - 1, S - (25 if prec == 'f32' else 9), -1)) | set(range(0, S, 100))
     full_steps = {S - 1, 500, 0}
     worst_sub, worst_full, flips_idx, flips_keep, npairs = 0.0, 0.0, 0, 0, 2 * 2 * B * T * H
     t0 = time.time()
@@ -453,7 +457,7 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model):
             e = maxabs(x_c[sub], ref)
             worst_sub = max(worst_sub, e)
             assert e <= TOL_FINAL, (i, e)
-    print(f'B=64 complete 1000-step DDPM loop ({time.time() - t0:.0f} s): lockstep |hip - oracle| worst {worst_sub:.2e} over '
+    print(f'B=64 complete 1000-step DDPM loop, precision {prec} ({time.time() - t0:.0f} s): lockstep |hip - oracle| worst {worst_sub:.2e} over '
           f'{len(sub_steps - full_steps)} steps x {len(sub)} samples, {worst_full:.2e} over {len(full_steps)} full-batch steps; free-running '
           f'oracle: expert-id flips {flips_idx}, keep flips {flips_keep} over {len(full_steps) * FULL["NL"]} routings of {npairs} pairs; '
           f'final x std {float(x.std()):.3f}')
