@@ -390,15 +390,16 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model, prec
     device (what bench.py extrapolates from its timed steps), and the CPU oracle walks beside it in lockstep -- from the
     HIP path's own x_t, with the same noise, teacher-forced to the HIP path's routing decisions:
 
-      * the first 24 consecutive steps and every 100th step down to t = 0, on 8 of the 64 samples (with the discrete
+      * the first 20 consecutive steps and every 200th step down to t = 0, on 4 of the 64 samples (with the discrete
         decisions forced every token is an independent row, so a sub-batch reproduces the full-batch arithmetic exactly
-        at 1/8 of the CPU time): every x_{t-1} within 1e-3 (north-star tolerance);
-      * at t = 999, 500 and 0 on the FULL batch, where the free-running oracle's own decisions are compared too: at
+        at 1/16 of the CPU time): every x_{t-1} within 1e-3 (north-star tolerance);
+      * at t = 999 and 0 on the FULL batch, where the free-running oracle's own decisions are compared too: at
         N = 301 056 tokens the scores next to a capacity boundary / the two best experts of a token are ~1e-6 apart, so a
         handful of the 602 112 (token, choice) pairs per routing legitimately differ (DESIGN.md section 2);
       * every x_t finite, the statistics of x_t following the oracle's at each full-batch checkpoint.
     prec = 'f16x3': the same loop in the fp16-MFMA split mode (mc_ctx_set_precision) against the SAME fp32 oracle and the same
-    1e-3 bound, with fewer sub-batch checkpoints (first 8 steps + every 100th)."""
+    1e-3 bound, with fewer checkpoints (first 8 steps + every 250th on the sub-batch, t = 500 on the full batch).
+    (Checkpoint counts are sized so that the whole `-m gpu` suite stays within a few minutes of oracle CPU time.)"""
     from motioncraft_amd.diffusion import build_diffusion
     from oracle import stmogen_oracle as O
     sd, nm = full_model
@@ -414,15 +415,15 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model, prec
     ctx.set_timesteps(d.timestep_map)
     ctx.set_condition(xf.cuda(), mask.cuda())
     torch.set_num_threads(min(32, os.cpu_count()))
-    sub = torch.arange(0, B, 8)                                   # 8 samples, mixed lengths
+    sub = torch.arange(0, B, 16)                                  # 4 samples, mixed lengths
     tf_full = O.precompute_text(sd, xf, FULL)
     # the text K/V hoist is routed over the whole CFG-doubled condition batch: slice the full-batch result
     tf_sub = [t.view(2, B, *t.shape[1:])[:, sub].reshape(2 * len(sub), *t.shape[1:]) for t in tf_full]
     gen = torch.Generator(device='cuda').manual_seed(77)
     x = x_T.cuda()
     nxt = torch.empty_like(x)
-    sub_steps = set(range(S - 1, S - (25 if prec == 'f32' else 9), -1)) | set(range(0, S, 100))
-    full_steps = {S - 1, 500, 0}
+    sub_steps = set(range(S - 1, S - (21 if prec == 'f32' else 9), -1)) | set(range(0, S, 200 if prec == 'f32' else 250))
+    full_steps = {S - 1, 0} if prec == 'f32' else {500}
     worst_sub, worst_full, flips_idx, flips_keep, npairs = 0.0, 0.0, 0, 0, 2 * 2 * B * T * H
     t0 = time.time()
     for i in range(S - 1, -1, -1):
@@ -546,7 +547,8 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     ControlT2MHalf, controlnet.py:340-424), reduced-precision MFMA, 50-step DDIM.  Precision 'f16x3' (fp16 hi/lo split,
     fp32 accumulate; gate / routing / LayerNorm statistics stay fp32) walks the whole loop in lockstep with the fp32 CPU
     oracle -- teacher-forced to the HIP path's routing decisions, from the HIP path's own x_t: every x_{t-1} within
-    1e-3, routing flips of the free-running oracle reported.  Plain 'f16' (one rounding to fp16 per operand, what
+    1e-3, routing flips of the free-running oracle reported (all 50 steps at the small size, the first 30 at the 0.125b
+    width; the replay test below runs all 50 there).  Plain 'f16' (one rounding to fp16 per operand, what
     mmcv's wrap_fp16_model does to the reference, tools/test.py:95-97) is measured on the first steps and held to the
     fp16-class bound it can meet."""
     from motioncraft_amd.diffusion import build_diffusion
@@ -556,7 +558,7 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
         dims, copy, feats, B, T, Tc = CTRL, CTRL_COPY, CTRL_FEATS, 2, 24, 20
         sd = W.make_state_dict(dims, SMALL_SEED, shapes=W.control_param_shapes(dims, copy, feats))
     else:       # the 0.125b architecture (L=128, 12 parts, 4 layers) + 2 control copies, pre-encoded audio of width D
-        dims, copy, feats, B, T, Tc = FULL, 2, 1536, 4, 196, 196
+        dims, copy, feats, B, T, Tc = FULL, 2, 1536, 2, 196, 196
         sd = W.make_state_dict(dims, 0, shapes=W.control_param_shapes(dims, copy, feats))
     nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
     g = torch.Generator().manual_seed(91)
@@ -568,7 +570,7 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     NL = dims['NL']
     torch.set_num_threads(min(32, os.cpu_count()))
     noises = step_noise_from_seed(93, (B, T, dims['input_feats']), 50)
-    for prec, nsteps, tol in (('f16x3', 50, TOL_FINAL), ('f16', 6, 3e-2)):
+    for prec, nsteps, tol in (('f16x3', 50 if size == 'small' else 30, TOL_FINAL), ('f16', 4, 3e-2)):
         ctx = nm.context(B, T, max_steps=50)
         ctx.set_precision(prec)
         ctx.enable_capture()
