@@ -231,6 +231,64 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
         }
 }
 
+// The gate's per-token finish on fragment-distributed logits: lane l and lane l ^ 32 hold the two halves of token (l & 31)
+// (this lane: experts e(r) = (r & 3) + 8 (r >> 2) + 4 hf, r = 0..7); ss = this lane's part of |p|^2.
+// cosine logits, softmax, top-2 (lowest index on ties), renormalised gates, importance key, (choice, expert) counts in LDS.
+__device__ __forceinline__ void gate_tail(const GateArgs& g, float ss, const float (&l8)[8], int hf, int lane, bool rok, long tok,
+                                          int* s_cnt) {
+    constexpr int MAXE = 16;
+    ss += __shfl_xor(ss, 32, 64);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);                    // F.normalize(dim=1)
+    const float scale = g.logit_scale[0];
+    // this lane holds the logits of experts e(r) = (r & 3) + 8 (r >> 2) + 4 hf, r = 0..7; its partner the other 8
+    float lg[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        lg[r] = e < g.E ? (l8[r] / denom) * scale : -INFINITY;
+        mx = fmaxf(mx, lg[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        lg[r] = expf(lg[r] - mx);          // exp(-inf) = 0 for e >= E
+        sum += lg[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    auto merge = [&](float& v, int& e) {   // combine with the partner half: larger score, lowest index on ties
+        const float pv = __shfl_xor(v, 32, 64);
+        const int pe = __shfl_xor(e, 32, 64);
+        if (pv > v || (pv == v && pe < e)) { v = pv; e = pe; }
+    };
+    float m1 = -1.f, m2 = -1.f;
+    int c1 = 99, c2 = 99;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        lg[r] = lg[r] / sum;
+        if (e < g.E && lg[r] > m1) { m1 = lg[r]; c1 = e; }
+    }
+    merge(m1, c1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (e < g.E && e != c1 && lg[r] > m2) { m2 = lg[r]; c2 = e; }
+    }
+    merge(m2, c2);
+    if (rok && lane < 32) {
+        const float den = fmaxf(m1 + m2, 1.1920928955078125e-07f);   // normalize_gate, finfo(float32).eps
+        g.idx[tok * 2] = c1;
+        g.idx[tok * 2 + 1] = c2;
+        g.gate[tok * 2] = m1 / den;
+        g.gate[tok * 2 + 1] = m2 / den;
+        g.key[tok] = __float_as_uint(m1);
+        atomicAdd(&s_cnt[c1], 1);
+        atomicAdd(&s_cnt[MAXE + c2], 1);
+    }
+}
+
 // =================================================================================================
 // Gate: LayerNorm + embedding + cosine projector + logits + softmax + top-2
 // (st_attention.py:116-120 LN; MOE.forward :49-51; tutel cosine_top gate + moe_layer routing())
@@ -304,55 +362,119 @@ __global__ __launch_bounds__(256, 2) void gate_k(GateArgs g) {
         }
         __syncthreads();
     }
-    ss += __shfl_xor(ss, 32, 64);
-    const float denom = fmaxf(sqrtf(ss), 1e-12f);                    // F.normalize(dim=1)
-    const float scale = g.logit_scale[0];
-    // this lane holds the logits of experts e(r) = (r & 3) + 8 (r >> 2) + 4 hf, r = 0..7; its partner the other 8
-    float lg[8];
-    float mx = -INFINITY;
+    {
+        float l8[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
-        lg[r] = e < g.E ? (lacc[r] / denom) * scale : -INFINITY;
-        mx = fmaxf(mx, lg[r]);
+        for (int r = 0; r < 8; ++r) l8[r] = lacc[r];
+        gate_tail(g, ss, l8, hf, lane, rok, tok, s_cnt);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+    __syncthreads();
+    if (tid < 2 * MAXE && s_cnt[tid]) atomicAdd(&g.cnt[tid], s_cnt[tid]);
+}
+
+// Small batches (a few thousand tokens): gate_k's 128-token workgroups leave most CUs idle while each wave walks all 8
+// projector chunks.  Here a workgroup owns 32 tokens and its 4 waves split the 8 chunks of p = z Wp^T + bp (2 each;
+// every wave rebuilds the same row fragment): 4x the workgroups, a 4x shorter projector chain per wave.  Weight fragments
+// are wave-private, so they come straight from L2 into registers (no LDS staging, no barrier in the chunk loop).
+// The p fragments meet in LDS and wave 0 runs |p|^2 and the [256 -> experts] MFMA chain over them in gate_k's order
+// (chunk, quad, element ascending), so scores, expert choices and importance keys are bit-identical to gate_k's: which
+// of the two kernels a batch size selects never changes a routing decision.
+template <int L>
+__global__ __launch_bounds__(256) void gate_small_k(GateArgs g) {
+    constexpr int NJ = L / 8, MAXE = 16, PC = 8;
+    __shared__ float s_v[PC][16][64];          // p (+ bias) in C^T fragment layout: [chunk][accumulator element][lane]
+    __shared__ int s_cnt[2 * MAXE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 2 * MAXE) s_cnt[tid] = 0;
+    const long tok = g.tok0 + (long)blockIdx.x * 32 + (lane & 31);
+    const bool rok = tok < g.N;
+    const int hf = lane >> 5, kq = hf * 4;
+    const int c0 = 2 * wave;
+    // this wave's first weight chunk is requested before the row loads
+    const float* wrow = g.Wp + (long)(lane & 31) * L + kq;
+    f32x4 w[NJ], wn[NJ];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        lg[r] = expf(lg[r] - mx);          // exp(-inf) = 0 for e >= E
-        sum += lg[r];
-    }
-    sum += __shfl_xor(sum, 32, 64);
-    auto merge = [&](float& v, int& e) {   // combine with the partner half: larger score, lowest index on ties
-        const float pv = __shfl_xor(v, 32, 64);
-        const int pe = __shfl_xor(e, 32, 64);
-        if (pv > v || (pv == v && pe < e)) { v = pv; e = pe; }
-    };
-    float m1 = -1.f, m2 = -1.f;
-    int c1 = 99, c2 = 99;
+    for (int j = 0; j < NJ; ++j) w[j] = *reinterpret_cast<const f32x4*>(wrow + (long)c0 * 32 * L + 8 * j);
+    f32x4 zf[NJ];
+    {
+        const long tk = rok ? tok : g.N - 1;
+        const float* xp = g.X + tk * g.ldx + kq;
+        const float* ep = g.emb + (tk % g.emb_mod) * L + kq;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
-        lg[r] = lg[r] / sum;
-        if (e < g.E && lg[r] > m1) { m1 = lg[r]; c1 = e; }
-    }
-    merge(m1, c1);
+        for (int j = 0; j < NJ; ++j) zf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+        f32x4 ef[NJ];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int e = (r & 3) + 8 * (r >> 2) + 4 * hf;
-        if (e < g.E && e != c1 && lg[r] > m2) { m2 = lg[r]; c2 = e; }
+        for (int j = 0; j < NJ; ++j) ef[j] = *reinterpret_cast<const f32x4*>(ep + 8 * j);
+        frag_layernorm<NJ>(zf, g.gamma, g.beta, kq);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) zf[j] += ef[j];
+        if (rok && wave == 0) {
+            float* zp = g.Z + tok * L + kq;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(zp + 8 * j) = zf[j];
+        }
     }
-    merge(m2, c2);
-    if (rok && lane < 32) {
-        const float den = fmaxf(m1 + m2, 1.1920928955078125e-07f);   // normalize_gate, finfo(float32).eps
-        g.idx[tok * 2] = c1;
-        g.idx[tok * 2 + 1] = c2;
-        g.gate[tok * 2] = m1 / den;
-        g.gate[tok * 2 + 1] = m2 / den;
-        g.key[tok] = __float_as_uint(m1);
-        atomicAdd(&s_cnt[c1], 1);
-        atomicAdd(&s_cnt[MAXE + c2], 1);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = c0 + cc;
+        if (cc == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wn[j] = *reinterpret_cast<const f32x4*>(wrow + (long)(c + 1) * 32 * L + 8 * j);
+        }
+        f32x4 bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const f32x4*>(g.bp + c * 32 + 8 * q + kq);
+        // the same two round-robin accumulator chains as chunk_mma<NJ, 2> (gate_k), summed the same way
+        f32x16 acc[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][i], zf[j][i], acc[j & 1], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_v[c][4 * q + i][lane] = (acc[0][4 * q + i] + acc[1][4 * q + i]) + bb[q][i];
+        if (cc == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) w[j] = wn[j];
+        }
+    }
+    // wave 0: sim_n^T fragments of the first chunks are requested before the barrier
+    const float* simp = g.sim_nT + (lane & 31) * 256 + kq;
+    f32x4 sv[4], svn[4];
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const f32x4*>(simp + 8 * q);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float ss = 0.f;
+        f32x16 lacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+            if (c + 1 < PC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) svn[q] = *reinterpret_cast<const f32x4*>(simp + (c + 1) * 32 + 8 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = s_v[c][4 * q + i][lane];
+                    ss += v * v;
+                    lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[q][i], v, lacc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] = svn[q];
+        }
+        float l8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) l8[r] = lacc[r];
+        gate_tail(g, ss, l8, hf, lane, rok, tok, s_cnt);
     }
     __syncthreads();
     if (tid < 2 * MAXE && s_cnt[tid]) atomicAdd(&g.cnt[tid], s_cnt[tid]);
@@ -439,7 +561,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 4087;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel
+        v = e ? atoi(e) : 24567;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel, 12 small batches: the SFFN's split-hidden partial sums are added up by the FiLM row kernel instead of a reduce launch (the same fold into the 4 column slices of rowchain_k was measured slower: B=1 +2.6 ms), 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream
     }
     return v;
 }
@@ -454,7 +576,7 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
     MC_REQUIRE(mc_mlp_supported(g.L, g.hidden), "fused mlp: L=%d hidden=%d unsupported", g.L, g.hidden);
     MC_REQUIRE(g.ldx % 4 == 0 && g.ldy % 4 == 0 && g.x_gstride % 4 == 0 && g.y_gstride % 4 == 0, "fused mlp: unaligned strides");
     dim3 grid;
-    MC_REQUIRE(g.nsplit >= 1 && (g.hidden / 32) % g.nsplit == 0, "fused mlp: %d hidden chunks cannot be split %d ways", g.hidden / 32, g.nsplit);
+    MC_REQUIRE(g.nsplit >= 1 && g.hidden / 32 >= g.nsplit, "fused mlp: %d hidden chunks cannot be split %d ways", g.hidden / 32, g.nsplit);
     if (mode == MLP_EXPERT) {
         if (max_tiles <= 0) return MC_OK;
         grid = dim3(max_tiles, 1, g.nsplit);
@@ -482,6 +604,18 @@ int mc_launch_gate(const GateArgs& g, hipStream_t s) {
     MC_REQUIRE(g.E >= 2 && g.E <= 16, "gate: num_experts=%d unsupported (2..16)", g.E);
     if (g.zero_cnt) MC_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * 32, s));
     if (g.N <= g.tok0) return MC_OK;
+    const long small_tokens = [] { const char* e = getenv("MC_GATE_SMALL"); return e ? atol(e) : 12000L; }();     // (read per launch: tests flip it)
+    if (g.N - g.tok0 <= small_tokens) {        // latency-bound sizes (B <= 2 at 196 frames; B=1 -2.8 ms per 50 steps, B=4 +1 ms): 32-token workgroups
+        dim3 grid(cdiv(g.N - g.tok0, 32));
+        switch (g.L) {
+            case 128: hipLaunchKernelGGL(gate_small_k<128>, grid, dim3(256), 0, s, g); break;
+            case 64: hipLaunchKernelGGL(gate_small_k<64>, grid, dim3(256), 0, s, g); break;
+            case 32: hipLaunchKernelGGL(gate_small_k<32>, grid, dim3(256), 0, s, g); break;
+            default: mc_set_error("gate: L=%d unsupported", g.L); return MC_ERR_ARG;
+        }
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
     dim3 grid(cdiv(g.N - g.tok0, 128));
     switch (g.L) {
         case 128: hipLaunchKernelGGL(gate_k<128>, grid, dim3(256), 0, s, g); break;

@@ -24,7 +24,7 @@ struct StepRef {
 };
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
                         const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias = TwinAlias(), long row0 = 0,
-                        StepRef step = StepRef());
+                        StepRef step = StepRef(), int y1_parts = 1, long y1_pstride = 0);   // y1_parts > 1: Y1 = sum of that many partial planes
 // te[s][0:D] = cat(cos(t_s f), sin(t_s f))
 int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s);
 int mc_launch_silu(const float* X, float* Y, long n, hipStream_t s);
@@ -105,6 +105,7 @@ struct RouteBufs {
     uint32_t tie_xor = 0xFFFFFFFFu;   // order of equal-importance tokens at the capacity cut: ~0 = lower index first (stable), 0 = higher first
 };
 size_t mc_route_state_ints(int E);
+bool mc_route_is_small(long N);   // routing of N tokens runs as the one-workgroup kernel, which also leaves the (choice, expert) counts zeroed
 // proj [N][256] (cosine_projector output incl. bias) -> idx/gate/key + per-expert choice counts
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
                           RouteBufs rb, hipStream_t s);

@@ -51,7 +51,8 @@ constexpr int FILM_MAXC = 8;  // 8 float4 chunks x 64 lanes = 2048 channels
 __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ Y1, const float* __restrict__ Y2,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ ss, float* __restrict__ A,
-                                                   long rows, int D, TwinAlias y1_alias, long row0, StepRef step) {
+                                                   long rows, int D, TwinAlias y1_alias, long row0, StepRef step, int y1_parts,
+                                                   long y1_pstride) {
     if (step.ptr) ss += (long)(*step.ptr) * step.stride;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -68,6 +69,8 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
         v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ch < nch) {
             v[c] = *reinterpret_cast<const f32x4*>(Y1 + r1 * D + ch * 4);
+            // Y1 left as split-hidden partial sums by the producer (small batches): summed here, parts ascending like splitk_reduce_k
+            for (int p = 1; p < y1_parts; ++p) v[c] += *reinterpret_cast<const f32x4*>(Y1 + (long)p * y1_pstride + r1 * D + ch * 4);
             if (Y2) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(Y2 + r * D + ch * 4);
                 v[c] += w;
@@ -324,10 +327,12 @@ int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, c
 }
 
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
-                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0, StepRef step) {
+                        const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0, StepRef step,
+                        int y1_parts, long y1_pstride) {
     MC_REQUIRE(D % 4 == 0 && D <= FILM_MAXC * 256, "film_rows: unsupported D=%d", D);
     if (rows <= 0) return MC_OK;
-    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step);
+    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step,
+                       y1_parts < 1 ? 1 : y1_parts, y1_pstride);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -68,6 +68,7 @@ struct mc_ctx {
     int64_t bytes = 0;
     float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2, *xpad;
     size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
+    bool cnt_clean = false;     // the routing state's (choice, expert) counts are known to be zero on the stream (route_small_k cleans up after itself)
     float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
     const float* mask = nullptr;   // = mask_own after mc_ctx_set_condition (a private copy: the pointer is baked into captured graphs)
     float* mask_own = nullptr;
@@ -347,8 +348,9 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
             return mc_launch_mlp_h(MLP_EXPERT, m, hw->hi, hw->lo, hw2->hi, hw2->lo, c->prec == MC_PREC_F16X3, 1, max_tiles, s);
         // small batches (a few dozen tiles, each walking all hidden chunks serially): split the hidden dimension 4 ways,
         // partial FC2 sums in hbuf, reduced in a fixed order (rows of dropped pairs stay unwritten garbage: never read)
-        const int S = 4;
-        if (z == c->z && c->rows <= 2048 && (hid / 32) % S == 0 && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
+        static const int S_env = [] { const char* e = getenv("MC_SPLIT_EXPERT"); return e ? atoi(e) : 4; }();
+        const int S = S_env;
+        if (z == c->z && c->rows <= 2048 && S > 1 && hid / 32 >= S && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
             if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
             return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s);
@@ -386,7 +388,9 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
         if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
     }
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
+    c->cnt_clean = false;
     if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, gsplit, E, capacity, c->rb, s))) return r;
+    c->cnt_clean = mc_route_is_small(Ntok);
     if (gsplit < Ntok) return MC_OK;
     if ((r = moe_experts(c, w, z, Ntok, 0, s, hw, hw2))) return r;
     if (!out) return MC_OK;                        // the caller launches the projection itself (row ranges)
@@ -407,13 +411,15 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
-               bool prologue_only = false, TwinAlias y1_alias = TwinAlias(), const HalfW* hw = nullptr) {
+               bool prologue_only = false, TwinAlias y1_alias = TwinAlias(), const HalfW* hw = nullptr, int y1_parts = 1) {
+    // y1_parts > 1: y1 = that many partial planes of [nrows][D] starting AT y1 (rows relative to row0), summed by the row kernel
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     const long o = row0 * D;
     int r;
     StepRef sref;
     if (c->graph_mode) { sref.ptr = c->gstep; sref.stride = 2L * D; }     // `ss` then is the table's row of step 0
-    if ((r = mc_launch_film_rows(y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0, sref))) return r;
+    if ((r = mc_launch_film_rows(y1_parts > 1 ? y1 : y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0, sref,
+                                 y1_parts, nrows * D))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
     if (hw && hw->hi && c->prec != MC_PREC_F32)
@@ -472,12 +478,15 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     }
     // ---- temporal linear attention: needs only mf; on `st` (a second stream for small batches) or inline ----
     const float* tfl = c->tf + (long)i * c->Ntxt * 2 * L;
+    // small batches: the longer branch (temporal) stays on `s`, LN + q/k/v + body go to the side stream -- the fork latency is
+    // then paid by the short branch and the join event has fired long before `s` reaches it (B=1: -13 us per layer vs the
+    // temporal branch on the side stream)
+    hipStream_t sb = s;          // stream of the body branch
+    hipStream_t stt = s;         // stream of the temporal branch
     if (st != s) {
         MC_HIP(hipEventRecord(c->ev_fork, s));
         MC_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
-        if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
-                                    g.max_text_len, H, L, st, twin_flag))) return r;
-        MC_HIP(hipEventRecord(c->ev_join, st));
+        if (mc_chain_enabled(14)) sb = st; else stt = st;
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
     if (pq_fused) {
@@ -487,19 +496,19 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
         q.Y = c->qkv; q.ldy = 3 * L; q.tok0 = tok0; q.N = tok0 + ntok; q.L = L; q.Nout = 3 * L;
         q.alias = tok_alias;
-        if ((r = mc_launch_rowchain(1, q, s))) return r;
+        if ((r = mc_launch_rowchain(1, q, sb))) return r;
     } else {
-        if ((r = mc_launch_ln_rows(c->mf + tok0 * 4 * L, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z + tok0 * L, L, ntok, L, s))) return r;
-        if ((r = dense(c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, s))) return r;
+        if ((r = mc_launch_ln_rows(c->mf + tok0 * 4 * L, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z + tok0 * L, L, ntok, L, sb))) return r;
+        if ((r = dense(c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, sb))) return r;
     }
-    if ((r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, s,
+    if ((r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, sb,
                             frame_alias, row0))) return r;
-    if (st != s) {
-        MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-        return MC_OK;
-    }
-    return mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
-                              g.max_text_len, H, L, s, twin_flag);
+    if (sb != s) MC_HIP(hipEventRecord(c->ev_join, sb));
+    if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
+                                g.max_text_len, H, L, stt, twin_flag))) return r;
+    if (stt != s) MC_HIP(hipEventRecord(c->ev_join, stt));
+    if (st != s) MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+    return MC_OK;
 }
 
 int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s) {
@@ -513,19 +522,22 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
     if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias, &w.h_ca_out))) return r;
     // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
     const long o = row0 * D;
+    int z2_parts = 1;
     if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
         MlpArgs m;
         m.X = hs + o; m.ldx = D; m.x_gstride = L;
         m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
         m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;
-        const int S = 4;
+        static const int S_env = [] { const char* e = getenv("MC_SPLIT_SFFN"); return e ? atoi(e) : 4; }();
+        const int S = S_env;
         if (c->prec != MC_PREC_F32 && w.h_w1.hi && w.h_w2.hi) {
             if ((r = mc_launch_mlp_h(MLP_PARTS, m, w.h_w1.hi, w.h_w1.lo, w.h_w2.hi, w.h_w2.lo, c->prec == MC_PREC_F16X3, H, 0, s))) return r;
         } else
-        if (nrows <= 2048 && (F / 32) % S == 0 && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
+        if (nrows <= 2048 && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = nrows * D;
             if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
-            if ((r = mc_launch_splitk_reduce(c->hbuf, S, nrows, D, nullptr, nullptr, c->z2 + o, s))) return r;
+            if (mc_chain_enabled(12)) z2_parts = S;          // the FiLM row kernel adds the partial planes up itself
+            else if ((r = mc_launch_splitk_reduce(c->hbuf, S, nrows, D, nullptr, nullptr, c->z2 + o, s))) return r;
         } else if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
     } else {
         GemmArgs f1;
@@ -544,8 +556,8 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         if ((r = mc_launch_gemm(GM_PLAIN, f2, H, 0, s))) return r;
     }
     const float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS + step) * 2 * D;
-    return film_block(c, hs, c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, row0, nrows, s,
-                      c->defer_last_gemm && i == g.num_layers - 1, TwinAlias(), &w.h_ffn_out);
+    return film_block(c, hs, z2_parts > 1 ? c->hbuf : c->z2, nullptr, w.ffn_ln_g, w.ffn_ln_b, ss1, w.ffn_out_w, w.ffn_out_b, row0, nrows, s,
+                      c->defer_last_gemm && i == g.num_layers - 1, TwinAlias(), &w.h_ffn_out, z2_parts);
 }
 
 // groups of whole samples for the multi-stream schedule: group k = rows [part_row0(k), part_row0(k + 1))
@@ -597,6 +609,8 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
             }
         } else {
             ga.N = twin ? c->N / 2 : c->N;
+            ga.zero_cnt = c->cnt_clean ? 0 : 1;      // small batches: the previous layer's routing kernel left the counts zeroed
+            c->cnt_clean = false;
             if ((r = mc_launch_gate(ga, s))) return r;
         }
         if (split == 2 && (r = parts_join(c, s))) return r;      // routing ranks the whole batch: every group must have arrived
@@ -1116,8 +1130,10 @@ int mc_ctx_graph_capture(mc_ctx* c, float* x_dev, const float* noise_dev, const 
     MC_HIP(hipStreamSynchronize(s));                 // (`tab` is a temporary)
     MC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     c->graph_mode = true;
+    c->cnt_clean = false;        // a replay must not assume anything about the routing counts it starts from: the first gate clears them
     r = mc_sample_step(c, x_dev, 0, &coefs_host[0], noise_dev, x_dev, nullptr, stream);     // in place: x_prev aliases x_t
     c->graph_mode = false;
+    c->cnt_clean = false;        // (nothing of the captured step ran)
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(s, &g);
     if (r != MC_OK) { if (g) (void)hipGraphDestroy(g); return r; }

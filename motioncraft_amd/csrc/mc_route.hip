@@ -319,7 +319,191 @@ __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx,
 // microseconds of work each.  Same state block, same decisions (integer arithmetic on the same composite keys).
 // ---------------------------------------------------------------------------------------
 constexpr int SMALL_THREADS = 1024;
+// PER = (token, choice) pairs per thread, held in registers for the whole kernel: problem id + composite key are built
+// once, the radix passes and the keep / compaction phases touch no global memory for them.
+// A selection problem is resolved early when the bin that holds the rank-th key is taken whole (all keys of the bin are
+// kept: the threshold is the prefix with zero low bits) -- with distinct scores that happens after the 4 score bytes,
+// the token-index bytes only ever split exact ties.
+template <int PER>
 __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __restrict__ idx, const float* __restrict__ gate,
+                                                              const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
+                                                              int E, int capacity, int cnt_mul, float* __restrict__ comb_w,
+                                                              int* __restrict__ state, int* __restrict__ src_row,
+                                                              int* __restrict__ dst_row, int* __restrict__ tile_group,
+                                                              int* __restrict__ tile_row0, int* __restrict__ tile_nrows, int max_tiles,
+                                                              uint32_t tie_xor) {
+    __shared__ int h[MAXP * 256];
+    __shared__ int s_act[MAXP], s_rank[MAXP];      // act: 1 selecting, 2 resolved (threshold in s_pre), 0 keep all, -1 keep none
+    __shared__ unsigned long long s_pre[MAXP];
+    __shared__ int s_kept[2 * MAXE], s_fill[2 * MAXE], s_off[2 * MAXE + 1], s_t0[2][MAXE + 1];
+    __shared__ int s_any, s_split;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pairs a = tid + i * SMALL_THREADS: importance key (1 register) and problem id (one byte, -1 past the end / no slot);
+    // the composite key is rebuilt from them (the token index is a function of a)
+    uint32_t kk[PER];
+    int pp8[(PER + 3) / 4];
+    auto get_p = [&](int i) { return (int)(pp8[i >> 2] << (24 - 8 * (i & 3))) >> 24; };
+    auto set_p = [&](int i, int v) { pp8[i >> 2] = (pp8[i >> 2] & ~(0xFF << (8 * (i & 3)))) | ((v & 0xFF) << (8 * (i & 3))); };
+    auto tok_of = [&](int i) { return (long)(tid + (long)i * SMALL_THREADS) >> 1; };
+#pragma unroll
+    for (int i = 0; i < (PER + 3) / 4; ++i) pp8[i] = -1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long a = tid + (long)i * SMALL_THREADS;
+        kk[i] = 0u;
+        if (a < 2 * N) {
+            const long tok = a >> 1;
+            const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+            set_p(i, (int)(a & 1) * MAXE + idx[2 * ts + (a & 1)]);
+            kk[i] = key[ts];
+        }
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // at most 8 pairs' loads in flight: enough to hide the latency, no spills
+    }
+    if (tid == 0) { s_any = 0; s_split = 0; }
+    if (tid < 2 * MAXE) { s_kept[tid] = 0; s_fill[tid] = 0; }
+    __syncthreads();
+    if (tid < MAXP) {                                            // problem setup (route_init_k)
+        const int choice = tid / MAXE, e = tid % MAXE;
+        int act = 0, rank = 0;
+        if (e < E) {
+            const int c0 = state[ST_CNT + e] * cnt_mul;
+            const int cnt = state[ST_CNT + tid] * cnt_mul;
+            const int limit = choice == 0 ? capacity : capacity - c0;
+            if (limit <= 0) act = cnt > 0 ? -1 : 0;
+            else if (cnt > limit) { act = 1; rank = limit; }
+        }
+        s_act[tid] = act;
+        s_rank[tid] = rank;
+        s_pre[tid] = 0ull;
+        if (act == 1) atomicOr(&s_any, 1);
+    }
+    __syncthreads();
+    if (tid < MAXP) state[ST_CNT + tid] = 0;                     // counts consumed: left clean for the next layer's gate (no memset launch)
+#pragma unroll 1
+    for (int pass = 0; pass < 8 && s_any; ++pass) {              // radix select, one byte per pass (route_hist_k + pick)
+        if (pass == 4 || pass == 5) {
+            // token indices are < 2^16 here (<= 32768 pairs), so the two upper bytes of (token ^ tie_xor) are those of
+            // tie_xor for every key: the pass cannot split the candidates, append the byte and go on (rank unchanged)
+            if (tid < MAXP && s_act[tid] == 1) s_pre[tid] = (s_pre[tid] << 8) | (unsigned long long)((tie_xor >> (pass == 4 ? 24 : 16)) & 0xFFu);
+            __syncthreads();
+            continue;
+        }
+        for (int i = tid; i < MAXP * 256; i += SMALL_THREADS) h[i] = 0;
+        __syncthreads();
+        if (tid == 0) s_any = 0;                                 // (every thread read it in the loop condition before the barrier above)
+        const int shift = 56 - 8 * pass;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int p = get_p(i);
+            if (p < 0 || s_act[p] != 1) continue;
+            const unsigned long long V = composite(kk[i], (uint32_t)tok_of(i), tie_xor);
+            if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
+            atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
+        }
+        __syncthreads();
+        for (int p = wave; p < MAXP; p += SMALL_THREADS / 64) {
+            if (s_act[p] != 1) continue;
+            int cb[4], t = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cb[j] = h[p * 256 + 4 * lane + j]; t += cb[j]; }
+            int suf = t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_down(suf, o, 64);
+                if (lane + o < 64) suf += v;
+            }
+            const int rank = s_rank[p];
+            int above = suf - t, found = -1, above_found = 0, incl_found = 0;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                const int incl = above + cb[j];
+                if (found < 0 && incl >= rank && above < rank) { found = 4 * lane + j; above_found = above; incl_found = incl; }
+                above = incl;
+            }
+            if (found >= 0) {                                // exactly one lane finds the bin
+                const unsigned long long pre = (s_pre[p] << 8) | (unsigned long long)found;
+                if (incl_found == rank && pass < 7) {        // the whole bin is kept: threshold = prefix, low bits zero
+                    s_pre[p] = pre << shift;
+                    s_act[p] = 2;
+                } else {
+                    s_pre[p] = pre;
+                    s_rank[p] = rank - above_found;
+                    s_any = 1;                               // (benign race: every writer stores 1)
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {                               // keep / drop, combine weights, kept counts (route_keep_k)
+        const int p = get_p(i);
+        if (p < 0) continue;
+        const long a = tid + (long)i * SMALL_THREADS;
+        const long tok = a >> 1;
+        const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+        const int act = s_act[p];
+        bool keep = true;
+        if (act == -1) keep = false;
+        else if (act > 0) keep = composite(kk[i], (uint32_t)tok, tie_xor) >= s_pre[p];
+        comb_w[a] = keep ? gate[2 * ts + (a & 1)] : 0.f;
+        if (tok >= Nsrc && act > 0) {
+            const bool keep_orig = composite(kk[i], (uint32_t)ts, tie_xor) >= s_pre[p];
+            if (keep_orig != keep) s_split = 1;
+        }
+        if (!(keep && tok < Nsrc)) set_p(i, -1);                  // from here on: p >= 0 marks a pair that gets an expert slot
+        else atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + (p & (MAXE - 1))], 1);
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (tid == 0) {                                              // slot ranges + tile counts (route_plan_k)
+        int off = 0;
+        for (int g = 0; g < 2; ++g) {
+            int nt = 0;
+            for (int e = 0; e < E; ++e) {
+                s_off[g * MAXE + e] = off;
+                s_t0[g][e] = nt;
+                state[ST_OFF + g * MAXE + e] = off;
+                const int cnt = s_kept[g * MAXE + e];
+                off += cnt;
+                nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+            }
+            for (int e = E; e < MAXE; ++e) { s_off[g * MAXE + e] = off; state[ST_OFF + g * MAXE + e] = off; }
+            s_t0[g][E] = nt;
+            state[ST_NTILES + g] = min(nt, max_tiles);
+        }
+        s_off[2 * MAXE] = off;
+        state[ST_OFF + 2 * MAXE] = off;
+        state[ST_SPLIT] = s_split;
+        state[ST_DONE] = 0;
+    }
+    __syncthreads();
+    for (int g = 0; g < 2; ++g)
+        for (int e = 0; e < E; ++e) {
+            const int ve = g * MAXE + e, t1 = min(s_t0[g][e + 1], max_tiles);
+            for (int t = s_t0[g][e] + tid; t < t1; t += SMALL_THREADS) {
+                const int r = (t - s_t0[g][e]) * TILE_ROWS;
+                tile_group[g * max_tiles + t] = e;
+                tile_row0[g * max_tiles + t] = s_off[ve] + r;
+                tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {                               // compaction (route_fill_k)
+        const int p = get_p(i);
+        if (p < 0) continue;
+        const long a = tid + (long)i * SMALL_THREADS;
+        const int le = ((a >> 1) >= gsplit ? MAXE : 0) + (p & (MAXE - 1));
+        const int slot = s_off[le] + atomicAdd(&s_fill[le], 1);
+        src_row[slot] = (int)(a >> 1);
+        dst_row[slot] = (int)a;
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The same kernel for more pairs than fit in registers (10 < pairs per thread <= 32): idx / key are re-read from L2 in
+// every phase.
+__global__ __launch_bounds__(SMALL_THREADS) void route_small_stream_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                               const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
                                                               int E, int capacity, int cnt_mul, float* __restrict__ comb_w,
                                                               int* __restrict__ state, int* __restrict__ src_row,
@@ -351,6 +535,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
         if (act == 1) atomicOr(&s_any, 1);
     }
     __syncthreads();
+    if (tid < MAXP) state[ST_CNT + tid] = 0;                     // counts consumed: left clean for the next layer's gate (no memset launch)
     if (s_any) {
         for (int pass = 0; pass < 8; ++pass) {                   // radix select, one byte per pass (route_hist_k + pick)
             if (pass == 4 || pass == 5) {
@@ -461,11 +646,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
 }  // namespace
 
 static long route_small_pairs() {
-    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 32768L; return x > 131072L ? 131072L : x; }();   // route_small_k assumes token indices < 2^16
+    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 32768L; return x > 32768L ? 32768L : x; }();   // route_small_k: <= 32 pairs per thread, token indices < 2^16
     return v;
 }
 
 size_t mc_route_state_ints(int) { return ST_TOTAL; }
+bool mc_route_is_small(long N) { return 2 * N <= route_small_pairs(); }
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
 const int* mc_route_split_flag_ptr(const RouteBufs& rb) { return rb.state + ST_SPLIT; }
 
@@ -490,9 +676,13 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
     MC_REQUIRE(Nsrc == N || 2 * Nsrc == N, "route: Nsrc=%ld must be N or N/2 (N=%ld)", Nsrc, N);
     MC_REQUIRE(Nsrc == N || rb.tie_xor == 0xFFFFFFFFu, "route: the twin mode needs the stable tie order (a twin must rank right behind its original)");
     if (2 * N <= route_small_pairs()) {
-        hipLaunchKernelGGL(route_small_k, dim3(1), dim3(SMALL_THREADS), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity,
-                           (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,
-                           rb.max_tiles, rb.tie_xor);
+#define MC_ROUTE_SMALL(KERNEL)                                                                                                       \
+    hipLaunchKernelGGL(KERNEL, dim3(1), dim3(SMALL_THREADS), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity,   \
+                       (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,        \
+                       rb.max_tiles, rb.tie_xor)
+        if (2 * N <= 10L * SMALL_THREADS) MC_ROUTE_SMALL(route_small_k<10>);
+        else MC_ROUTE_SMALL(route_small_stream_k);
+#undef MC_ROUTE_SMALL
         MC_LAUNCH_CHECK();
         return MC_OK;
     }
