@@ -556,59 +556,94 @@ __global__ __launch_bounds__(256, 2) void gemm_wp_k(GemmArgs g) {
 // C = A W^T + bias (+ add[(r % add_mod)]) + R (also written dup_rows below), fp32, lda / ldw / ldc / ldr % 4 == 0,
 // N % 64 == 0, K % 32 == 0.
 // ---------------------------------------------------------------------------------------
-constexpr int SM = 64, SN = 64;
+constexpr int SM = 64, SN = 64, SRING = 4;
+// Operand staging: LDS-DMA into a ring of SRING stages, issued THREE k-tiles ahead.  With one wave per SIMD nothing else
+// hides a stall, and a k-tile is only 16 MFMAs (~0.4 us): W (9.4 MB for the FiLM Linear) does not fit an XCD's L2, so
+// the register double buffer this kernel used first (one tile of lead) waited for the MALL in every iteration.  The DMAs
+// are inline asm with hand-counted s_waitcnt (the compiler's own insertion drains every outstanding load in front of
+// an LDS access of the loop).  LDS image of a stage: unpadded [64][32] A rows then [64][32] W rows, 16-byte chunk c of
+// row r at position c ^ (r & 7) (gemm_dma_k's layout); accumulation order over k is unchanged: results are bit-identical.
 template <bool VEC>     // VEC: N % 64 == 0 and 16-byte aligned output rows (float4 epilogue); else guarded scalar stores
 __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][SM][LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SN][LD];
+    __shared__ __attribute__((aligned(16))) float smem[SRING * 2 * SM * BK];      // 4 x (8 + 8) KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + SN - 1) / SN;
     const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn, grp = blockIdx.y;
     const int row0 = tm * SM;
-    // staging: thread -> (row sr, 16-byte chunk sc) of the 64 x 32 slabs, two rows 32 apart each for A and W
-    const int sr = tid >> 3, sc = (tid & 7) * 4;
-    const int ar0 = min(row0 + sr, g.M - 1), ar1 = min(row0 + sr + 32, g.M - 1);      // rows past M / N re-read the last row (never stored)
-    const int wr0 = min(tn * SN + sr, g.N - 1), wr1 = min(tn * SN + sr + 32, g.N - 1);
-    const float* Ab = g.A + (long)grp * g.a_gstride + g.a_col + sc;
-    const float* Wb = g.W + (long)grp * g.w_gstride + sc;
-    const float* a0 = Ab + (long)ar0 * g.lda;
-    const float* a1 = Ab + (long)ar1 * g.lda;
-    const float* w0 = Wb + (long)wr0 * g.ldw;
-    const float* w1 = Wb + (long)wr1 * g.ldw;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // DMA piece q of a wave: rows 16 wave + 8 q + (lane >> 3) of the A slab and of the W slab, LDS position lane & 7,
+    // global chunk (lane & 7) ^ (row & 7); rows past M / N re-read the last row (never stored)
+    const int dr = lane >> 3, dc = ((lane & 7) ^ dr) * 4;
+    const float* Ab = g.A + (long)grp * g.a_gstride + g.a_col;       // uniform bases (SGPR pair of the DMA)
+    const float* Wb = g.W + (long)grp * g.w_gstride;
+    unsigned voa[2], vow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ar = min(row0 + 16 * wave + 8 * q + dr, g.M - 1), wr = min(tn * SN + 16 * wave + 8 * q + dr, g.N - 1);
+        voa[q] = (unsigned)(((long)ar * g.lda + dc) * 4);
+        vow[q] = (unsigned)(((long)wr * g.ldw + dc) * 4);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem + (unsigned)(16 * wave_u) * BK * 4;
+    auto issue = [&](int kt) {
+        const unsigned l = lds0 + (unsigned)(kt & (SRING - 1)) * (2 * SM * BK * 4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            dma16(voa[q], Ab + kt * BK, l + q * 8 * BK * 4);
+            dma16(vow[q], Wb + kt * BK, l + SM * BK * 4 + q * 8 * BK * 4);
+        }
+    };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int nk = g.K / BK;
-    f32x4 ra0 = *reinterpret_cast<const f32x4*>(a0), ra1 = *reinterpret_cast<const f32x4*>(a1);
-    f32x4 rw0 = *reinterpret_cast<const f32x4*>(w0), rw1 = *reinterpret_cast<const f32x4*>(w1);
-    const int frow = lane & 31, hf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        *reinterpret_cast<f32x4*>(&As[buf][sr][sc]) = ra0;
-        *reinterpret_cast<f32x4*>(&As[buf][sr + 32][sc]) = ra1;
-        *reinterpret_cast<f32x4*>(&Bs[buf][sr][sc]) = rw0;
-        *reinterpret_cast<f32x4*>(&Bs[buf][sr + 32][sc]) = rw1;
-        if (kt + 1 < nk) {
-            const int ko = (kt + 1) * BK;
-            ra0 = *reinterpret_cast<const f32x4*>(a0 + ko); ra1 = *reinterpret_cast<const f32x4*>(a1 + ko);
-            rw0 = *reinterpret_cast<const f32x4*>(w0 + ko); rw1 = *reinterpret_cast<const f32x4*>(w1 + ko);
+    const int frow = lane & 31, hf = lane >> 5, sw = frow & 7;
+    // epilogue operands (bias, row-periodic table, residual) are requested before anything else: by the end of the k-loop
+    // they sit in registers instead of costing a memory round trip between the last MFMA and the stores.  (Older than
+    // every DMA, so they never stand between a counted wait and the stage it waits for.)
+    const int me = min(row0 + wm * 32 + frow, g.M - 1);
+    const long rgs = g.r_gstride >= 0 ? g.r_gstride : g.c_gstride;
+    f32x4 pb[4], pa[4], pr[4];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = tn * SN + wn * 32 + 8 * q + 4 * hf;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pb[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + (long)grp * g.b_gstride + n) : z;
+            pa[q] = g.add ? *reinterpret_cast<const f32x4*>(g.add + (long)(me % g.add_mod) * g.ld_add + n) : z;
+            pr[q] = g.R ? *reinterpret_cast<const f32x4*>(g.R + (long)grp * rgs + (long)me * g.ldr + g.c_col + n) : z;
         }
-        __syncthreads();                          // one barrier per k-tile: the other buffer was last read two tiles ago
-        const float* At = &As[buf][wm * 32 + frow][0];
-        const float* Bt = &Bs[buf][wn * 32 + frow][0];
+    }
+    for (int kt = 0; kt < SRING - 1 && kt < nk; ++kt) issue(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's DMAs of stage kt have landed when at most the 4 * (stages issued beyond kt) later ones are in flight
+        const int ahead = min(nk - 1 - kt, SRING - 2);
+        if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                          // every wave's part of stage kt is in LDS; every wave is done reading stage kt-1
+        if (kt + SRING - 1 < nk) issue(kt + SRING - 1);      // into the buffer of stage kt-1
+        const float* St = smem + (kt & (SRING - 1)) * (2 * SM * BK);
+        const float* At = St + (wm * 32 + frow) * BK;
+        const float* Bt = St + SM * BK + (wn * 32 + frow) * BK;
+        // all 8 fragment reads of the k-tile are requested up front (the scheduler otherwise sinks each pair to its use
+        // and exposes the LDS latency four times per k-tile)
+        f32x4 fa[4], fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 fa = *reinterpret_cast<const f32x4*>(At + (2 * j + hf) * 4);
-            const f32x4 fb = *reinterpret_cast<const f32x4*>(Bt + (2 * j + hf) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[i], fa[i], acc, 0, 0, 0);
+            const int pos = ((2 * j + hf) ^ sw) * 4;
+            fa[j] = *reinterpret_cast<const f32x4*>(At + pos);
+            fb[j] = *reinterpret_cast<const f32x4*>(Bt + pos);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][i], fa[j][i], acc, 0, 0, 0);
     }
     const int m = row0 + wm * 32 + frow;
     if (m >= g.M) return;
     float* crow = g.C + (long)grp * g.c_gstride + (long)m * g.ldc + g.c_col;
-    const long rgs = g.r_gstride >= 0 ? g.r_gstride : g.c_gstride;
     const float* rrow = g.R ? g.R + (long)grp * rgs + (long)m * g.ldr + g.c_col : nullptr;
     const float* arow = g.add ? g.add + (long)(m % g.add_mod) * g.ld_add : nullptr;      // row-periodic table (pose encoder)
     const float* bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
@@ -617,9 +652,132 @@ __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
         const int n = tn * SN + wn * 32 + 8 * q + 4 * hf;
         f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         if constexpr (VEC) {
-            if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
-            if (arow) v += *reinterpret_cast<const f32x4*>(arow + n);
-            if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+            v += pb[q];
+            v += pa[q];
+            v += pr[q];
+            *reinterpret_cast<f32x4*>(crow + n) = v;
+            if (g.dup_rows) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (n + i >= g.N) continue;
+                float x = v[i];
+                if (bias) x += bias[n + i];
+                if (arow) x += arow[n + i];
+                if (rrow) x += rrow[n + i];
+                crow[n + i] = x;
+                if (g.dup_rows) crow[g.dup_rows * g.ldc + n + i] = x;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// gemm_small_k on 64 x (16 NBLK) tiles (NBLK = 3: 64 x 48, NBLK = 6: 64 x 96) with v_mfma_f32_16x16x4_f32: wave w owns rows
+// [16 w, 16 w + 16) of the tile and all NBLK 16-column blocks (one A fragment feeds NBLK MFMAs).  Small-M launches are
+// bound by the MFMA pipe of the CUs that HAVE a tile -- at M = 392, N = 1536 the 64 x 64 grid is 168 workgroups on 256
+// CUs -- so the tile width is chosen per launch to even out the work per CU (mc_launch_gemm_small): 224 tiles of 64 x 48
+// there, 3/4 of the MFMA chain per CU.  Same DMA ring as gemm_small_k.  Fragments: lane -> row (lane & 15), k-group
+// lane >> 4; C^T block: lane holds row (lane & 15), columns 16 blk + 4 (lane >> 4) + 0..3.
+// (the k accumulation order differs from gemm_small_k's: results agree to fp32 round-off, not bit for bit)
+// ---------------------------------------------------------------------------------------
+template <int NBLK, bool VEC>
+__global__ __launch_bounds__(256) void gemm_small16_k(GemmArgs g) {
+    constexpr int NB = 16 * NBLK, NWP = NB / 8;               // W slab rows, 8-row DMA pieces of the W slab
+    constexpr int STAGE = (SM + NB) * BK;                     // floats per stage
+    __shared__ __attribute__((aligned(16))) float smem[SRING * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = (g.N + NB - 1) / NB;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn, grp = blockIdx.y;
+    const int row0 = tm * SM;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int dr = lane >> 3, dc = ((lane & 7) ^ dr) * 4;
+    const float* Ab = g.A + (long)grp * g.a_gstride + g.a_col;
+    const float* Wb = g.W + (long)grp * g.w_gstride;
+    // A slab: pieces 2 wave, 2 wave + 1; W slab: pieces wave, wave + 4, wave + 8 (< NWP)
+    constexpr int MAXW = (NWP + 3) / 4;
+    unsigned voa[2], vow[MAXW];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) voa[q] = (unsigned)(((long)min(row0 + 16 * wave + 8 * q + dr, g.M - 1) * g.lda + dc) * 4);
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q) vow[q] = (unsigned)(((long)min(tn * NB + 8 * (wave + 4 * q) + dr, g.N - 1) * g.ldw + dc) * 4);
+    const int nw = (NWP - wave_u + 3) / 4;                    // W pieces of this wave (uniform)
+    const unsigned lds_base = (unsigned)(size_t)smem;
+    auto issue = [&](int kt) {
+        const unsigned l = lds_base + (unsigned)(kt & (SRING - 1)) * (STAGE * 4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16(voa[q], Ab + kt * BK, l + (unsigned)(16 * wave_u + 8 * q) * BK * 4);
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+            if (q < nw) dma16(vow[q], Wb + kt * BK, l + SM * BK * 4 + (unsigned)(8 * (wave_u + 4 * q)) * BK * 4);
+    };
+    f32x4 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = g.K / BK;
+    const int frow = lane & 15, kg = lane >> 4;
+    const int per = 2 + nw;                                   // DMAs of this wave per stage
+    const int sw = frow & 7;                                  // (16 wave and 16 blk are multiples of 8)
+    // epilogue operands first (see gemm_small_k)
+    const int me = min(row0 + 16 * wave + frow, g.M - 1);
+    const long rgs = g.r_gstride >= 0 ? g.r_gstride : g.c_gstride;
+    f32x4 pb[NBLK], pa[NBLK], pr[NBLK];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int n = tn * NB + 16 * b + 4 * kg;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pb[b] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + (long)grp * g.b_gstride + n) : z;
+            pa[b] = g.add ? *reinterpret_cast<const f32x4*>(g.add + (long)(me % g.add_mod) * g.ld_add + n) : z;
+            pr[b] = g.R ? *reinterpret_cast<const f32x4*>(g.R + (long)grp * rgs + (long)me * g.ldr + g.c_col + n) : z;
+        }
+    }
+    for (int kt = 0; kt < SRING - 1 && kt < nk; ++kt) issue(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+        switch (min(nk - 1 - kt, SRING - 2) * per) {          // this wave's DMAs issued after those of stage kt
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        __syncthreads();
+        if (kt + SRING - 1 < nk) issue(kt + SRING - 1);
+        const float* St = smem + (kt & (SRING - 1)) * STAGE;
+        const float* At = St + (16 * wave + frow) * BK;
+        const float* Bt = St + SM * BK + frow * BK;
+        f32x4 fa[2], fb[NBLK][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pos = ((4 * j + kg) ^ sw) * 4;
+            fa[j] = *reinterpret_cast<const f32x4*>(At + pos);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) fb[b][j] = *reinterpret_cast<const f32x4*>(Bt + b * 16 * BK + pos);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[b][j][i], fa[j][i], acc[b], 0, 0, 0);
+    }
+    const int m = row0 + 16 * wave + frow;
+    if (m >= g.M) return;
+    float* crow = g.C + (long)grp * g.c_gstride + (long)m * g.ldc + g.c_col;
+    const float* rrow = g.R ? g.R + (long)grp * rgs + (long)m * g.ldr + g.c_col : nullptr;
+    const float* arow = g.add ? g.add + (long)(m % g.add_mod) * g.ld_add : nullptr;
+    const float* bias = g.bias ? g.bias + (long)grp * g.b_gstride : nullptr;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int n = tn * NB + 16 * b + 4 * kg;
+        f32x4 v = acc[b];
+        if constexpr (VEC) {
+            v += pb[b];
+            v += pa[b];
+            v += pr[b];
             *reinterpret_cast<f32x4*>(crow + n) = v;
             if (g.dup_rows) *reinterpret_cast<f32x4*>(crow + g.dup_rows * g.ldc + n) = v;
         } else {
@@ -653,11 +811,31 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
                    g.act == ACT_NONE,
                "gemm_small: unsupported shape / options (M=%d N=%d K=%d)", g.M, g.N, g.K);
     if (g.M <= 0 || g.N <= 0) return MC_OK;
+    if ((long)g.M * g.lda * 4 >= (1L << 32) || (long)g.N * g.ldw * 4 >= (1L << 32))      // the DMA takes 32-bit byte offsets into A and W
+        return mc_launch_gemm(GM_PLAIN, g, groups, 0, stream);
     const bool vec = g.N % SN == 0 && g.ldc % 4 == 0 && g.c_col % 4 == 0 && g.c_gstride % 4 == 0 && (!g.R || (g.ldr % 4 == 0 && (g.r_gstride < 0 || g.r_gstride % 4 == 0))) &&
                      (!g.add || g.ld_add % 4 == 0) && g.b_gstride % 4 == 0;
-    dim3 grid(cdiv(g.M, SM) * cdiv(g.N, SN), groups > 0 ? groups : 1);
-    if (vec) hipLaunchKernelGGL(gemm_small_k<true>, grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL(gemm_small_k<false>, grid, dim3(256), 0, stream, g);
+    // tile width: the launch is bound by the MFMA pipe of the busiest CU, i.e. by rounds of (up to 256) tiles x tile width;
+    // 64 x 64 unless a 64 x 48 or 64 x 96 grid needs strictly less (few-hundred-row launches: B = 1, 2 at 196 frames)
+    static const int force_nb = [] { const char* e = getenv("MC_SMALL_TILE_N"); return e ? atoi(e) : 0; }();
+    const int ng = groups > 0 ? groups : 1;
+    auto cost = [&](int nb) { return (long)cdiv((long)cdiv(g.M, SM) * cdiv(g.N, nb) * ng, 256) * nb; };
+    int nb = SN;
+    if (g.N % 48 == 0 && cost(48) < cost(nb)) nb = 48;
+    if (g.N % 96 == 0 && cost(96) < cost(nb)) nb = 96;
+    if (nb == 48 && g.N % 96 == 0 && cost(96) == cost(48)) nb = 96;        // same cost: fewer, larger tiles
+    if (force_nb == 64 || (force_nb && g.N % force_nb == 0 && (force_nb == 48 || force_nb == 96))) nb = force_nb;
+    dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
+    if (nb == 48) {
+        if (vec) hipLaunchKernelGGL((gemm_small16_k<3, true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_small16_k<3, false>), grid, dim3(256), 0, stream, g);
+    } else if (nb == 96) {
+        if (vec) hipLaunchKernelGGL((gemm_small16_k<6, true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_small16_k<6, false>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (vec) hipLaunchKernelGGL(gemm_small_k<true>, grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL(gemm_small_k<false>, grid, dim3(256), 0, stream, g);
+    }
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -62,7 +62,11 @@ def test_gemm_family_vs_fp64():
     g = torch.Generator().manual_seed(0)
     for (M, N, K, act, res) in [(128, 128, 32, 0, False), (300, 200, 64, 1, True), (77, 322, 1536, 0, False),
                                 (1000, 64, 192, 2, False), (5, 3072, 2048, 0, False), (257, 129, 20, 0, True),
-                                (1, 1, 4, 0, False)]:
+                                (1, 1, 4, 0, False),
+                                # the small-M kernel picks its tile width per launch (mc_launch_gemm_small): 64 x 48 tiles
+                                # (B=1 FiLM Linear), 64 x 96 (B=2), 48-wide with ragged N and M (scalar epilogue), 64 x 64
+                                (392, 1536, 1536, 0, True), (784, 1536, 1536, 0, True), (37, 144, 96, 0, True),
+                                (100, 96, 64, 0, False), (1176, 1536, 256, 0, True)]:
         a = torch.randn(M, K, generator=g)
         w = torch.randn(N, K, generator=g) / K ** 0.5
         b = torch.randn(N, generator=g)
