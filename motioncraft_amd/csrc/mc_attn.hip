@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
         const int c4 = (tid % C4) * 4, sl = tid / C4;
         // log2 domain: k2 = k * log2(e); exp(k - m) = exp2(k2 - m2) is one v_exp_f32
         f32x4 m = {-3e38f, -3e38f, -3e38f, -3e38f}, s = {0.f, 0.f, 0.f, 0.f};
-        constexpr int BATCH = 8;
+        constexpr int BATCH = LSPLIT ? 12 : 8;       // (small batches: 3 round trips to L2 instead of 5 for the 273 rows; the extra registers are free there)
         for (int n0 = sl; n0 < Nseq; n0 += NSL * BATCH) {
             f32x4 kk[BATCH];
             float mv[BATCH];

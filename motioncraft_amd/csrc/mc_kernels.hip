@@ -310,6 +310,17 @@ __global__ __launch_bounds__(256) void cfg_combine_tab_k(const float* __restrict
         out[i] = a * x[i] + b * y[i];
 }
 
+// The CFG combine of the folded decoder tail runs on two row sets (h and a): both in one launch, blockIdx.y picks the set.
+// Coefficients by value, or (graph replay) from the device table at *step_ptr.
+struct AxpbySet { const float* x; const float* y; float* out; };
+__global__ __launch_bounds__(256) void axpby_pair_k(AxpbySet s0, AxpbySet s1, float a, float b, const SamplerCoefs* __restrict__ table,
+                                                    const int* __restrict__ step_ptr, long n) {
+    if (table) { a = table[*step_ptr].text_coef; b = table[*step_ptr].none_coef; }
+    const AxpbySet s = blockIdx.y ? s1 : s0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        s.out[i] = a * s.x[i] + b * s.y[i];
+}
+
 __global__ void set_int_k(int* dst, int value) { *dst = value; }
 
 }  // namespace
@@ -382,6 +393,16 @@ int mc_launch_cfg_combine_tab(const float* x, const float* y, const SamplerCoefs
     int blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(cfg_combine_tab_k, dim3(blocks), dim3(256), 0, s, x, y, table, step_ptr, out, n);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_axpby_pair(const float* x0, const float* y0, float* out0, const float* x1, const float* y1, float* out1, float a, float b,
+                         const SamplerCoefs* table, const int* step_ptr, long n, hipStream_t s) {
+    if (n <= 0) return MC_OK;
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(axpby_pair_k, dim3(blocks, 2), dim3(256), 0, s, AxpbySet{x0, y0, out0}, AxpbySet{x1, y1, out1}, a, b, table, step_ptr, n);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

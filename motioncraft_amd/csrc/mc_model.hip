@@ -1054,14 +1054,17 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
         if (c->graph_mode) return mc_launch_cfg_combine_tab(x, y, c->gcoefs, c->gstep, out, BT * D, s);
         return mc_launch_axpby(x, y, k->text_coef, k->none_coef, out, BT * D, s);
     };
-    if ((r = combine(c->h, c->h + BT * D, c->z2))) return r;     // h_c
+    if (defer && c->dec_cat_w && mc_chain_enabled(11)) {
+        // h_c and a_c in one launch
+        if ((r = mc_launch_axpby_pair(c->h, c->h + BT * D, c->z2, c->a, c->a + BT * D, c->z2 + BT * D, k->text_coef, k->none_coef,
+                                      c->graph_mode ? c->gcoefs : nullptr, c->graph_mode ? c->gstep : nullptr, BT * D, s))) return r;
+    } else if ((r = combine(c->h, c->h + BT * D, c->z2))) return r;     // h_c
     if (defer) {
         if (c->dec_cat_w && mc_chain_enabled(11)) {
             // ... and that Linear composed with the decoder is one [C, D] matrix (folded at pack time):
             //   x0 = [dec(h_c) + Wd b] + [a_c (Wd W)^T]
             // the two skinny products (N = C = 322: 294 tiles each, half a chip) are the two groups of ONE grouped GEMM
             // over (h_c | a_c) x (Wd | Wd W); the sampler kernel adds the two partial outputs
-            if ((r = combine(c->a, c->a + BT * D, c->z2 + BT * D))) return r;      // a_c
             GemmArgs t;
             t.A = c->z2; t.lda = D; t.a_gstride = BT * D; t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D;
             t.bias = c->dec_cat_b; t.b_gstride = C; t.C = c->out2; t.ldc = C; t.c_gstride = BT * C;
