@@ -23,7 +23,6 @@ def main(path, n=80):
     rows = cur.execute(f'select {sel} from kernels order by start desc limit {n}').fetchall()[::-1]
     t0 = rows[0][1]
     busy_end = rows[0][1]
-    print(f'# columns of `kernels`: {cols}')
     print(f'{"kernel":48s} {"queue":>6s} {"start_us":>10s} {"dur_us":>8s} {"gap_us":>8s}')
     tot_gap = 0.0
     for name, st, en, q in rows:
