@@ -1007,6 +1007,35 @@ def test_text_to_motion_call_with_clip_features_through_the_reference_api():
     arch.model.release()
 
 
+@pytest.mark.parametrize('L', [32, 128])
+def test_small_batch_gate_kernel_is_bit_identical_to_gate_k(L, monkeypatch):
+    """gate_small_k (32-token workgroups, projector chunks split over the waves: batches of up to 12000 tokens) against
+    gate_k on the same input: expert ids, renormalised gates, importance keys and the expert input z must match BIT FOR BIT --
+    the kernel a batch size selects must never change a routing decision (a tree sum of the waves' partial logits differs
+    by 1 ulp and flips near-tie choices of this flat-gate small model within a 50-step loop)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = W.default_dims(max_seq_len=24, L=L, NL=2, F=64, Te=64, Dt=32, Nt=8)
+    nm = NativeModel(dims, W.make_state_dict(dims, SMALL_SEED), cfg_scale=dims['scale'])
+    B, T = 2, 24
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, 322, generator=g).cuda()
+    xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],)).cuda()
+    got = {}
+    for mode in ('0', '1000000'):
+        monkeypatch.setenv('MC_GATE_SMALL', mode)            # read per launch (mc_launch_gate)
+        ctx = nm.context(B, T, max_steps=50)
+        ctx.set_timesteps(list(range(0, 1000, 20)))
+        ctx.set_condition(xf, torch.ones(B, T).cuda())
+        ctx.denoise(x, 30, stop_after_layers=2)              # buffers hold the gate outputs of layer 1 (all N tokens, no CFG twins)
+        torch.cuda.synchronize()
+        got[mode] = {k: ctx.buffer(k, dtype=torch.int32).cpu().clone() for k in ('idx', 'gate', 'key', 'z')}
+        ctx.close()
+    for k in ('idx', 'gate', 'key', 'z'):
+        assert torch.equal(got['0'][k], got['1000000'][k]), k
+    nm.close()
+
+
 @pytest.mark.parametrize('case', ['one_frame', 'fully_masked_sample', 'eight_experts', 'tiny_capacity', 'odd_tokens'])
 def test_edge_cases_vs_oracle(case):
     """Shapes and routing regimes the reference's own paths can reach: a single frame (temporal softmax over the text
