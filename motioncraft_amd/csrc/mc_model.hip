@@ -283,6 +283,15 @@ int bind_half_weights(mc_ctx* c) {
     return MC_OK;
 }
 
+// The fp16-MFMA kernels have no small-batch variants (128-row workgroups, no hidden / K split): up to this many residual
+// rows (B=1 at 196 frames: 392) the fp32 small-batch kernels are faster and the reduced-precision modes run on them
+// (B=1 50-step DDIM: 68.3 ms on the fp16 kernels, 57.3 ms on the fp32 ones; from B=2 the fp16 kernels win).
+static long half_min_rows() {
+    const char* e = getenv("MC_HALF_MIN_ROWS");      // (read per call: the tests force the fp16 kernels at their small sizes)
+    return e ? atol(e) : 512L;
+}
+static bool use_half(const mc_ctx* c) { return c->prec != MC_PREC_F32 && c->rows > half_min_rows(); }
+
 static long small_gemm_rows() {
     static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 6400L; }();
     return v;
@@ -344,7 +353,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
         m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
         m.num_tiles = mc_route_num_tiles_ptr(c->rb, group); m.src_row = c->rb.src_row; m.dst_row = c->rb.dst_row;
-        if (hw && hw->hi && hw2 && hw2->hi && c->prec != MC_PREC_F32)      // reduced-precision mode: the same fused MLP on the fp16 MFMA
+        if (hw && hw->hi && hw2 && hw2->hi && use_half(c))      // reduced-precision mode: the same fused MLP on the fp16 MFMA
             return mc_launch_mlp_h(MLP_EXPERT, m, hw->hi, hw->lo, hw2->hi, hw2->lo, c->prec == MC_PREC_F16X3, 1, max_tiles, s);
         // small batches (a few dozen tiles, each walking all hidden chunks serially): split the hidden dimension 4 ways,
         // partial FC2 sums in hbuf, reduced in a fixed order (rows of dropped pairs stay unwritten garbage: never read)
@@ -422,7 +431,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
                                  y1_parts, nrows * D))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
-    if (hw && hw->hi && c->prec != MC_PREC_F32)
+    if (hw && hw->hi && use_half(c))
         return dense_h(c, c->a + o, *hw, out_b, hs + o, hs + o, nrows, D, D, s);
     if (nrows <= small_gemm_rows() && D % 64 == 0) {     // up to a few thousand rows: 64 x 64 tiles, short MFMA chains, no K split (B=8: -11 % per step)
         GemmArgs q;
@@ -465,7 +474,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         p.alias = tok_alias;
         if (pq_fused) {       // + the dynamic body topology's shared LayerNorm and q/k/v on the body_value columns
             p.gamma = w.dyn_g; p.beta = w.dyn_b; p.W2 = w.qkv_w; p.bias2 = w.qkv_b; p.Y2 = c->qkv; p.ldy2 = 3 * L;
-            if (c->prec != MC_PREC_F32 && w.h_proj.hi && w.h_qkv.hi) {
+            if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
                 if ((r = mc_launch_projqkv_h(p, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
             } else if ((r = mc_launch_projqkv(p, s))) return r;
         } else if ((r = mc_launch_rowchain(0, p, s))) return r;
@@ -530,7 +539,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;
         static const int S_env = [] { const char* e = getenv("MC_SPLIT_SFFN"); return e ? atoi(e) : 4; }();
         const int S = S_env;
-        if (c->prec != MC_PREC_F32 && w.h_w1.hi && w.h_w2.hi) {
+        if (use_half(c) && w.h_w1.hi && w.h_w2.hi) {
             if ((r = mc_launch_mlp_h(MLP_PARTS, m, w.h_w1.hi, w.h_w1.lo, w.h_w2.hi, w.h_w2.lo, c->prec == MC_PREC_F16X3, H, 0, s))) return r;
         } else
         if (nrows <= 2048 && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
@@ -1009,7 +1018,7 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
             if ((r = run_layer(c, slot, c->hc, step, false, split, s))) return r;                       // copied_block
             const LayerW& cw = c->lw[slot];
             if ((r = by_group([&](long r0, long n, hipStream_t sk) {                                   // h += after_proj(c)
-                     if (c->prec != MC_PREC_F32 && cw.h_after.hi)
+                     if (use_half(c) && cw.h_after.hi)
                          return dense_h(c, c->hc + r0 * D, cw.h_after, cw.after_b, c->h + r0 * D, c->h + r0 * D, n, D, D, sk);
                      return dense(c->hc + r0 * D, D, cw.after_w, D, cw.after_b, c->h + r0 * D, D, c->h + r0 * D, D, n, D, D, ACT_NONE, sk); })))
                 return r;

@@ -1007,6 +1007,35 @@ def test_text_to_motion_call_with_clip_features_through_the_reference_api():
     arch.model.release()
 
 
+def test_fp16_modes_use_the_fp32_kernels_at_tiny_batches(monkeypatch):
+    """Default policy (MC_HALF_MIN_ROWS unset = 512 residual rows): a B=1-sized context in the f16x3 mode runs the fp32
+    small-batch kernels -- bit-identical to the f32 mode -- and the fp16 kernels once the limit is lifted."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = W.default_dims(max_seq_len=24, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
+    nm = NativeModel(dims, W.make_state_dict(dims, SMALL_SEED), cfg_scale=dims['scale'])
+    B, T = 2, 24
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, T, 322, generator=g).cuda()
+    xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],)).cuda()
+
+    def run(prec):
+        ctx = nm.context(B, T, max_steps=50)
+        ctx.set_precision(prec)
+        ctx.set_timesteps(list(range(0, 1000, 20)))
+        ctx.set_condition(xf, torch.ones(B, T).cuda())
+        out = ctx.denoise(x, 30).clone()
+        ctx.close()
+        return out
+    monkeypatch.delenv('MC_HALF_MIN_ROWS', raising=False)
+    ref, same = run('f32'), run('f16x3')
+    assert torch.equal(ref, same)
+    monkeypatch.setenv('MC_HALF_MIN_ROWS', '0')
+    other = run('f16x3')
+    assert not torch.equal(ref, other) and maxabs(ref, other) < 1e-3
+    nm.close()
+
+
 @pytest.mark.parametrize('L', [32, 128])
 def test_small_batch_gate_kernel_is_bit_identical_to_gate_k(L, monkeypatch):
     """gate_small_k (32-token workgroups, projector chunks split over the waves: batches of up to 12000 tokens) against
