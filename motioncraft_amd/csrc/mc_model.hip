@@ -495,7 +495,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     if (st != s) {
         MC_HIP(hipEventRecord(c->ev_fork, s));
         MC_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
-        if (mc_chain_enabled(14)) sb = st; else stt = st;
+        if (mc_chain_enabled(14) && c->rows <= 1200) sb = st; else stt = st;      // (B <= 3 at 196 frames: -1.5 .. -3 %; B = 4: +1 %)
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
     if (pq_fused) {
