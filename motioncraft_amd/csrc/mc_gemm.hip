@@ -811,8 +811,8 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
                    g.act == ACT_NONE,
                "gemm_small: unsupported shape / options (M=%d N=%d K=%d)", g.M, g.N, g.K);
     if (g.M <= 0 || g.N <= 0) return MC_OK;
-    if ((long)g.M * g.lda * 4 >= (1L << 32) || (long)g.N * g.ldw * 4 >= (1L << 32))      // the DMA takes 32-bit byte offsets into A and W
-        return mc_launch_gemm(GM_PLAIN, g, groups, 0, stream);
+    MC_REQUIRE((long)g.M * g.lda * 4 < (1L << 32) && (long)g.N * g.ldw * 4 < (1L << 32),
+               "gemm_small: operands beyond 4 GB (the DMA takes 32-bit byte offsets into A and W; this kernel is for a few thousand rows)");
     const bool vec = g.N % SN == 0 && g.ldc % 4 == 0 && g.c_col % 4 == 0 && g.c_gstride % 4 == 0 && (!g.R || (g.ldr % 4 == 0 && (g.r_gstride < 0 || g.r_gstride % 4 == 0))) &&
                      (!g.add || g.ld_add % 4 == 0) && g.b_gstride % 4 == 0;
     // tile width: the launch is bound by the MFMA pipe of the busiest CU, i.e. by rounds of (up to 256) tiles x tile width;
