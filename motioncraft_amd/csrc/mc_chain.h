@@ -43,6 +43,7 @@ struct GateArgs {
     const float* logit_scale = nullptr;
     long tok0 = 0, N = 0;          // tokens [tok0, N)
     int zero_cnt = 1;              // launcher clears cnt first (0: the caller did, several launches accumulate)
+    long small_tokens = 12000;     // launches of up to this many tokens run as gate_small_k (bit-identical; B <= 2 at 196 frames)
     int E = 0, L = 0;
     int* idx = nullptr;            // [N][2]
     float* gate = nullptr;         // [N][2]

@@ -604,8 +604,7 @@ int mc_launch_gate(const GateArgs& g, hipStream_t s) {
     MC_REQUIRE(g.E >= 2 && g.E <= 16, "gate: num_experts=%d unsupported (2..16)", g.E);
     if (g.zero_cnt) MC_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * 32, s));
     if (g.N <= g.tok0) return MC_OK;
-    const long small_tokens = [] { const char* e = getenv("MC_GATE_SMALL"); return e ? atol(e) : 12000L; }();     // (read per launch: tests flip it)
-    if (g.N - g.tok0 <= small_tokens) {        // latency-bound sizes (B <= 2 at 196 frames; B=1 -2.8 ms per 50 steps, B=4 +1 ms): 32-token workgroups
+    if (g.N - g.tok0 <= g.small_tokens) {        // latency-bound sizes (B <= 2 at 196 frames; B=1 -2.8 ms per 50 steps, B=4 +1 ms): 32-token workgroups
         dim3 grid(cdiv(g.N - g.tok0, 32));
         switch (g.L) {
             case 128: hipLaunchKernelGGL(gate_small_k<128>, grid, dim3(256), 0, s, g); break;

@@ -95,6 +95,8 @@ struct mc_ctx {
     hipGraphExec_t graph_exec = nullptr;
     int graph_steps = 0;
     int prec = MC_PREC_F32;      // MFMA operand precision of the per-step GEMM-shaped kernels (mc_ctx_set_precision)
+    long half_min_rows = 512;    // env MC_HALF_MIN_ROWS at context creation: see use_half()
+    long gate_small_tokens = 12000;   // env MC_GATE_SMALL at context creation: up to this many tokens the gate runs as gate_small_k
     int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
     float* cap_w = nullptr;      // ... and combine weights (0 = dropped) of every layer
 };
@@ -286,11 +288,7 @@ int bind_half_weights(mc_ctx* c) {
 // The fp16-MFMA kernels have no small-batch variants (128-row workgroups, no hidden / K split): up to this many residual
 // rows (B=1 at 196 frames: 392) the fp32 small-batch kernels are faster and the reduced-precision modes run on them
 // (B=1 50-step DDIM: 68.3 ms on the fp16 kernels, 57.3 ms on the fp32 ones; from B=2 the fp16 kernels win).
-static long half_min_rows() {
-    const char* e = getenv("MC_HALF_MIN_ROWS");      // (read per call: the tests force the fp16 kernels at their small sizes)
-    return e ? atol(e) : 512L;
-}
-static bool use_half(const mc_ctx* c) { return c->prec != MC_PREC_F32 && c->rows > half_min_rows(); }
+static bool use_half(const mc_ctx* c) { return c->prec != MC_PREC_F32 && c->rows > c->half_min_rows; }
 
 static long small_gemm_rows() {
     static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 6400L; }();
@@ -606,7 +604,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         GateArgs ga;
         ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
         ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_nT = w.mm.sim_nT; ga.logit_scale = w.mm.scale;
-        ga.E = g.num_experts; ga.L = L;
+        ga.E = g.num_experts; ga.L = L; ga.small_tokens = c->gate_small_tokens;
         ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
         if (split == 2 && !twin) {
             MC_HIP(hipMemsetAsync(ga.cnt, 0, sizeof(int) * 32, s));
@@ -744,6 +742,8 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     MC_REQUIRE(max_steps >= 1, "max_steps < 1");
     const mc_model_config& g = m->cfg;
     mc_ctx* c = new mc_ctx();
+    if (const char* e = getenv("MC_HALF_MIN_ROWS")) c->half_min_rows = atol(e);      // (the tests lift it to run the fp16 kernels at their small sizes)
+    if (const char* e = getenv("MC_GATE_SMALL")) c->gate_small_tokens = atol(e);
     c->m = m;
     c->B = batch;
     c->T = frames;

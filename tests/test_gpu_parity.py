@@ -1052,7 +1052,7 @@ def test_small_batch_gate_kernel_is_bit_identical_to_gate_k(L, monkeypatch):
     xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],)).cuda()
     got = {}
     for mode in ('0', '1000000'):
-        monkeypatch.setenv('MC_GATE_SMALL', mode)            # read per launch (mc_launch_gate)
+        monkeypatch.setenv('MC_GATE_SMALL', mode)            # read when the context is created
         ctx = nm.context(B, T, max_steps=50)
         ctx.set_timesteps(list(range(0, 1000, 20)))
         ctx.set_condition(xf, torch.ones(B, T).cuda())
