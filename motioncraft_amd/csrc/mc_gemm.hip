@@ -820,17 +820,18 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     static const int force_nb = [] { const char* e = getenv("MC_SMALL_TILE_N"); return e ? atoi(e) : 0; }();
     const int ng = groups > 0 ? groups : 1;
     auto cost = [&](int nb) { return (long)cdiv((long)cdiv(g.M, SM) * cdiv(g.N, nb) * ng, 256) * nb; };
-    int nb = SN;
-    if (g.N % 48 == 0 && cost(48) < cost(nb)) nb = 48;
-    if (g.N % 96 == 0 && cost(96) < cost(nb)) nb = 96;
-    if (nb == 48 && g.N % 96 == 0 && cost(96) == cost(48)) nb = 96;        // same cost: fewer, larger tiles
-    if (force_nb == 64 || (force_nb && g.N % force_nb == 0 && (force_nb == 48 || force_nb == 96))) nb = force_nb;
+    int nb = SN;                                   // (a ragged last column tile counts as a full one: N = 322 is 6 x 64 or 7 x 48)
+    if (cost(48) < cost(nb)) nb = 48;
+    if (cost(96) < cost(nb)) nb = 96;
+    if (nb == 48 && cost(96) == cost(48)) nb = 96;        // same cost: fewer, larger tiles
+    if (force_nb == 64 || force_nb == 48 || force_nb == 96) nb = force_nb;
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
+    const bool vec16 = vec && g.N % nb == 0;       // the float4 epilogue has no column guard
     if (nb == 48) {
-        if (vec) hipLaunchKernelGGL((gemm_small16_k<3, true>), grid, dim3(256), 0, stream, g);
+        if (vec16) hipLaunchKernelGGL((gemm_small16_k<3, true>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((gemm_small16_k<3, false>), grid, dim3(256), 0, stream, g);
     } else if (nb == 96) {
-        if (vec) hipLaunchKernelGGL((gemm_small16_k<6, true>), grid, dim3(256), 0, stream, g);
+        if (vec16) hipLaunchKernelGGL((gemm_small16_k<6, true>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((gemm_small16_k<6, false>), grid, dim3(256), 0, stream, g);
     } else {
         if (vec) hipLaunchKernelGGL(gemm_small_k<true>, grid, dim3(256), 0, stream, g);

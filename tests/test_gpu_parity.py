@@ -85,6 +85,33 @@ def test_gemm_family_vs_fp64():
         L_.check(lib.mc_op_gemm(_ptr(ad), _ptr(wd), None, None, _ptr(c), 4, 4, 3, 3, 0, _stream()))  # K % 4 != 0
 
 
+def test_small_gemm_random_shapes_vs_fp64():
+    """The small-M GEMM picks its kernel and tile width per launch (64 x 64 on the 32x32 MFMA, 64 x 48 / 64 x 96 on the 16x16
+    one, float4 or guarded scalar epilogue): random (M, N, K, bias, residual) against fp64, with guard rows behind C
+    (a tile wider than the ragged edge of N must not store past it)."""
+    import random
+    from motioncraft_amd import lib as L_
+    from motioncraft_amd.engine import _ptr, _stream
+    lib = L_.load(require_gpu=True)
+    rnd = random.Random(1)
+    for it in range(90):
+        M = rnd.choice([1, 5, 31, 33, 63, 64, 65, 100, 127, 200, 392, 500, 784, 1000, 1176, 2000])
+        N = rnd.choice([4, 16, 44, 48, 52, 64, 96, 100, 144, 192, 240, 288, 322, 384, 480, 768, 1536])
+        K = rnd.choice([32, 64, 96, 128, 256, 1536])
+        bias, res = rnd.random() < 0.7, rnd.random() < 0.5
+        g = torch.Generator().manual_seed(it)
+        a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+        b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ad, wd, bd, rd = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+        c = torch.full((M + 2, N), 777.0, device='cuda')
+        L_.check(lib.mc_op_gemm(_ptr(ad), _ptr(wd), _ptr(bd) if bias else None, _ptr(rd) if res else None, _ptr(c), M, N, K, K, 0,
+                                _stream()))
+        torch.cuda.synchronize()
+        ref = a.double() @ w.double().t() + (b.double() if bias else 0) + (r.double() if res else 0)
+        assert bool((c[M:] == 777.0).all()), ('stored past the last row', M, N, K)
+        assert maxabs(c[:M], ref) <= 3e-5, (M, N, K, bias, res)
+
+
 def test_ln_rows_and_sampler_update_ops():
     from motioncraft_amd import lib as L_
     from motioncraft_amd.diffusion import build_diffusion
