@@ -106,6 +106,7 @@ struct RouteBufs {
     int* state;        // small int block, layout in mc_route.hip
     int max_tiles;
     uint32_t tie_xor = 0xFFFFFFFFu;   // order of equal-importance tokens at the capacity cut: ~0 = lower index first (stable), 0 = higher first
+    bool reg_kernel = true;           // small batches: the register-resident one-workgroup routing kernel (false: the L2-streaming form at every size; env MC_ROUTE_REG=0, tests)
 };
 size_t mc_route_state_ints(int E);
 bool mc_route_is_small(long N);   // routing of N tokens runs as the one-workgroup kernel, which also leaves the (choice, expert) counts zeroed

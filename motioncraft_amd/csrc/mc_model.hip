@@ -744,6 +744,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     mc_ctx* c = new mc_ctx();
     if (const char* e = getenv("MC_HALF_MIN_ROWS")) c->half_min_rows = atol(e);      // (the tests lift it to run the fp16 kernels at their small sizes)
     if (const char* e = getenv("MC_GATE_SMALL")) c->gate_small_tokens = atol(e);
+    if (const char* e = getenv("MC_ROUTE_REG")) c->rb.reg_kernel = atoi(e) != 0;
     c->m = m;
     c->B = batch;
     c->T = frames;

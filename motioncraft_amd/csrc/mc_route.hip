@@ -680,7 +680,7 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
     hipLaunchKernelGGL(KERNEL, dim3(1), dim3(SMALL_THREADS), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity,   \
                        (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,        \
                        rb.max_tiles, rb.tie_xor)
-        if (2 * N <= 10L * SMALL_THREADS) MC_ROUTE_SMALL(route_small_k<10>);
+        if (rb.reg_kernel && 2 * N <= 10L * SMALL_THREADS) MC_ROUTE_SMALL(route_small_k<10>);
         else MC_ROUTE_SMALL(route_small_stream_k);
 #undef MC_ROUTE_SMALL
         MC_LAUNCH_CHECK();

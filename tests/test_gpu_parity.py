@@ -1320,6 +1320,45 @@ def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
     nm.close()
 
 
+@pytest.mark.parametrize('regime', ['random_scores', 'exact_ties', 'tiny_capacity', 'reverse_ties'])
+def test_register_routing_kernel_equals_the_streaming_form(regime, monkeypatch):
+    """route_small_k<10> (pairs in registers, selection problems resolved as soon as a bin is taken whole) against the
+    L2-streaming one-workgroup kernel it replaces up to 10240 pairs (MC_ROUTE_REG=0): identical keep flags / combine weights and
+    bit-identical denoiser output, with every radix pass exercised -- random scores (resolved after the 4 score bytes), exact
+    score ties (only the token-index bytes split them), capacity so small that second choices are dropped wholesale, and the
+    reverse tie order."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = SMALL
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    if regime in ('exact_ties', 'reverse_ties'):
+        for l in range(dims['NL']):
+            pre = f'temporal_decoder_blocks.{l}.ca_block.motion_moe.model.gates.0.cosine_projector.'
+            sd[pre + 'weight'] = torch.zeros_like(sd[pre + 'weight'])
+            sd[pre + 'bias'] = torch.randn(sd[pre + 'bias'].shape, generator=torch.Generator().manual_seed(21 + l))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'], capacity_factor=0.3 if regime == 'tiny_capacity' else 1.5)
+    x, xf, mask = synth_inputs(dims, 3, 24, seed=5, lengths=[24, 20, 7])
+    got = {}
+    for reg in ('0', '1'):
+        monkeypatch.setenv('MC_ROUTE_REG', reg)               # read when the context is created
+        ctx = nm.context(3, 24, max_steps=1)
+        if regime == 'reverse_ties':
+            ctx.set_tie_policy('reverse')
+        ctx.enable_capture()
+        ctx.set_timesteps([500])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out2 = ctx.denoise(x.cuda(), 0).clone()
+        got[reg] = (out2, [ctx.routing(l) for l in range(dims['NL'])])
+        ctx.close()
+    assert torch.equal(got['0'][0], got['1'][0])
+    dropped = 0
+    for (ia, ka), (ib, kb) in zip(got['0'][1], got['1'][1]):
+        assert torch.equal(ia, ib) and torch.equal(ka, kb)
+        dropped += int((~ka).sum())
+    assert dropped > 0, 'the capacity cut never engaged: the radix passes were not exercised'
+    nm.close()
+
+
 def test_control_branch_without_condition_cfg_vs_oracle():
     """condition_encode_cfg.condition_cfg=False: the control condition also drives the unconditional CFG half
     (controlnet.py forward_test: `c * cond_type` only when condition_cfg)."""
