@@ -501,7 +501,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_k(const int* __rest
     }
 }
 
-// The same kernel for more pairs than fit in registers (10 < pairs per thread <= 32): idx / key are re-read from L2 in
+// The same kernel for more pairs than fit in registers (20 < pairs per thread <= 32): idx / key are re-read from L2 in
 // every phase.
 __global__ __launch_bounds__(SMALL_THREADS) void route_small_stream_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                               const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit,
@@ -681,6 +681,7 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
                        (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,        \
                        rb.max_tiles, rb.tie_xor)
         if (rb.reg_kernel && 2 * N <= 10L * SMALL_THREADS) MC_ROUTE_SMALL(route_small_k<10>);
+        else if (rb.reg_kernel && 2 * N <= 20L * SMALL_THREADS) MC_ROUTE_SMALL(route_small_k<20>);      // (25 registers spill to scratch: still -4 % per step at B=2 vs the streaming form)
         else MC_ROUTE_SMALL(route_small_stream_k);
 #undef MC_ROUTE_SMALL
         MC_LAUNCH_CHECK();

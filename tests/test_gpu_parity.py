@@ -1320,10 +1320,11 @@ def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
     nm.close()
 
 
-@pytest.mark.parametrize('regime', ['random_scores', 'exact_ties', 'tiny_capacity', 'reverse_ties'])
-def test_register_routing_kernel_equals_the_streaming_form(regime, monkeypatch):
-    """route_small_k<10> (pairs in registers, selection problems resolved as soon as a bin is taken whole) against the
-    L2-streaming one-workgroup kernel it replaces up to 10240 pairs (MC_ROUTE_REG=0): identical keep flags / combine weights and
+@pytest.mark.parametrize('regime,B', [('random_scores', 3), ('exact_ties', 3), ('tiny_capacity', 3), ('reverse_ties', 3),
+                                      ('random_scores', 9), ('tiny_capacity', 9), ('exact_ties', 9)])
+def test_register_routing_kernel_equals_the_streaming_form(regime, B, monkeypatch):
+    """route_small_k<10> / <20> (pairs in registers, selection problems resolved as soon as a bin is taken whole; B = 3: 3456
+    pairs -> <10>, B = 9: 10368 pairs -> <20>) against the L2-streaming one-workgroup kernel they replace (MC_ROUTE_REG=0): identical keep flags / combine weights and
     bit-identical denoiser output, with every radix pass exercised -- random scores (resolved after the 4 score bytes), exact
     score ties (only the token-index bytes split them), capacity so small that second choices are dropped wholesale, and the
     reverse tie order."""
@@ -1337,11 +1338,11 @@ def test_register_routing_kernel_equals_the_streaming_form(regime, monkeypatch):
             sd[pre + 'weight'] = torch.zeros_like(sd[pre + 'weight'])
             sd[pre + 'bias'] = torch.randn(sd[pre + 'bias'].shape, generator=torch.Generator().manual_seed(21 + l))
     nm = NativeModel(dims, sd, cfg_scale=dims['scale'], capacity_factor=0.3 if regime == 'tiny_capacity' else 1.5)
-    x, xf, mask = synth_inputs(dims, 3, 24, seed=5, lengths=[24, 20, 7])
+    x, xf, mask = synth_inputs(dims, B, 24, seed=5, lengths=([24, 20, 7] * 3)[:B])
     got = {}
     for reg in ('0', '1'):
         monkeypatch.setenv('MC_ROUTE_REG', reg)               # read when the context is created
-        ctx = nm.context(3, 24, max_steps=1)
+        ctx = nm.context(B, 24, max_steps=1)
         if regime == 'reverse_ties':
             ctx.set_tie_policy('reverse')
         ctx.enable_capture()
