@@ -646,7 +646,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_stream_k(const int*
 }  // namespace
 
 static long route_small_pairs() {
-    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 32768L; return x > 32768L ? 32768L : x; }();   // route_small_k: <= 32 pairs per thread, token indices < 2^16
+    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 32768L; return x > 131072L ? 131072L : x; }();   // the one-workgroup kernels assume token indices < 2^16
     return v;
 }
 
