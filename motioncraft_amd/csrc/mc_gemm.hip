@@ -820,10 +820,14 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     static const int force_nb = [] { const char* e = getenv("MC_SMALL_TILE_N"); return e ? atoi(e) : 0; }();
     const int ng = groups > 0 ? groups : 1;
     auto cost = [&](int nb) { return (long)cdiv((long)cdiv(g.M, SM) * cdiv(g.N, nb) * ng, 256) * nb; };
-    int nb = SN;                                   // (a ragged last column tile counts as a full one: N = 322 is 6 x 64 or 7 x 48)
-    if (cost(48) < cost(nb)) nb = 48;
-    if (cost(96) < cost(nb)) nb = 96;
-    if (nb == 48 && cost(96) == cost(48)) nb = 96;        // same cost: fewer, larger tiles
+    // (only widths that divide N: the decoder tail, N = 322, would be 7 x 48 instead of 6 x 64 tiles and 5 us faster at B=1,
+    // but the 16x16 kernel accumulates k in another order, and that 1-ulp change of the decoded x0 was enough to move a
+    // near-tie gate decision of the free-running full-size 50-step golden -- 0.63 off the reference's final pose with
+    // per-step parity at 6e-6; the 64-wide kernel keeps the trajectory the golden test pins)
+    int nb = SN;
+    if (g.N % 48 == 0 && cost(48) < cost(nb)) nb = 48;
+    if (g.N % 96 == 0 && cost(96) < cost(nb)) nb = 96;
+    if (nb == 48 && g.N % 96 == 0 && cost(96) == cost(48)) nb = 96;        // same cost: fewer, larger tiles
     if (force_nb == 64 || force_nb == 48 || force_nb == 96) nb = force_nb;
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
     const bool vec16 = vec && g.N % nb == 0;       // the float4 epilogue has no column guard

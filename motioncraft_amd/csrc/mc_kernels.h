@@ -106,10 +106,15 @@ struct RouteBufs {
     int* state;        // small int block, layout in mc_route.hip
     int max_tiles;
     uint32_t tie_xor = 0xFFFFFFFFu;   // order of equal-importance tokens at the capacity cut: ~0 = lower index first (stable), 0 = higher first
+    bool coop = true;                 // larger batches: the cooperative one-launch routing kernel (false: the 12-launch sequence; env MC_ROUTE_COOP=0, tests)
+    long small_pairs = -1;            // >= 0: overrides MC_ROUTE_SMALL for this context (tests force the large-batch paths on small configs)
     bool reg_kernel = true;           // small batches: the register-resident one-workgroup routing kernel (false: the L2-streaming form at every size; env MC_ROUTE_REG=0, tests)
 };
 size_t mc_route_state_ints(int E);
-bool mc_route_is_small(long N);   // routing of N tokens runs as the one-workgroup kernel, which also leaves the (choice, expert) counts zeroed
+bool mc_route_is_small(long N);
+bool mc_route_cleans_counts(const RouteBufs& rb, long N);   // the routing kernel that will run for N tokens hands the (choice, expert) counts back zeroed
+size_t mc_route_barrier_offset();                          // ints into the state block: grid-barrier words, to be zeroed once
+size_t mc_route_barrier_ints();   // routing of N tokens runs as the one-workgroup kernel, which also leaves the (choice, expert) counts zeroed
 // proj [N][256] (cosine_projector output incl. bias) -> idx/gate/key + per-expert choice counts
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,
                           RouteBufs rb, hipStream_t s);

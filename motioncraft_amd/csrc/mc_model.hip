@@ -397,7 +397,7 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
     c->cnt_clean = false;
     if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, gsplit, E, capacity, c->rb, s))) return r;
-    c->cnt_clean = mc_route_is_small(Ntok);
+    c->cnt_clean = mc_route_cleans_counts(c->rb, Ntok);
     if (gsplit < Ntok) return MC_OK;
     if ((r = moe_experts(c, w, z, Ntok, 0, s, hw, hw2))) return r;
     if (!out) return MC_OK;                        // the caller launches the projection itself (row ranges)
@@ -607,7 +607,8 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         ga.E = g.num_experts; ga.L = L; ga.small_tokens = c->gate_small_tokens;
         ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
         if (split == 2 && !twin) {
-            MC_HIP(hipMemsetAsync(ga.cnt, 0, sizeof(int) * 32, s));
+            if (!c->cnt_clean) MC_HIP(hipMemsetAsync(ga.cnt, 0, sizeof(int) * 32, s));
+            c->cnt_clean = false;
             if ((r = parts_fork(c, s))) return r;
             ga.zero_cnt = 0;
             for (int k = 0; k < c->nparts; ++k) {
@@ -745,6 +746,8 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     if (const char* e = getenv("MC_HALF_MIN_ROWS")) c->half_min_rows = atol(e);      // (the tests lift it to run the fp16 kernels at their small sizes)
     if (const char* e = getenv("MC_GATE_SMALL")) c->gate_small_tokens = atol(e);
     if (const char* e = getenv("MC_ROUTE_REG")) c->rb.reg_kernel = atoi(e) != 0;
+    if (const char* e = getenv("MC_ROUTE_COOP")) c->rb.coop = atoi(e) != 0;
+    if (const char* e = getenv("MC_ROUTE_SMALL_CTX")) c->rb.small_pairs = atol(e);
     c->m = m;
     c->B = batch;
     c->T = frames;
@@ -824,6 +827,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->rb.tile_row0, 2 * c->rb.max_tiles);
     WS(c->rb.tile_nrows, 2 * c->rb.max_tiles);
     WS(c->rb.state, mc_route_state_ints(g.num_experts));
+    MC_HIP(hipMemset(c->rb.state + mc_route_barrier_offset(), 0, mc_route_barrier_ints() * sizeof(int)));      // grid-barrier words of the cooperative routing kernel
 #undef WS
     *out = c;
     return MC_OK;

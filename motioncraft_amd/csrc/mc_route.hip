@@ -40,7 +40,8 @@ enum {
     ST_SPLIT = ST_DONE + 1,
     ST_PREFIX = ST_DONE + 2,    // [MAXP][2]   (hi, lo) of the selected prefix / final threshold
     ST_HIST = ST_PREFIX + 2 * MAXP,  // [MAXP][256]
-    ST_TOTAL = ST_HIST + MAXP * 256
+    ST_BAR = (ST_HIST + MAXP * 256 + 31) / 32 * 32,   // grid barrier words of route_coop_k (17 x 32 ints, zeroed once at context creation)
+    ST_TOTAL = ST_BAR + 17 * 32
 };
 
 // tie_xor = 0xFFFFFFFF: among tokens of EQUAL importance the lower token index ranks first (a stable sort by descending
@@ -310,6 +311,284 @@ __global__ __launch_bounds__(256) void route_fill_k(const int* __restrict__ idx,
             src_row[slot] = (int)(a >> 1);
             dst_row[slot] = (int)a;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole routing step of a layer as ONE launch for any batch that fits 10 pairs per thread on <= 256 workgroups
+// (<= 655360 pairs: B <= 69 at 196 frames): the 12 launches above (init, 8 radix passes, keep, plan, fill) are the one
+// place of the step where every stream waits -- routing ranks the tokens of the whole batch against each other -- so their
+// launch gaps sit exposed on the critical path (~90 us per layer at B = 64, 60 us at B = 4).
+// Workgroups are co-resident (256 threads, 33 KB of LDS) and meet at a grid barrier (arrival counter + generation word in
+// the state block, device-scope atomics; the LAST workgroup to arrive runs the serial part of a phase -- pick the bins,
+// plan the slot ranges -- before it releases the others).  Pairs live in registers as in route_small_k (importance bits +
+// packed problem id), histograms go LDS -> global atomics, selection problems resolve early when a bin is taken whole,
+// and the loop ends as soon as no problem is left selecting: 1 + (passes run, 4 unless scores tie exactly) + 1 barriers.
+// Same integer decisions as the launch sequence above (test_cooperative_routing_kernel_equals_the_launch_sequence).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int ld_state(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Two-level arrival (MI355X_MICROARCH.md, barrier-xcd row): workgroups arrive at one of 8 group counters (group =
+// blockIdx & 7, the XCD a block lands on under round-robin dispatch -- only speed depends on that), the last of a group
+// arrives at the top counter, the last of all runs the hook and bumps the 8 group generation words the others poll.
+// 32 arrivals / pollers per word instead of 256.  One release fence before the arrival, relaxed polling with s_sleep, ONE
+// acquire fence after the wait.  Every word sits in its own 128-byte line: bar[0] top, bar[32 (1 + g)] group counter,
+// bar[32 (9 + g)] group generation.
+constexpr int BAR_STRIDE = 32, BAR_INTS = 17 * BAR_STRIDE;
+template <class F>
+__device__ __forceinline__ void grid_sync(int* bar, int nwg, int* s_last, int* s_gen, F&& last_hook) {
+    const int grp = (int)(blockIdx.x & 7), ngrp = nwg < 8 ? nwg : 8, members = (nwg - grp + 7) >> 3;
+    int* cnt = bar + BAR_STRIDE * (1 + grp);
+    int* gen = bar + BAR_STRIDE * (9 + grp);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *s_gen = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (cannot advance before this workgroup arrives)
+        __threadfence();                                          // this workgroup's writes are out before it signals
+        int last = 0;
+        if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+        }
+        if (last) __threadfence();                                // acquire: everybody else's writes
+        *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last) {
+        last_hook();                                              // the whole workgroup
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ngrp) __hip_atomic_fetch_add(bar + BAR_STRIDE * (9 + (int)threadIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x == 0) {
+        // bounded: if the grid is not fully resident (more than three of these kernels in flight on one GPU at once) the wait
+        // would never end -- a few seconds of polling, then the kernel aborts loudly instead of hanging the device
+        unsigned spins = 0;
+        while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == *s_gen) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 23)) __builtin_trap();
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+constexpr int COOP_PER = 10;
+__global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx, const float* __restrict__ gate,
+                                                    const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit, int E,
+                                                    int capacity, int cnt_mul, float* __restrict__ comb_w, int* state,
+                                                    int* __restrict__ src_row, int* __restrict__ dst_row,
+                                                    int* __restrict__ tile_group, int* __restrict__ tile_row0,
+                                                    int* __restrict__ tile_nrows, int max_tiles, uint32_t tie_xor, int skip_mid) {
+    constexpr int PER = COOP_PER;
+    __shared__ int h[MAXP * 256];
+    __shared__ int s_act[MAXP];
+    __shared__ unsigned long long s_pre[MAXP];
+    __shared__ int s_kept[2 * MAXE], s_cnt[2 * MAXE], s_base[2 * MAXE];
+    __shared__ int s_off[2 * MAXE + 1], s_t0[2][MAXE + 1];
+    __shared__ int s_last, s_gen, s_any;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwg = (int)gridDim.x;
+    int* bar = state + ST_BAR;
+    // pairs a = (blockIdx.x * PER + i) * 256 + tid: importance bits + problem id byte (-1: past the end / no slot)
+    uint32_t kk[PER];
+    int pp8[(PER + 3) / 4];
+    auto get_p = [&](int i) { return (int)(pp8[i >> 2] << (24 - 8 * (i & 3))) >> 24; };
+    auto set_p = [&](int i, int v) { pp8[i >> 2] = (pp8[i >> 2] & ~(0xFF << (8 * (i & 3)))) | ((v & 0xFF) << (8 * (i & 3))); };
+    auto pair_of = [&](int i) { return ((long)blockIdx.x * PER + i) * 256 + tid; };
+#pragma unroll
+    for (int i = 0; i < (PER + 3) / 4; ++i) pp8[i] = -1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const long a = pair_of(i);
+        kk[i] = 0u;
+        if (a < 2 * N) {
+            const long tok = a >> 1;
+            const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+            set_p(i, (int)(a & 1) * MAXE + idx[2 * ts + (a & 1)]);
+            kk[i] = key[ts];
+        }
+    }
+    // ---- problem setup (route_init_k) by workgroup 0; it also hands the (choice, expert) counts back zeroed ----
+    if (blockIdx.x == 0) {
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if (tid < MAXP) {
+            const int choice = tid / MAXE, e = tid % MAXE;
+            int act = 0, rank = 0;
+            if (e < E) {
+                const int c0 = state[ST_CNT + e] * cnt_mul;
+                const int cnt = state[ST_CNT + tid] * cnt_mul;
+                const int limit = choice == 0 ? capacity : capacity - c0;
+                if (limit <= 0) act = cnt > 0 ? -1 : 0;
+                else if (cnt > limit) { act = 1; rank = limit; }
+            }
+            state[ST_ACTIVE + tid] = act;
+            state[ST_RANK + tid] = rank;
+            state[ST_PREFIX + 2 * tid] = 0;
+            state[ST_PREFIX + 2 * tid + 1] = 0;
+            if (act == 1) atomicOr(&s_any, 1);
+        }
+        for (int i = tid; i < MAXP * 256; i += 256) state[ST_HIST + i] = 0;
+        if (tid < 2 * MAXE) { state[ST_KEPT + tid] = 0; state[ST_FILL + tid] = 0; }
+        if (tid < 2) state[ST_DONE + tid] = 0;                    // (ST_DONE, ST_SPLIT)
+        __syncthreads();
+        if (tid < MAXP) state[ST_CNT + tid] = 0;
+        if (tid == 0) state[ST_ANY] = s_any;
+    }
+    grid_sync(bar, nwg, &s_last, &s_gen, [] {});
+    // ---- radix select, one byte per pass ----
+    for (int pass = 0; pass < 8; ++pass) {
+        if (ld_state(&state[ST_ANY]) == 0) break;                 // (uniform: written before the barrier every workgroup has passed)
+        if (skip_mid && (pass == 4 || pass == 5)) continue;       // token indices < 2^16: the pick of pass 3 appended both constant bytes
+        if (tid < MAXP) {
+            s_act[tid] = ld_state(&state[ST_ACTIVE + tid]);
+            s_pre[tid] = ((unsigned long long)(uint32_t)ld_state(&state[ST_PREFIX + 2 * tid]) << 32) | (uint32_t)ld_state(&state[ST_PREFIX + 2 * tid + 1]);
+        }
+        for (int i = tid; i < MAXP * 256; i += 256) h[i] = 0;
+        __syncthreads();
+        const int shift = 56 - 8 * pass;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int p = get_p(i);
+            if (p < 0 || s_act[p] != 1) continue;
+            const unsigned long long V = composite(kk[i], (uint32_t)(pair_of(i) >> 1), tie_xor);
+            if (pass > 0 && (V >> (shift + 8)) != s_pre[p]) continue;
+            atomicAdd(&h[p * 256 + (int)((V >> shift) & 255)], 1);
+        }
+        __syncthreads();
+        for (int i = tid; i < MAXP * 256; i += 256)
+            if (h[i]) atomicAdd(&state[ST_HIST + i], h[i]);
+        grid_sync(bar, nwg, &s_last, &s_gen, [&] {
+            // the last workgroup to arrive picks, per selecting problem, the bin that holds the rank-th largest key
+            if (tid == 0) s_any = 0;
+            __syncthreads();
+            for (int p = wave; p < MAXP; p += 4) {
+                if (s_act[p] != 1) continue;
+                int cb[4], t = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int* hp = &state[ST_HIST + p * 256 + 4 * lane + j];
+                    cb[j] = ld_state(hp);
+                    __hip_atomic_store(hp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t += cb[j];
+                }
+                int suf = t;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_down(suf, o, 64);
+                    if (lane + o < 64) suf += v;
+                }
+                const int rank = ld_state(&state[ST_RANK + p]);
+                int above = suf - t, found = -1, above_found = 0, incl_found = 0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int incl = above + cb[j];
+                    if (found < 0 && incl >= rank && above < rank) { found = 4 * lane + j; above_found = above; incl_found = incl; }
+                    above = incl;
+                }
+                if (found >= 0) {                                // exactly one lane finds the bin
+                    unsigned long long pre = (s_pre[p] << 8) | (unsigned long long)found;
+                    if (incl_found == rank && pass < 7) {        // the whole bin is kept: threshold = prefix, low bits zero
+                        pre <<= shift;
+                        state[ST_ACTIVE + p] = 2;
+                    } else {
+                        if (skip_mid && pass == 3) pre = (pre << 16) | (unsigned long long)((tie_xor >> 16) & 0xFFFFu);
+                        state[ST_RANK + p] = rank - above_found;
+                        s_any = 1;                               // (benign race: every writer stores 1)
+                    }
+                    state[ST_PREFIX + 2 * p] = (int)(uint32_t)(pre >> 32);
+                    state[ST_PREFIX + 2 * p + 1] = (int)(uint32_t)pre;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) state[ST_ANY] = s_any;
+        });
+    }
+    // ---- keep / drop, combine weights, kept counts (route_keep_k) ----
+    if (tid < MAXP) {
+        s_act[tid] = ld_state(&state[ST_ACTIVE + tid]);
+        s_pre[tid] = ((unsigned long long)(uint32_t)ld_state(&state[ST_PREFIX + 2 * tid]) << 32) | (uint32_t)ld_state(&state[ST_PREFIX + 2 * tid + 1]);
+    }
+    if (tid < 2 * MAXE) { s_kept[tid] = 0; s_cnt[tid] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int p = get_p(i);
+        if (p < 0) continue;
+        const long a = pair_of(i);
+        const long tok = a >> 1;
+        const long ts = tok >= Nsrc ? tok - Nsrc : tok;
+        const int act = s_act[p];
+        bool keep = true;
+        if (act == -1) keep = false;
+        else if (act > 0) keep = composite(kk[i], (uint32_t)tok, tie_xor) >= s_pre[p];
+        comb_w[a] = keep ? gate[2 * ts + (a & 1)] : 0.f;
+        if (tok >= Nsrc && act > 0) {
+            const bool keep_orig = composite(kk[i], (uint32_t)ts, tie_xor) >= s_pre[p];
+            if (keep_orig != keep) state[ST_SPLIT] = 1;
+        }
+        if (!(keep && tok < Nsrc)) set_p(i, -1);                  // from here on: p >= 0 marks a pair that gets an expert slot
+        else atomicAdd(&s_kept[(tok >= gsplit ? MAXE : 0) + (p & (MAXE - 1))], 1);
+    }
+    __syncthreads();
+    if (tid < 2 * MAXE && s_kept[tid]) atomicAdd(&state[ST_KEPT + tid], s_kept[tid]);
+    grid_sync(bar, nwg, &s_last, &s_gen, [&] {
+        // slot ranges + tile map (route_plan_k) by the last workgroup to arrive
+        if (tid == 0) {
+            int off = 0;
+            for (int g = 0; g < 2; ++g) {
+                int nt = 0;
+                for (int e = 0; e < E; ++e) {
+                    s_off[g * MAXE + e] = off;
+                    s_t0[g][e] = nt;
+                    state[ST_OFF + g * MAXE + e] = off;
+                    const int cnt = ld_state(&state[ST_KEPT + g * MAXE + e]);
+                    off += cnt;
+                    nt += (cnt + TILE_ROWS - 1) / TILE_ROWS;
+                }
+                for (int e = E; e < MAXE; ++e) { s_off[g * MAXE + e] = off; state[ST_OFF + g * MAXE + e] = off; }
+                s_t0[g][E] = nt;
+                state[ST_NTILES + g] = min(nt, max_tiles);
+            }
+            s_off[2 * MAXE] = off;
+            state[ST_OFF + 2 * MAXE] = off;
+        }
+        __syncthreads();
+        for (int g = 0; g < 2; ++g)
+            for (int e = 0; e < E; ++e) {
+                const int ve = g * MAXE + e, t1 = min(s_t0[g][e + 1], max_tiles);
+                for (int t = s_t0[g][e] + tid; t < t1; t += 256) {
+                    const int r = (t - s_t0[g][e]) * TILE_ROWS;
+                    tile_group[g * max_tiles + t] = e;
+                    tile_row0[g * max_tiles + t] = s_off[ve] + r;
+                    tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
+                }
+            }
+    });
+    // ---- compaction (route_fill_k): workgroup-local cursors, one global reservation per (workgroup, expert) ----
+    int lp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int p = get_p(i);
+        lp[i] = 0;
+        if (p < 0) continue;
+        const int le = ((pair_of(i) >> 1) >= gsplit ? MAXE : 0) + (p & (MAXE - 1));
+        lp[i] = atomicAdd(&s_cnt[le], 1);
+    }
+    __syncthreads();
+    if (tid < 2 * MAXE && s_cnt[tid]) s_base[tid] = ld_state(&state[ST_OFF + tid]) + atomicAdd(&state[ST_FILL + tid], s_cnt[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int p = get_p(i);
+        if (p < 0) continue;
+        const long a = pair_of(i);
+        const int le = ((a >> 1) >= gsplit ? MAXE : 0) + (p & (MAXE - 1));
+        const int slot = s_base[le] + lp[i];
+        src_row[slot] = (int)(a >> 1);
+        dst_row[slot] = (int)a;
     }
 }
 
@@ -652,6 +931,11 @@ static long route_small_pairs() {
 
 size_t mc_route_state_ints(int) { return ST_TOTAL; }
 bool mc_route_is_small(long N) { return 2 * N <= route_small_pairs(); }
+bool mc_route_cleans_counts(const RouteBufs& rb, long N) {
+    return 2 * N <= (rb.small_pairs >= 0 ? rb.small_pairs : route_small_pairs()) || (rb.coop && 2 * N <= 256L * 256 * COOP_PER);
+}
+size_t mc_route_barrier_offset() { return ST_BAR; }
+size_t mc_route_barrier_ints() { return 17 * 32; }
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
 const int* mc_route_split_flag_ptr(const RouteBufs& rb) { return rb.state + ST_SPLIT; }
 
@@ -675,7 +959,7 @@ int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* lo
 int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBufs rb, hipStream_t s) {
     MC_REQUIRE(Nsrc == N || 2 * Nsrc == N, "route: Nsrc=%ld must be N or N/2 (N=%ld)", Nsrc, N);
     MC_REQUIRE(Nsrc == N || rb.tie_xor == 0xFFFFFFFFu, "route: the twin mode needs the stable tie order (a twin must rank right behind its original)");
-    if (2 * N <= route_small_pairs()) {
+    if (2 * N <= (rb.small_pairs >= 0 ? rb.small_pairs : route_small_pairs())) {
 #define MC_ROUTE_SMALL(KERNEL)                                                                                                       \
     hipLaunchKernelGGL(KERNEL, dim3(1), dim3(SMALL_THREADS), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity,   \
                        (int)(N / Nsrc), rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows,        \
@@ -684,6 +968,14 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
         else if (rb.reg_kernel && 2 * N <= 20L * SMALL_THREADS) MC_ROUTE_SMALL(route_small_k<20>);      // (25 registers spill to scratch: still -4 % per step at B=2 vs the streaming form)
         else MC_ROUTE_SMALL(route_small_stream_k);
 #undef MC_ROUTE_SMALL
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
+    if (rb.coop && 2 * N <= 256L * 256 * COOP_PER) {
+        const int nwg = cdiv(2 * N, 256L * COOP_PER);
+        hipLaunchKernelGGL(route_coop_k, dim3(nwg), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity, (int)(N / Nsrc),
+                           rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows, rb.max_tiles, rb.tie_xor,
+                           N <= 65536 ? 1 : 0);
         MC_LAUNCH_CHECK();
         return MC_OK;
     }

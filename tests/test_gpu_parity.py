@@ -1360,6 +1360,55 @@ def test_register_routing_kernel_equals_the_streaming_form(regime, B, monkeypatc
     nm.close()
 
 
+@pytest.mark.parametrize('regime,B', [('random_scores', 3), ('exact_ties', 3), ('tiny_capacity', 9), ('reverse_ties', 3),
+                                      ('random_scores', 9), ('exact_ties', 9)])
+def test_cooperative_routing_kernel_equals_the_launch_sequence(regime, B, monkeypatch):
+    """route_coop_k (the routing of a layer as ONE launch with grid barriers: what batches above 32768 pairs run) against
+    the 12-launch sequence it replaces (MC_ROUTE_COOP=0), both forced onto the small config (MC_ROUTE_SMALL_CTX=0 switches the
+    one-workgroup kernels off): identical expert ids / keep flags and bit-identical denoiser output over random scores,
+    exact ties (all 8 radix passes), wholesale drops and the reverse tie order, on 2 and 5 workgroups."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = SMALL
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    if regime in ('exact_ties', 'reverse_ties'):
+        for l in range(dims['NL']):
+            pre = f'temporal_decoder_blocks.{l}.ca_block.motion_moe.model.gates.0.cosine_projector.'
+            sd[pre + 'weight'] = torch.zeros_like(sd[pre + 'weight'])
+            sd[pre + 'bias'] = torch.randn(sd[pre + 'bias'].shape, generator=torch.Generator().manual_seed(21 + l))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'], capacity_factor=0.3 if regime == 'tiny_capacity' else 1.5)
+    x, xf, mask = synth_inputs(dims, B, 24, seed=6, lengths=([24, 20, 7] * 3)[:B])
+    got = {}
+    monkeypatch.setenv('MC_ROUTE_SMALL_CTX', '0')
+    for coop in ('0', '1'):
+        monkeypatch.setenv('MC_ROUTE_COOP', coop)              # read when the context is created
+        ctx = nm.context(B, 24, max_steps=1)
+        if regime == 'reverse_ties':
+            ctx.set_tie_policy('reverse')
+        ctx.enable_capture()
+        ctx.set_timesteps([500])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        outs = [ctx.denoise(x.cuda(), 0).clone() for _ in range(3)]      # repeated: the barrier words and counts are left reusable
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        got[coop] = (outs[0], [ctx.routing(l) for l in range(dims['NL'])])
+        ctx.close()
+    monkeypatch.delenv('MC_ROUTE_SMALL_CTX')
+    ctx = nm.context(B, 24, max_steps=1)                       # and the one-workgroup kernels the small config normally runs
+    if regime == 'reverse_ties':
+        ctx.set_tie_policy('reverse')
+    ctx.set_timesteps([500])
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    small = ctx.denoise(x.cuda(), 0).clone()
+    ctx.close()
+    assert torch.equal(got['0'][0], got['1'][0]) and torch.equal(got['1'][0], small)
+    dropped = 0
+    for (ia, ka), (ib, kb) in zip(got['0'][1], got['1'][1]):
+        assert torch.equal(ia, ib) and torch.equal(ka, kb)
+        dropped += int((~ka).sum())
+    assert dropped > 0, 'the capacity cut never engaged'
+    nm.close()
+
+
 def test_control_branch_without_condition_cfg_vs_oracle():
     """condition_encode_cfg.condition_cfg=False: the control condition also drives the unconditional CFG half
     (controlnet.py forward_test: `c * cond_type` only when condition_cfg)."""
