@@ -553,16 +553,19 @@ __global__ __launch_bounds__(256, 2) void gemm_wp_k(GemmArgs g) {
 // Small-M variant (latency-bound launches of a few hundred rows): 64 x 64 tiles, each wave one 32 x 32 MFMA tile, so
 // the serial MFMA chain per k-tile is 16 instead of 64 instructions and a K = 1536 product takes ~30 us instead of
 // ~105 us per tile; 4x more workgroups fill the chip without splitting K (no partial sums, no reduction pass).
-// C = A W^T + bias (+ add[(r % add_mod)]) + R (also written dup_rows below), fp32, lda / ldw / ldc / ldr % 4 == 0,
-// N % 64 == 0, K % 32 == 0.
+// C = A W^T + bias (+ add[(r % add_mod)]) + R (also written dup_rows below), fp32, lda / ldw % 4 == 0, K % 32 == 0; any M, N
+// (float4 epilogue when N % 64 == 0 and the output rows are 16-byte aligned, guarded scalar stores otherwise).
 // ---------------------------------------------------------------------------------------
 constexpr int SM = 64, SN = 64, SRING = 4;
-// Operand staging: LDS-DMA into a ring of SRING stages, issued THREE k-tiles ahead.  With one wave per SIMD nothing else
-// hides a stall, and a k-tile is only 16 MFMAs (~0.4 us): W (9.4 MB for the FiLM Linear) does not fit an XCD's L2, so
-// the register double buffer this kernel used first (one tile of lead) waited for the MALL in every iteration.  The DMAs
-// are inline asm with hand-counted s_waitcnt (the compiler's own insertion drains every outstanding load in front of
-// an LDS access of the loop).  LDS image of a stage: unpadded [64][32] A rows then [64][32] W rows, 16-byte chunk c of
-// row r at position c ^ (r & 7) (gemm_dma_k's layout); accumulation order over k is unchanged: results are bit-identical.
+// Operand staging: LDS-DMA into a ring of SRING stages, issued THREE k-tiles ahead (no staging registers, no ds_write in
+// the loop).  The DMAs are inline asm with hand-counted s_waitcnt (the compiler's own insertion drains every outstanding
+// load in front of an LDS access of the loop).  LDS image of a stage: unpadded [64][32] A rows then [64][32] W rows, 16-byte
+// chunk c of row r at position c ^ (r & 7) (gemm_dma_k's layout); accumulation order over k is unchanged: results are
+// bit-identical to the register double buffer this kernel used first.  Measured: the SAME speed as that version (and
+// fragment double buffering across the barrier or DMA issue / LDS reads dealt out behind single MFMAs are 1-2 us SLOWER):
+// the bare 768-MFMA chain of a K = 1536 tile is 22.9 us (tools/clock_probe.hip), the loop sits within ~2 us of it, the
+// rest of a 34 us launch is the first operand round trip and the epilogue.  What does help: the epilogue operands
+// requested before the loop (-1.2 us) and, per launch, a tile width that evens out the work per CU (gemm_small16_k).
 template <bool VEC>     // VEC: N % 64 == 0 and 16-byte aligned output rows (float4 epilogue); else guarded scalar stores
 __global__ __launch_bounds__(256) void gemm_small_k(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[SRING * 2 * SM * BK];      // 4 x (8 + 8) KB
