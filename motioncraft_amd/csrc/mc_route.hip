@@ -925,7 +925,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void route_small_stream_k(const int*
 }  // namespace
 
 static long route_small_pairs() {
-    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 32768L; return x > 131072L ? 131072L : x; }();   // the one-workgroup kernels assume token indices < 2^16
+    static const long v = [] { const char* e = getenv("MC_ROUTE_SMALL"); const long x = e ? atol(e) : 20480L; return x > 131072L ? 131072L : x; }();   // the one-workgroup kernels assume token indices < 2^16; default = what fits the register kernels (beyond: route_coop_k; B=3: 97.5 -> 90.4 ms vs the streaming form)
     return v;
 }
 
