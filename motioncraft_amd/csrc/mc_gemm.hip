@@ -818,19 +818,25 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
                "gemm_small: operands beyond 4 GB (the DMA takes 32-bit byte offsets into A and W; this kernel is for a few thousand rows)");
     const bool vec = g.N % SN == 0 && g.ldc % 4 == 0 && g.c_col % 4 == 0 && g.c_gstride % 4 == 0 && (!g.R || (g.ldr % 4 == 0 && (g.r_gstride < 0 || g.r_gstride % 4 == 0))) &&
                      (!g.add || g.ld_add % 4 == 0) && g.b_gstride % 4 == 0;
-    // tile width: the launch is bound by the MFMA pipe of the busiest CU, i.e. by rounds of (up to 256) tiles x tile width;
-    // 64 x 64 unless a 64 x 48 or 64 x 96 grid needs strictly less (few-hundred-row launches: B = 1, 2 at 196 frames)
-    static const int force_nb = [] { const char* e = getenv("MC_SMALL_TILE_N"); return e ? atoi(e) : 0; }();
-    const int ng = groups > 0 ? groups : 1;
-    auto cost = [&](int nb) { return (long)cdiv((long)cdiv(g.M, SM) * cdiv(g.N, nb) * ng, 256) * nb; };
+    // Tile width per launch.  The launch is bound by the MFMA pipe of the busiest CU: n = ceil(tiles / 256) tiles land on it,
+    // two co-resident tiles share the pipe and finish in 1.45x (not 2x) the time of one, so its load is
+    // (1.45 floor(n / 2) + n mod 2) tile times; a 64 x 48 / 64 x 64 / 64 x 96 tile costs 23 / 30 / 41 units (the 32x32-MFMA
+    // kernel is ~15 % more efficient per flop than the 16x16 one).  Fitted on 392 B x 1536 x 1536 for B = 1 .. 16
+    // (tools/gemm_sweep.py): picks the measured-best width in every case, e.g. 48 at B = 1, 2, 7, 96 at B = 4, 5, 10, else 64.
     // (only widths that divide N: the decoder tail, N = 322, would be 7 x 48 instead of 6 x 64 tiles and 5 us faster at B=1,
     // but the 16x16 kernel accumulates k in another order, and that 1-ulp change of the decoded x0 was enough to move a
     // near-tie gate decision of the free-running full-size 50-step golden -- 0.63 off the reference's final pose with
     // per-step parity at 6e-6; the 64-wide kernel keeps the trajectory the golden test pins)
+    static const int force_nb = [] { const char* e = getenv("MC_SMALL_TILE_N"); return e ? atoi(e) : 0; }();
+    const int ng = groups > 0 ? groups : 1;
+    auto cost = [&](int nb, double unit) {
+        const long n = cdiv((long)cdiv(g.M, SM) * cdiv(g.N, nb) * ng, 256);
+        return (1.45 * (double)(n / 2) + (double)(n % 2)) * unit;
+    };
     int nb = SN;
-    if (g.N % 48 == 0 && cost(48) < cost(nb)) nb = 48;
-    if (g.N % 96 == 0 && cost(96) < cost(nb)) nb = 96;
-    if (nb == 48 && g.N % 96 == 0 && cost(96) == cost(48)) nb = 96;        // same cost: fewer, larger tiles
+    double best = cost(SN, 30.0);
+    if (g.N % 48 == 0 && cost(48, 23.0) < 0.97 * best) { nb = 48; best = cost(48, 23.0); }     // (3 % margin: near ties go to the more efficient kernel)
+    if (g.N % 96 == 0 && cost(96, 41.0) < 0.97 * best) { nb = 96; best = cost(96, 41.0); }
     if (force_nb == 64 || force_nb == 48 || force_nb == 96) nb = force_nb;
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
     const bool vec16 = vec && g.N % nb == 0;       // the float4 epilogue has no column guard
