@@ -96,6 +96,7 @@ struct mc_ctx {
     int graph_steps = 0;
     int prec = MC_PREC_F32;      // MFMA operand precision of the per-step GEMM-shaped kernels (mc_ctx_set_precision)
     long half_min_rows = 512;    // env MC_HALF_MIN_ROWS at context creation: see use_half()
+    int split_expert = 0;        // env MC_SPLIT_EXPERT at context creation: hidden-dimension split of the small-batch expert MLP (0 = load model)
     long gate_small_tokens = 12000;   // env MC_GATE_SMALL at context creation: up to this many tokens the gate runs as gate_small_k
     int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
     float* cap_w = nullptr;      // ... and combine weights (0 = dropped) of every layer
@@ -355,8 +356,20 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
             return mc_launch_mlp_h(MLP_EXPERT, m, hw->hi, hw->lo, hw2->hi, hw2->lo, c->prec == MC_PREC_F16X3, 1, max_tiles, s);
         // small batches (a few dozen tiles, each walking all hidden chunks serially): split the hidden dimension 4 ways,
         // partial FC2 sums in hbuf, reduced in a fixed order (rows of dropped pairs stay unwritten garbage: never read)
-        static const int S_env = [] { const char* e = getenv("MC_SPLIT_EXPERT"); return e ? atoi(e) : 4; }();
-        const int S = S_env;
+        // how many ways: the launch is bound by the busiest CU (n = ceil(workgroups / 256) of them land on it, two co-resident
+        // ones finish in 1.45x one -- the load model of mc_launch_gemm_small) times the hidden chunks per workgroup; ~2 Ntok / 128
+        // + E / 2 tiles are real.  4 ways except where 3 take a whole round off: B = 2 at 196 frames (620 -> 465 workgroups,
+        // 3 -> 2 rounds: 80.5 -> 77.7 ms per 50-step DDIM; at B = 1 the tile count straddles 256 / 3 and 3 ways lose 2 %).
+        int S = c->split_expert;                   // env MC_SPLIT_EXPERT at context creation (0: the model below)
+        if (S <= 0) {
+            const long tiles = 2 * Ntok / 128 + E / 2;
+            auto load = [&](int ways) {
+                const long n = cdiv(tiles * ways, 256);
+                return (1.45 * (double)(n / 2) + (double)(n % 2)) * (double)cdiv(hid / 32, ways);
+            };
+            S = 4;
+            if (hid / 32 >= 4 && load(3) < 0.92 * load(4) && tiles * 3 > 300) S = 3;     // (tiles * 3 <= 300: B = 1, see above)
+        }
         if (z == c->z && c->rows <= 2048 && S > 1 && hid / 32 >= S && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
             if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
@@ -745,6 +758,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     mc_ctx* c = new mc_ctx();
     if (const char* e = getenv("MC_HALF_MIN_ROWS")) c->half_min_rows = atol(e);      // (the tests lift it to run the fp16 kernels at their small sizes)
     if (const char* e = getenv("MC_GATE_SMALL")) c->gate_small_tokens = atol(e);
+    if (const char* e = getenv("MC_SPLIT_EXPERT")) c->split_expert = atoi(e);
     if (const char* e = getenv("MC_ROUTE_REG")) c->rb.reg_kernel = atoi(e) != 0;
     if (const char* e = getenv("MC_ROUTE_COOP")) c->rb.coop = atoi(e) != 0;
     if (const char* e = getenv("MC_ROUTE_SMALL_CTX")) c->rb.small_pairs = atol(e);

@@ -1034,6 +1034,31 @@ def test_text_to_motion_call_with_clip_features_through_the_reference_api():
     arch.model.release()
 
 
+def test_small_batch_expert_mlp_split_choices_agree(full_model, monkeypatch):
+    """Small batches split the hidden dimension of the fused expert MLP over workgroups (partial FC2 sums, fixed-order reduce);
+    the number of ways comes from a load model (3 at B = 2 x 196 frames: uneven 5 / 5 / 6 chunk shares, 4 elsewhere).  The
+    3-way and 4-way splits must route identically and agree to fp32 round-off on a full-size B = 2 step."""
+    sd, nm = full_model
+    B, T = 2, 196
+    x, xf, mask = synth_inputs(FULL, B, T, seed=31, lengths=[196, 150])
+    got = {}
+    for ways in ('0', '4', '2'):
+        monkeypatch.setenv('MC_SPLIT_EXPERT', ways)            # read when the context is created; 0 = the model (3 ways here)
+        ctx = nm.context(B, T, max_steps=1)
+        ctx.enable_capture()
+        ctx.set_timesteps([400])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out = ctx.denoise(x.cuda(), 0).clone()
+        got[ways] = (out, [ctx.routing(l) for l in range(FULL['NL'])])
+        ctx.close()
+    for ways in ('4', '2'):
+        for (ia, ka), (ib, kb) in zip(got['0'][1], got[ways][1]):
+            assert torch.equal(ia, ib) and torch.equal(ka, kb)
+        err = maxabs(got['0'][0], got[ways][0])
+        print(f'expert MLP split: model choice vs {ways} ways: {err:.2e}')
+        assert 0 < err <= 2e-5
+
+
 def test_fp16_modes_use_the_fp32_kernels_at_tiny_batches(monkeypatch):
     """Default policy (MC_HALF_MIN_ROWS unset = 512 residual rows): a B=1-sized context in the f16x3 mode runs the fp32
     small-batch kernels -- bit-identical to the f32 mode -- and the fp16 kernels once the limit is lifted."""
