@@ -96,6 +96,7 @@ struct mc_ctx {
     int graph_steps = 0;
     int prec = MC_PREC_F32;      // MFMA operand precision of the per-step GEMM-shaped kernels (mc_ctx_set_precision)
     long half_min_rows = 512;    // env MC_HALF_MIN_ROWS at context creation: see use_half()
+    int split_sffn = 0;          // env MC_SPLIT_SFFN at context creation: hidden-dimension split of the SFFN (0 = load model)
     int split_expert = 0;        // env MC_SPLIT_EXPERT at context creation: hidden-dimension split of the small-batch expert MLP (0 = load model)
     long gate_small_tokens = 12000;   // env MC_GATE_SMALL at context creation: up to this many tokens the gate runs as gate_small_k
     int* cap_idx = nullptr;      // [NL][2N] routing capture (tests): expert ids ...
@@ -291,6 +292,13 @@ int bind_half_weights(mc_ctx* c) {
 // (B=1 50-step DDIM: 68.3 ms on the fp16 kernels, 57.3 ms on the fp32 ones; from B=2 the fp16 kernels win).
 static bool use_half(const mc_ctx* c) { return c->prec != MC_PREC_F32 && c->rows > c->half_min_rows; }
 
+// residual rows up to which the fused MLPs split their hidden dimension over workgroups (which = 0 experts, 1 SFFN)
+static long split_rows(int which) {
+    static const long v[2] = {[] { const char* e = getenv("MC_SPLIT_ROWS_EXPERT"); return e ? atol(e) : 2048L; }(),
+                              [] { const char* e = getenv("MC_SPLIT_ROWS_SFFN"); return e ? atol(e) : 8192L; }()};
+    return v[which];
+}
+
 static long small_gemm_rows() {
     static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 6400L; }();
     return v;
@@ -370,7 +378,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
             S = 4;
             if (hid / 32 >= 4 && load(3) < 0.92 * load(4) && tiles * 3 > 300) S = 3;     // (tiles * 3 <= 300: B = 1, see above)
         }
-        if (z == c->z && c->rows <= 2048 && S > 1 && hid / 32 >= S && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
+        if (z == c->z && c->rows <= split_rows(0) && S > 1 && hid / 32 >= S && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
             if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
             return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s);
@@ -548,12 +556,26 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         m.X = hs + o; m.ldx = D; m.x_gstride = L;
         m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
         m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;
-        static const int S_env = [] { const char* e = getenv("MC_SPLIT_SFFN"); return e ? atoi(e) : 4; }();
-        const int S = S_env;
+        // hidden split of the part-wise FFNs (partial sums folded into the FiLM row kernel): ways by the load model of
+        // mc_launch_gemm_small plus ~2 chunk times of fixed cost per workgroup -- 4 ways up to B = 5 (and at B = 8: 184.5 -> 178.0 ms
+        // per 50-step DDIM), 2 at B = 6 and B = 16 (293.7 -> 287.5), none at B = 12 or beyond 8192 rows
+        int S = c->split_sffn;                     // env MC_SPLIT_SFFN at context creation (0: the model below)
+        if (S <= 0) {
+            S = 1;
+            if (nrows <= split_rows(1)) {
+                auto load = [&](int ways) {
+                    const long n = cdiv((long)cdiv(nrows, 128) * H * ways, 256);
+                    return (1.45 * (double)(n / 2) + (double)(n % 2)) * ((double)cdiv(F / 32, ways) + 2.0);
+                };
+                double best = load(1);
+                for (int ways = 2; ways <= 4; ways *= 2)
+                    if (F / 32 >= ways && load(ways) <= 1.03 * best) { S = ways; best = load(ways) < best ? load(ways) : best; }
+            }
+        }
         if (use_half(c) && w.h_w1.hi && w.h_w2.hi) {
             if ((r = mc_launch_mlp_h(MLP_PARTS, m, w.h_w1.hi, w.h_w1.lo, w.h_w2.hi, w.h_w2.lo, c->prec == MC_PREC_F16X3, H, 0, s))) return r;
         } else
-        if (nrows <= 2048 && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
+        if (nrows <= split_rows(1) && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = nrows * D;
             if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
             if (mc_chain_enabled(12)) z2_parts = S;          // the FiLM row kernel adds the partial planes up itself
@@ -759,6 +781,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     if (const char* e = getenv("MC_HALF_MIN_ROWS")) c->half_min_rows = atol(e);      // (the tests lift it to run the fp16 kernels at their small sizes)
     if (const char* e = getenv("MC_GATE_SMALL")) c->gate_small_tokens = atol(e);
     if (const char* e = getenv("MC_SPLIT_EXPERT")) c->split_expert = atoi(e);
+    if (const char* e = getenv("MC_SPLIT_SFFN")) c->split_sffn = atoi(e);
     if (const char* e = getenv("MC_ROUTE_REG")) c->rb.reg_kernel = atoi(e) != 0;
     if (const char* e = getenv("MC_ROUTE_COOP")) c->rb.coop = atoi(e) != 0;
     if (const char* e = getenv("MC_ROUTE_SMALL_CTX")) c->rb.small_pairs = atol(e);
