@@ -378,7 +378,8 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
             S = 4;
             if (hid / 32 >= 4 && load(3) < 0.92 * load(4) && tiles * 3 > 300) S = 3;     // (tiles * 3 <= 300: B = 1, see above)
         }
-        if (z == c->z && c->rows <= split_rows(0) && S > 1 && hid / 32 >= S && c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
+        if (z == c->z && c->rows <= split_rows(0) && c->N <= 65536 && S > 1 && hid / 32 >= S &&      // (c->N <= 65536: the one-stream schedule, one user of hbuf)
+            c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
             if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
             return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s);
@@ -562,7 +563,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         int S = c->split_sffn;                     // env MC_SPLIT_SFFN at context creation (0: the model below)
         if (S <= 0) {
             S = 1;
-            if (nrows <= split_rows(1)) {
+            if (nrows <= split_rows(1) && nrows == c->rows) {      // (one launch over the whole batch: the partial planes live in the one hbuf -- not in the two-stream schedule)
                 auto load = [&](int ways) {
                     const long n = cdiv((long)cdiv(nrows, 128) * H * ways, 256);
                     return (1.45 * (double)(n / 2) + (double)(n % 2)) * ((double)cdiv(F / 32, ways) + 2.0);
@@ -575,7 +576,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         if (use_half(c) && w.h_w1.hi && w.h_w2.hi) {
             if ((r = mc_launch_mlp_h(MLP_PARTS, m, w.h_w1.hi, w.h_w1.lo, w.h_w2.hi, w.h_w2.lo, c->prec == MC_PREC_F16X3, H, 0, s))) return r;
         } else
-        if (nrows <= split_rows(1) && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
+        if (nrows <= split_rows(1) && nrows == c->rows && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = nrows * D;
             if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
             if (mc_chain_enabled(12)) z2_parts = S;          // the FiLM row kernel adds the partial planes up itself

@@ -364,8 +364,10 @@ def test_full_size_50_step_ddim_vs_reference_golden(full_model):
     ctx.close()
 
 
-def test_baseline_batch_64_single_step_vs_oracle(full_model):
-    """BASELINE.json configs[1] size (B=64, T=196, mixed lengths): one denoiser call vs the CPU oracle.
+@pytest.mark.parametrize('B', [64, 16])
+def test_baseline_batch_64_single_step_vs_oracle(full_model, B):
+    """BASELINE.json configs[1] size (B=64, T=196, mixed lengths): one denoiser call vs the CPU oracle.  (B=16: the smallest
+    batches of the two-stream schedule -- sample groups of 3136 rows, where the small-batch kernel choices end.)
 
     At N = 301 056 tokens neighbouring importance scores at an expert's capacity boundary are ~1e-6
     apart -- the size of fp32 rounding differences between ANY two implementations of the gate
@@ -378,7 +380,7 @@ def test_baseline_batch_64_single_step_vs_oracle(full_model):
           matches within the north-star tolerance of 1e-3."""
     from oracle import stmogen_oracle as O
     sd, nm = full_model
-    B, T = 64, 196
+    T = 196
     g = torch.Generator().manual_seed(5)
     lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
     x_T, xf, mask = synth_inputs(FULL, B, T, seed=33, lengths=lengths)
