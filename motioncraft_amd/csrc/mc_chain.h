@@ -27,7 +27,13 @@ struct MlpArgs {
     // Y + z * y_sstride (b2 added by split 0 only); the caller reduces the partials in a fixed order
     int nsplit = 1;
     long y_sstride = 0;
+    // MLP_EXPERT, nsplit == 4: the kernel picks 3 or 4 ways itself from the REAL tile count (mc_mlp_dyn_ways) -- with 3 ways
+    // a B=1 layer's ~80 tiles are 240 workgroups, one per CU, instead of 320 (two rounds on 64 CUs); the tile count is
+    // data-dependent and known on the device only.  The launch is then 1-D: workgroup b = (slice b / tiles, tile b % tiles).
+    int dyn_split = 0;
 };
+// ways a small-batch expert launch splits its hidden dimension, from the number of real tiles (host + device)
+__host__ __device__ inline int mc_mlp_dyn_ways(int real_tiles) { return (real_tiles * 4 <= 256 || real_tiles * 3 > 256) ? 4 : 3; }
 
 struct GateArgs {
     const float* X = nullptr;      // token rows [N][ldx] (the residual stream viewed per part)

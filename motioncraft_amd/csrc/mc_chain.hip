@@ -132,10 +132,18 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int grp, row0, nrows;
+    int zs = (int)blockIdx.z, ns = g.nsplit;              // hidden slice of this workgroup, number of slices
     if constexpr (MODE == MLP_EXPERT) {
         const int real = *g.num_tiles;
-        if ((int)blockIdx.x >= real) return;
-        const int t = xcd_remap(blockIdx.x, real);
+        int bt = (int)blockIdx.x;
+        if (g.dyn_split) {                                    // 1-D launch: ways chosen from the real tile count
+            ns = mc_mlp_dyn_ways(real);
+            zs = bt / max(real, 1);
+            bt -= zs * real;
+            if (zs >= ns) return;
+        }
+        if (bt >= real) return;
+        const int t = xcd_remap(bt, real);
         grp = g.tile_group[t];
         row0 = g.tile_row0[t];
         nrows = g.tile_nrows[t];
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
 
     // hidden chunks [hc0, nch) of this workgroup (all of them unless the hidden dimension is split over blockIdx.z)
     const int nch_all = g.hidden / HC;
-    const int hc0 = (int)((long)nch_all * blockIdx.z / g.nsplit), nch = (int)((long)nch_all * (blockIdx.z + 1) / g.nsplit);
+    const int hc0 = (int)((long)nch_all * zs / ns), nch = (int)((long)nch_all * (zs + 1) / ns);
     S1 s1;
     S2 s2;
     s1.fetch(W1, L, hc0 * HC, 0, tid);
@@ -218,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
     if (!rok) return;
     long drow = row0 + r;
     if constexpr (MODE == MLP_EXPERT) drow = g.dst_row[row0 + r];
-    float* yrow = g.Y + (long)blockIdx.z * g.y_sstride + (long)grp * g.y_gstride + drow * g.ldy;
-    const bool add_b2 = blockIdx.z == 0;
+    float* yrow = g.Y + (long)zs * g.y_sstride + (long)grp * g.y_gstride + drow * g.ldy;
+    const bool add_b2 = zs == 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -561,7 +569,7 @@ int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 24567;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel, 12 small batches: the SFFN's split-hidden partial sums are added up by the FiLM row kernel instead of a reduce launch (the same fold into the 4 column slices of rowchain_k was measured slower: B=1 +2.6 ms), 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream
+        v = e ? atoi(e) : 32759;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel, 12 small batches: the SFFN's split-hidden partial sums are added up by the FiLM row kernel instead of a reduce launch (the same fold into the 4 column slices of rowchain_k was measured slower: B=1 +2.6 ms), 13 B=1 sizes: the expert MLP picks 3 or 4 hidden slices on the device from the real tile count, 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream
     }
     return v;
 }
@@ -579,7 +587,8 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
     MC_REQUIRE(g.nsplit >= 1 && g.hidden / 32 >= g.nsplit, "fused mlp: %d hidden chunks cannot be split %d ways", g.hidden / 32, g.nsplit);
     if (mode == MLP_EXPERT) {
         if (max_tiles <= 0) return MC_OK;
-        grid = dim3(max_tiles, 1, g.nsplit);
+        MC_REQUIRE(!g.dyn_split || g.nsplit == 4, "fused mlp: dyn_split launches are sized for 4 ways");
+        grid = g.dyn_split ? dim3(max_tiles * 4, 1, 1) : dim3(max_tiles, 1, g.nsplit);
     } else {
         if (g.M <= 0) return MC_OK;
         grid = dim3(cdiv(g.M, 128), groups, g.nsplit);

@@ -79,7 +79,7 @@ struct SeedArgs {
 int mc_launch_pad_rows_seeded(float* X, float* Y, long rows, int C, int Cp, const SeedArgs& sd, hipStream_t s);
 // out[M][N] (contiguous) = sum_s part[s][M][N] + bias[N] + res[M][N]
 int mc_launch_splitk_reduce(const float* part, int S, long M, int N, const float* bias, const float* res, float* out,
-                            hipStream_t s);
+                            hipStream_t s, const int* dyn_tiles = nullptr);   // dyn_tiles: S = mc_mlp_dyn_ways(*dyn_tiles) on the device
 int mc_launch_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s);
 // out0 = a x0 + b y0 and out1 = a x1 + b y1 in one launch; table != null: (a, b) = table[*step_ptr].{text_coef, none_coef}
 int mc_launch_axpby_pair(const float* x0, const float* y0, float* out0, const float* x1, const float* y1, float* out1, float a, float b,

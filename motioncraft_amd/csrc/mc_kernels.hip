@@ -3,6 +3,7 @@
 // All loads/stores are 16 B per lane, rows are reduced with wavefront shuffles (wave = 64).
 #include "mc_common.h"
 #include "mc_kernels.h"
+#include "mc_chain.h"
 
 namespace {
 
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) void pad_rows_seeded_k(float* __restrict__ X, 
 // split-K reduction: out[r][n] = sum_s part[s][r][n] (s ascending: deterministic) + bias[n] + res[r][n]
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ part, int S, long MN, int N,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, const int* __restrict__ dyn_tiles) {
+    if (dyn_tiles) S = mc_mlp_dyn_ways(*dyn_tiles);       // the producer chose its ways on the device (MlpArgs::dyn_split)
     const long n4 = MN >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * i);
@@ -456,13 +458,13 @@ int mc_launch_pad_rows_seeded(float* X, float* Y, long rows, int C, int Cp, cons
 }
 
 int mc_launch_splitk_reduce(const float* part, int S, long M, int N, const float* bias, const float* res, float* out,
-                            hipStream_t s) {
+                            hipStream_t s, const int* dyn_tiles) {
     MC_REQUIRE(N % 4 == 0 && S >= 1, "split-K reduce: N=%d S=%d", N, S);
     const long MN = M * N;
     if (MN <= 0) return MC_OK;
     int blocks = cdiv(MN / 4, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, s, part, S, MN, N, bias, res, out);
+    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, s, part, S, MN, N, bias, res, out, dyn_tiles);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -381,8 +381,12 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         if (z == c->z && c->rows <= split_rows(0) && c->N <= 65536 && S > 1 && hid / 32 >= S &&      // (c->N <= 65536: the one-stream schedule, one user of hbuf)
             c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
+            // B = 1 sizes (the estimated tile count straddles 256 / 3): 3 or 4 ways decided on the device from the real count
+            const bool dyn = S == 4 && c->split_expert == 0 && (2 * Ntok / 128 + E / 2) * 3 <= 300 && mc_chain_enabled(13);
+            m.dyn_split = dyn ? 1 : 0;
             if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
-            return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s);
+            return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s,
+                                           dyn ? mc_route_num_tiles_ptr(c->rb, group) : nullptr);
         }
         return mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s);
     }
