@@ -320,8 +320,11 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
             }
         }
     };
-    prefetch_q(0);
-    for (int tc = 0; tc < ntc; ++tc) {
+    // (LSPLIT launches deal the 32-row output chunks over blockIdx.z: both workgroups of a (sample, part, slice) build the
+    // same A2 tile, each projects half of the query rows)
+    const int tc0 = LSPLIT ? (int)blockIdx.z : 0, tcs = LSPLIT ? (int)gridDim.z : 1;
+    prefetch_q(tc0);
+    for (int tc = tc0; tc < ntc; tc += tcs) {
         {
             const int t = tc * 32 + qrow;
             float mx = -3e38f;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
             }
         }
         __syncthreads();
-        if (tc + 1 < ntc) prefetch_q(tc + 1);
+        if (tc + tcs < ntc) prefetch_q(tc + tcs);
         __builtin_amdgcn_sched_barrier(0);
         if (mm_active) {
             f32x16 o;
@@ -421,6 +424,7 @@ int mc_launch_temporal(const float* mf, const float* tf, const float* mask, floa
     static const long lsplit_max = [] { const char* e = getenv("MC_TEMPORAL_SPLIT"); return e ? atol(e) : 96L; }();
     if (L >= 64 && (long)nb * H <= lsplit_max) {
         grid.y = L / 32;
+        grid.z = (long)nb * H * (L / 32) * 2 <= 256 ? 2 : 1;      // still one workgroup per CU: the output rows halved as well (B=1: 96 -> 192 workgroups)
         if (L == 128) hipLaunchKernelGGL((temporal_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
         else hipLaunchKernelGGL((temporal_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
         MC_LAUNCH_CHECK();
