@@ -120,6 +120,14 @@ int mc_model_finalize(mc_model* m);
 int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps, mc_ctx** out);
 void mc_ctx_destroy(mc_ctx* c);
 int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
+/* Synchronises `stream` and reports a sticky device-side error of the context (MC_ERR_STATE): today the one error a kernel can
+ * raise is the grid-barrier time-out of the cooperative routing kernel (route_coop_k; its grid is reserved out of the device's
+ * resident-workgroup capacity per context at mc_ctx_create, so only barrier kernels of ANOTHER process can starve it).  The
+ * Python sampler loops call it once after the last step -- the reference has no counterpart (its routing is tutel's, on the
+ * framework's stream: st_attention.py:28-45). */
+int mc_ctx_check(mc_ctx* c, void* stream);
+/* 1 if this context routes its layers with the one-launch cooperative kernel (0: one-workgroup kernels or the launch sequence) */
+int mc_ctx_uses_coop_routing(const mc_ctx* c);
 /* tests: keep the routing decisions (expert ids, combine weights; 0 = dropped) of every layer of the
  * last mc_denoise call in buffers "cap_idx" / "cap_w" */
 int mc_ctx_enable_capture(mc_ctx* c);

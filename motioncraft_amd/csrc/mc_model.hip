@@ -75,6 +75,7 @@ struct mc_ctx {
     int* t_orig;
     float *te, *e1, *emb, *semb, *ss;   // ss: [NL][2][maxS][2D]
     RouteBufs rb;
+    int coop_reserved = 0;      // resident route_coop_k workgroups this context holds (mc_route_coop_reserve)
     bool have_cond = false;
     // side stream: the temporal branch of STMA needs only the motion-MoE output, so it runs beside
     // (LN + qkv -> body attention) of the same layer (fork after the MoE projection, join before proj_out)
@@ -870,6 +871,17 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->rb.tile_nrows, 2 * c->rb.max_tiles);
     WS(c->rb.state, mc_route_state_ints(g.num_experts));
     MC_HIP(hipMemset(c->rb.state + mc_route_barrier_offset(), 0, mc_route_barrier_ints() * sizeof(int)));      // grid-barrier words of the cooperative routing kernel
+    // the cooperative routing kernel needs its whole grid resident: reserve it out of what the device holds, or run the
+    // launch sequence instead (no env var needed: a fifth concurrent B = 64 context, or a CPX partition, simply falls back)
+    if (c->rb.coop) {
+        const long small = c->rb.small_pairs >= 0 ? c->rb.small_pairs : -1;
+        const int nwg = mc_route_coop_wgs(c->N);
+        const bool one_wg = small >= 0 ? 2 * c->N <= small : mc_route_is_small(c->N);
+        if (nwg > 0 && !one_wg) {
+            if (mc_route_coop_reserve(nwg)) c->coop_reserved = nwg;
+            else c->rb.coop = false;
+        }
+    }
 #undef WS
     *out = c;
     return MC_OK;
@@ -880,6 +892,7 @@ static void graph_release(mc_ctx* c);
 void mc_ctx_destroy(mc_ctx* c) {
     if (!c) return;
     graph_release(c);
+    if (c->coop_reserved) { mc_route_coop_release(c->coop_reserved); c->coop_reserved = 0; }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (int k = 1; k < 3; ++k)
         if (c->parts[k]) { (void)hipStreamSynchronize(c->parts[k]); (void)hipStreamDestroy(c->parts[k]); }
@@ -892,6 +905,22 @@ void mc_ctx_destroy(mc_ctx* c) {
 }
 
 int64_t mc_ctx_workspace_bytes(const mc_ctx* c) { return c ? c->bytes : 0; }
+
+int mc_ctx_check(mc_ctx* c, void* stream) {
+    MC_REQUIRE(c, "null context");
+    int flag = 0;
+    MC_HIP(hipMemcpyAsync(&flag, c->rb.state + mc_route_error_offset(), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (flag != 0) {
+        mc_set_error("the cooperative routing kernel's grid barrier timed out (its workgroups were not all resident: another process "
+                     "is holding the GPU with barrier kernels of its own); the results of this context are invalid -- destroy it and "
+                     "create the context with MC_ROUTE_COOP=0");
+        return MC_ERR_STATE;
+    }
+    return MC_OK;
+}
+
+int mc_ctx_uses_coop_routing(const mc_ctx* c) { return c && c->coop_reserved > 0 ? 1 : 0; }
 
 int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy) {
     MC_REQUIRE(c, "null context");

@@ -335,8 +335,13 @@ __device__ __forceinline__ int ld_state(const int* p) { return __hip_atomic_load
 // acquire fence after the wait.  Every word sits in its own 128-byte line: bar[0] top, bar[32 (1 + g)] group counter,
 // bar[32 (9 + g)] group generation.
 constexpr int BAR_STRIDE = 32, BAR_INTS = 17 * BAR_STRIDE;
+// Returns false if the barrier timed out (the grid was not fully resident -- see mc_route_coop_reserve, which keeps that from
+// happening inside one process; another PROCESS filling the GPU with barrier kernels of its own is the case left): the
+// sticky error word bar[1] is raised, every workgroup leaves the kernel, and the host reports it (mc_ctx_check); the results of
+// that routing call are invalid.  No trap: the process and the other contexts of the GPU keep running.
+constexpr unsigned BAR_SPIN_LIMIT = 1u << 23;       // x s_sleep(1): a few seconds
 template <class F>
-__device__ __forceinline__ void grid_sync(int* bar, int nwg, int* s_last, int* s_gen, F&& last_hook) {
+__device__ __forceinline__ bool grid_sync(int* bar, int nwg, int* s_last, int* s_gen, F&& last_hook) {
     const int grp = (int)(blockIdx.x & 7), ngrp = nwg < 8 ? nwg : 8, members = (nwg - grp + 7) >> 3;
     int* cnt = bar + BAR_STRIDE * (1 + grp);
     int* gen = bar + BAR_STRIDE * (9 + grp);
@@ -363,16 +368,21 @@ __device__ __forceinline__ void grid_sync(int* bar, int nwg, int* s_last, int* s
         __syncthreads();
         if ((int)threadIdx.x < ngrp) __hip_atomic_fetch_add(bar + BAR_STRIDE * (9 + (int)threadIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (threadIdx.x == 0) {
-        // bounded: if the grid is not fully resident (more than three of these kernels in flight on one GPU at once) the wait
-        // would never end -- a few seconds of polling, then the kernel aborts loudly instead of hanging the device
         unsigned spins = 0;
+        bool timed_out = false;
         while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == *s_gen) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 23)) __builtin_trap();
+            if (++spins > BAR_SPIN_LIMIT || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { timed_out = true; break; }
         }
-        __threadfence();
+        if (timed_out) {
+            __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky; the other waiters see it and leave too
+            *s_last = -1;
+        } else {
+            __threadfence();
+        }
     }
     __syncthreads();
+    return *s_last >= 0;
 }
 
 constexpr int COOP_PER = 10;
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx,
         if (tid < MAXP) state[ST_CNT + tid] = 0;
         if (tid == 0) state[ST_ANY] = s_any;
     }
-    grid_sync(bar, nwg, &s_last, &s_gen, [] {});
+    if (!grid_sync(bar, nwg, &s_last, &s_gen, [] {})) return;
     // ---- radix select, one byte per pass ----
     for (int pass = 0; pass < 8; ++pass) {
         if (ld_state(&state[ST_ANY]) == 0) break;                 // (uniform: written before the barrier every workgroup has passed)
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx,
         __syncthreads();
         for (int i = tid; i < MAXP * 256; i += 256)
             if (h[i]) atomicAdd(&state[ST_HIST + i], h[i]);
-        grid_sync(bar, nwg, &s_last, &s_gen, [&] {
+        const bool ok = grid_sync(bar, nwg, &s_last, &s_gen, [&] {
             // the last workgroup to arrive picks, per selecting problem, the bin that holds the rank-th largest key
             if (tid == 0) s_any = 0;
             __syncthreads();
@@ -505,6 +515,7 @@ __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx,
             __syncthreads();
             if (tid == 0) state[ST_ANY] = s_any;
         });
+        if (!ok) return;
     }
     // ---- keep / drop, combine weights, kept counts (route_keep_k) ----
     if (tid < MAXP) {
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx,
     }
     __syncthreads();
     if (tid < 2 * MAXE && s_kept[tid]) atomicAdd(&state[ST_KEPT + tid], s_kept[tid]);
-    grid_sync(bar, nwg, &s_last, &s_gen, [&] {
+    if (!grid_sync(bar, nwg, &s_last, &s_gen, [&] {
         // slot ranges + tile map (route_plan_k) by the last workgroup to arrive
         if (tid == 0) {
             int off = 0;
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx,
                     tile_nrows[g * max_tiles + t] = min(TILE_ROWS, s_off[ve + 1] - s_off[ve] - r);
                 }
             }
-    });
+    })) return;
     // ---- compaction (route_fill_k): workgroup-local cursors, one global reservation per (workgroup, expert) ----
     int lp[PER];
 #pragma unroll
@@ -936,6 +947,47 @@ bool mc_route_cleans_counts(const RouteBufs& rb, long N) {
 }
 size_t mc_route_barrier_offset() { return ST_BAR; }
 size_t mc_route_barrier_ints() { return 17 * 32; }
+size_t mc_route_error_offset() { return ST_BAR + 1; }
+
+// ---- admission of the cooperative routing kernel ---------------------------------------------------------------
+// route_coop_k meets at a hand-rolled grid barrier, so ALL its workgroups have to be resident at once.  A context launches at
+// most one such kernel at a time (stream order), so the library reserves a context's workgroups out of what the device can
+// hold -- occupancy query x compute units of the VISIBLE device (a CPX partition reports its own 32 CUs) -- when the context
+// is created, and a context that does not fit runs the launch sequence instead (RouteBufs::coop = false).  Other kernels in
+// flight only delay the barrier (they finish); only barrier kernels the library does not know of (another process on the same
+// GPU) can still starve it, and then the barrier times out into an error flag (grid_sync) instead of hanging.
+#include <atomic>
+static std::atomic<int> g_coop_reserved[64];
+int mc_route_coop_wgs(long N) { return (2 * N <= 256L * 256 * COOP_PER) ? cdiv(2 * N, 256L * COOP_PER) : 0; }
+int mc_route_coop_slots() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cached[dev].load();
+    if (v > 0) return v;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, route_coop_k, 256, 0) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (per_cu > 8) per_cu = 8;                    // (hardware admits at most 8 256-thread blocks per CU: MI355X_MICROARCH.md, residency)
+    v = per_cu * prop.multiProcessorCount;
+    if (const char* e = getenv("MC_ROUTE_COOP_SLOTS")) v = atoi(e) > 0 ? atoi(e) : v;      // (tests: a small capacity exercises the fallback)
+    cached[dev].store(v);
+    return v;
+}
+bool mc_route_coop_reserve(int nwg) {
+    int dev = 0;
+    if (nwg <= 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const int slots = mc_route_coop_slots();
+    int cur = g_coop_reserved[dev].load();
+    while (cur + nwg <= slots)
+        if (g_coop_reserved[dev].compare_exchange_weak(cur, cur + nwg)) return true;
+    return false;
+}
+void mc_route_coop_release(int nwg) {
+    int dev = 0;
+    if (nwg > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) g_coop_reserved[dev].fetch_sub(nwg);
+}
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
 const int* mc_route_split_flag_ptr(const RouteBufs& rb) { return rb.state + ST_SPLIT; }
 

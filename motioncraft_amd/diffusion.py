@@ -260,6 +260,8 @@ class GaussianDiffusion:
                     ctx.graph_step(i)
                 img.copy_(st['x'])
             torch.cuda.current_stream(device).wait_stream(side)
+            if getattr(ctx, 'uses_coop_routing', False):
+                ctx.check()
             return img
         for i, denoise in plan:
             if not denoise:                                                   # _undo (:429-435)
@@ -297,6 +299,8 @@ class GaussianDiffusion:
             img, nxt = nxt, img
             if trajectory is not None:
                 trajectory.append((i, img.clone(), x0.clone()))
+        if getattr(ctx, 'uses_coop_routing', False):
+            ctx.check()            # one sync after the last step: a timed-out grid barrier of the routing kernel raises here
         return img
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,

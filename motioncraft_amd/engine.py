@@ -83,8 +83,18 @@ class NativeContext:
     def workspace_bytes(self):
         return int(self.lib.mc_ctx_workspace_bytes(self.handle))
 
+    def check(self):
+        """Synchronise the current stream and raise if a kernel of this context flagged an error (the cooperative routing
+        kernel's bounded grid barrier); the sampler loops call it once after the last step."""
+        _lib.check(self.lib.mc_ctx_check(self.handle, _stream()), 'mc_ctx_check')
+
+    @property
+    def uses_coop_routing(self):
+        return bool(self.lib.mc_ctx_uses_coop_routing(self.handle))
+
     def enable_capture(self):
         """Keep every layer's routing decisions of the last denoise call (tests)."""
+        self._drop_graph()
         _lib.check(self.lib.mc_ctx_enable_capture(self.handle), 'mc_ctx_enable_capture')
 
     def _drop_graph(self):
@@ -104,6 +114,8 @@ class NativeContext:
         """'stable' (default) or 'reverse': order of equal-importance tokens at a capacity cut (tutel boundary, a16).
         Call before set_condition."""
         code = {'stable': 0, 'reverse': 1}[policy]
+        self._drop_graph()             # a captured graph has the tie key and the twin-mode launch sequence baked in
+        self._keep = []                # the library forgets the condition: set_condition must follow
         _lib.check(self.lib.mc_ctx_set_tie_policy(self.handle, code), 'mc_ctx_set_tie_policy')
 
     def routing(self, layer):

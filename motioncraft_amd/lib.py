@@ -71,6 +71,8 @@ _SIGNATURES = {
     'mc_ctx_create': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     'mc_ctx_destroy': (None, [_P]),
     'mc_ctx_workspace_bytes': (ctypes.c_int64, [_P]),
+    'mc_ctx_check': (ctypes.c_int, [_P, _P]),
+    'mc_ctx_uses_coop_routing': (ctypes.c_int, [_P]),
     'mc_ctx_enable_capture': (ctypes.c_int, [_P]),
     'mc_ctx_set_tie_policy': (ctypes.c_int, [_P, ctypes.c_int32]),
     'mc_ctx_set_precision': (ctypes.c_int, [_P, ctypes.c_int32]),

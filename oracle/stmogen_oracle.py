@@ -213,8 +213,19 @@ def control_forward_c(p, c, T):
     return c_new
 
 
+def precompute_text_control(p, xf_out, dims, copy_blocks_num):
+    """The step-invariant text K/V of every layer slot of the control wrapper (base layers 0..NL-1, control copy j at
+    NL + j), routed over the CFG-doubled condition batch like `precompute_text` -- lets a lockstep test evaluate a
+    SUB-batch of samples with the text features the full batch produced (the text MoE's capacity couples the batch)."""
+    xf2 = xf_out.repeat(2, 1, 1)
+    out = {i: text_kv(p, f'base_model.temporal_decoder_blocks.{i}.ca_block.', xf2, dims) for i in range(dims['NL'])}
+    for j in range(copy_blocks_num):
+        out[dims['NL'] + j] = text_kv(p, f'controlnet.{j}.copied_block.ca_block.', xf2, dims)
+    return out
+
+
 def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_num, condition_cfg=True, cap=None,
-                    forced_routing=None):
+                    forced_routing=None, text_feats=None):
     """ControlT2MHalf.forward + forward_test (controlnet.py:201-266, 340-424) with a condition `c`
     [B, Tc, cond_feats]; `p` uses the wrapper's key names (base_model.* / controlnet.* / control_cond_input.*).
     ``forced_routing`` / ``cap['routing'][slot]``: per layer slot, base layers 0..NL-1 first, control copy j at NL + j."""
@@ -238,6 +249,7 @@ def denoise_control(p, dims, x_t, t_orig, xf_out, motion_mask, c, copy_blocks_nu
     def layer(pp, pre, x, slot):
         lcap = {} if cap is not None else None
         x = stma(pp, pre + 'ca_block.', x, xf2, emb2, mask2, cond, dims, cap=lcap,
+                 text_feat=None if text_feats is None else text_feats[slot],
                  forced=None if forced_routing is None else forced_routing[slot])
         if cap is not None:
             cap['routing'][slot] = lcap['routing']

@@ -320,11 +320,11 @@ def test_full_size_50_step_ddim_vs_reference_golden(full_model):
     test walks the HIP trajectory in LOCKSTEP: at every one of the 50 steps the oracle is evaluated
     on the HIP path's own x_t with the HIP path's discrete routing decisions and must reproduce
     x_{t-1} within 1e-3 (observed ~5e-6), and the discrete decisions are compared with what the
-    oracle would have chosen freely on the same input.  The distance of the final sample to the
-    committed reference golden is asserted (<= 1e-3, observed ~6e-6) whenever the two trajectories
-    never take different routing decisions (every recorded run); it would be O(0.5) as soon as the
-    ~1e-5 difference between them moved a single token across a capacity boundary at any of the
-    200 routings of the loop, which the flip count would show."""
+    oracle would have chosen freely on the same input (recorded runs: 0 or 1 differing pair over the
+    200 routings of the loop -- a differing pair whose gate weight is tiny does not move the result).
+    The distance of the final sample to the committed reference golden is asserted UNCONDITIONALLY
+    (<= 1e-3, observed 6.4e-6 .. 6.7e-6): a flip that did separate the trajectories (O(0.5) on the
+    final pose) fails the test, as the north-star bar says it should."""
     from motioncraft_amd.diffusion import build_diffusion
     from oracle import stmogen_oracle as O
     sd, nm = full_model
@@ -358,9 +358,9 @@ def test_full_size_50_step_ddim_vs_reference_golden(full_model):
     print(f'50-step DDIM lockstep: worst per-step |hip - oracle| {worst:.2e}; routing flips {flips}; '
           f'final vs reference golden {final_err:.2e}')
     assert worst <= TOL_FINAL
-    assert flips <= 2                      # observed: 0 in every recorded run
-    if flips == 0:                         # the north-star assertion: <= 1e-3 on the final 322-d pose tensor vs the reference
-        assert final_err <= TOL_FINAL, final_err
+    assert flips <= 2                      # observed: 0 or 1 (of 200 routings x 4704 pairs) in the recorded runs
+    # the north-star assertion, unconditional: <= 1e-3 on the final 322-d pose tensor vs the reference's own result
+    assert final_err <= TOL_FINAL, final_err
     ctx.close()
 
 
@@ -541,6 +541,62 @@ def test_baseline_control_configs_at_their_per_gpu_batches_vs_oracle(case):
     print(f'{case}: B={B} T={T} NL={NL}+{copy}: |hip - oracle (teacher-forced)| {err:.2e}; expert-id flips {tot_i}, keep flips '
           f'{tot_k} over {NL + copy} routings of {2 * 2 * B * T * dims["H"]} pairs')
     assert err <= TOL_FINAL
+    ctx.close()
+    nm.close()
+
+
+@pytest.mark.parametrize('case', ['s2g_b32', 'm2d_160_windows'])
+def test_baseline_control_configs_sampler_loop_lockstep(case):
+    """BASELINE configs[2] / [3] as a LOOP at their per-GPU batches (tools/s2g_test.py:220, tools/m2d_test.py:139-232 drive
+    `ddim_sample_loop` at these sizes): the first 8 steps of the 50-step DDIM schedule run on the device on the whole batch
+    (S2G: 32 samples x 196 frames, 8 base layers + 2 control copies; M2D: 160 windows x 120 frames, 4 + 3 layers), and the CPU
+    oracle walks beside it in lockstep on a 4-sample sub-batch -- from the HIP path's own x_t, with the same noise, the text
+    K/V of the full condition batch, teacher-forced to the HIP path's routing decisions (with the discrete decisions forced
+    every token is an independent row: the sub-batch reproduces the full-batch arithmetic).  Every x_{t-1} within 1e-3."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    if case == 's2g_b32':
+        dims, copy, feats, B, T, Tc = W.default_dims(NL=8), 2, 1536, 32, 196, 196
+    else:
+        dims, copy, feats, B, T, Tc = W.default_dims(L=64, F=256), 3, 35, 160, 120, 120
+    NL, H, NSTEP = dims['NL'], dims['H'], 8
+    sd = W.make_state_dict(dims, 0, shapes=W.control_param_shapes(dims, copy, feats))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    g = torch.Generator().manual_seed(83)
+    lengths = [int(v) for v in torch.randint(T // 2, T + 1, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=84, lengths=lengths)
+    c = torch.randn(B, Tc, feats, generator=g)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    sched = O.Schedule(1000, '15,15,8,6,6')
+    ctx = nm.context(B, T, max_steps=50)
+    ctx.enable_capture()
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    ctx.set_control(c.cuda())
+    torch.set_num_threads(min(32, os.cpu_count()))
+    sub = torch.arange(0, B, B // 4)                              # 4 samples, mixed lengths
+    tf_full = O.precompute_text_control(sd, xf, dims, copy)
+    tf_sub = {k: t.view(2, B, *t.shape[1:])[:, sub].reshape(2 * len(sub), *t.shape[1:]) for k, t in tf_full.items()}
+    gen = torch.Generator(device='cuda').manual_seed(85)
+    x = x_T.cuda()
+    worst = 0.0
+    for i in range(49, 49 - NSTEP, -1):
+        eps = torch.randn(B, T, dims['input_feats'], device='cuda', generator=gen)
+        x_in = x.cpu()
+        x = ctx.sample_step(x, i, d.step_coefs(i, 'ddim', dims['scale']), eps)
+        forced = {slot: ctx.routing(slot) for slot in range(NL + copy)}
+        fsub = {slot: tuple(v.view(2, B, T * H, 2)[:, sub].reshape(-1, 2) for v in f) for slot, f in forced.items()}
+        x0 = O.denoise_control(sd, dims, x_in[sub], sched.timestep_map[i], xf[sub], mask[sub], c[sub], copy,
+                               forced_routing=fsub, text_feats=tf_sub)
+        ref = O.ddim_step(sched, i, x_in[sub], x0, eps.cpu()[sub])
+        e = maxabs(x.cpu()[sub], ref)
+        worst = max(worst, e)
+        assert e <= TOL_FINAL, (case, i, e)
+    assert bool(torch.isfinite(x).all())
+    print(f'{case}: first {NSTEP} DDIM steps at B={B} T={T} NL={NL}+{copy}: lockstep |hip - oracle| worst {worst:.2e} '
+          f'on {len(sub)} samples')
     ctx.close()
     nm.close()
 
@@ -1441,6 +1497,73 @@ def test_cooperative_routing_kernel_equals_the_launch_sequence(regime, B, monkey
         dropped += int((~ka).sum())
     assert dropped > 0, 'the capacity cut never engaged'
     nm.close()
+
+
+def test_cooperative_routing_admission_and_concurrent_contexts(full_model):
+    """route_coop_k needs its whole grid resident, so the library reserves a context's workgroups out of the device's
+    capacity (occupancy query x CUs) at mc_ctx_create and a context that does not fit falls back to the launch sequence
+    by itself (no env var, no trap).  Four B=16 contexts (59 workgroups each) run their denoiser calls CONCURRENTLY on four
+    streams, three rounds: every result equals the same context's result when run alone, and mc_ctx_check stays clean."""
+    sd, nm = full_model
+    B, T = 16, 196
+    ctxs, inputs = [], []
+    for k in range(4):
+        x, xf, mask = synth_inputs(FULL, B, T, seed=300 + k, lengths=[T - 3 * j for j in range(B)])
+        c = nm.context(B, T, max_steps=1)
+        assert c.uses_coop_routing
+        c.set_timesteps([400 + 100 * k])
+        c.set_condition(xf.cuda(), mask.cuda())
+        ctxs.append(c)
+        inputs.append(x.cuda())
+    alone = [c.denoise(x, 0).clone() for c, x in zip(ctxs, inputs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in ctxs]
+    for rnd in range(3):
+        outs = []
+        for c, x, st in zip(ctxs, inputs, streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(c.denoise(x, 0))
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        for k, (a, o) in enumerate(zip(alone, outs)):
+            assert torch.equal(a, o), (rnd, k)
+    for c in ctxs:
+        c.check()
+        c.close()
+
+
+def test_cooperative_routing_falls_back_when_the_device_cannot_hold_the_grid(monkeypatch):
+    """With the resident-workgroup capacity set to 3 (MC_ROUTE_COOP_SLOTS, read once per process -- so this runs in a child
+    process), the first small-config context (2 workgroups) gets the cooperative kernel, the second does not fit and runs
+    the 12-launch sequence; both give the same bits; closing the first frees its reservation for a third."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, 'tests')
+from helpers import SMALL, SMALL_SEED, synth_inputs
+from oracle import weights as W
+from motioncraft_amd.engine import NativeModel
+sd = W.make_state_dict(SMALL, SMALL_SEED)
+nm = NativeModel(SMALL, sd, cfg_scale=SMALL['scale'])
+x, xf, mask = synth_inputs(SMALL, 3, 24, seed=6, lengths=[24, 20, 7])
+def run(c):
+    c.set_timesteps([500]); c.set_condition(xf.cuda(), mask.cuda()); return c.denoise(x.cuda(), 0).clone()
+a = nm.context(3, 24, max_steps=1); b = nm.context(3, 24, max_steps=1)
+assert a.uses_coop_routing and not b.uses_coop_routing, (a.uses_coop_routing, b.uses_coop_routing)
+ra, rb = run(a), run(b)
+assert torch.equal(ra, rb)
+a.check(); b.check(); a.close()
+c = nm.context(3, 24, max_steps=1)
+assert c.uses_coop_routing
+assert torch.equal(run(c), ra)
+print('fallback ok')
+"""
+    env = dict(os.environ, MC_ROUTE_COOP_SLOTS='3', MC_ROUTE_SMALL_CTX='0', PYTHONPATH=os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'fallback ok' in r.stdout, r.stdout + r.stderr
 
 
 def test_control_branch_without_condition_cfg_vs_oracle():

@@ -1,0 +1,505 @@
+// Round-3 GEMM lab, part 2 (NOT part of the library): the stream-K big-tile fp32 GEMM before it moved into mc_gemm.hip.
+//   gemm_sk_k   256 x 256 x 16 tiles, 8 waves x (128 x 64), NST-stage LDS-DMA ring, ONE barrier per k-tile with the MFMAs first
+//               behind it (DMA issue and fragment reads sit between MFMA groups), persistent stream-K: the tile x k-tile
+//               iteration space is cut into G equal contiguous ranges (G = workgroups = CUs), a tile cut by a range border is
+//               finished by the owner of its k = 0 end, which adds the other parts' fp32 slabs in a fixed order.
+//   wp_k        the library's 128 x 128 wave-private kernel (reference for bit / tolerance comparison and timing)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab3.hip -o /tmp/gemm_lab3 && /tmp/gemm_lab3
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int q = nwg / NX, r = nwg % NX, xcd = bid % NX, idx = bid / NX;
+    return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+__device__ __forceinline__ void dma16(unsigned voff, const float* sbase, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+struct SkArgs {
+    const float *A, *W, *bias, *R;
+    float* C;
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    float* slab;      // [G][8 waves][32][64 lanes] float4: partial accumulators of a range's first (non-head) segment
+    int* sync;        // [0] ticket, [1] done, [2 + v] slab-ready flag of virtual worker v (all zero between launches)
+    unsigned long long* stamp;   // optional: [G][4] cycles: start, end, wait cycles, (unused)
+};
+
+constexpr int SKK = 16, SK_STAGE = 512 * SKK;
+enum { O_STREAMK = 1, O_MFMA_FIRST = 2 };
+
+template <int NST, int OPT>
+__global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[NST * SK_STAGE + 16];
+    int* sm_i = reinterpret_cast<int*>(smem + NST * SK_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int G = (int)gridDim.x;
+    const int ntn = g.N / 256, ntm = (g.M + 255) / 256, ntiles = ntm * ntn, nk = g.K / SKK;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int dr = lane >> 2, dc = ((lane & 3) ^ ((dr >> 2) & 3)) * 4;
+    const int frow = lane & 31, hf = lane >> 5, sw = (frow >> 2) & 3;
+    const float* gsrc = wave_u < 4 ? g.A : g.W;
+    const long gld = wave_u < 4 ? g.lda : g.ldw;
+    unsigned long long t_start = 0, t_wait = 0;
+    if (g.stamp) t_start = __builtin_amdgcn_s_memtime();
+    // virtual worker id: tickets are drawn in start order, so worker v + 1 has started (or starts as soon as a slot frees)
+    // whenever worker v waits for its slab -- no assumption about dispatch order or co-residency
+    if (tid == 0) sm_i[0] = __hip_atomic_fetch_add(g.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int v = xcd_remap(__builtin_amdgcn_readfirstlane(sm_i[0]), G);
+    const unsigned I = (unsigned)ntiles * (unsigned)nk;       // (host side checks I * G < 2^32)
+    auto range_start = [&](int w) { return (int)((unsigned)w * I / (unsigned)G); };
+    const int it0 = (OPT & O_STREAMK) ? range_start(v) : 0, it1 = (OPT & O_STREAMK) ? range_start(v + 1) : 0;
+
+    struct Frag { f32x4 a[4], w[2]; };
+    f32x16 acc[4][2];
+    auto ld_frag = [&](int j, int grp) {
+        const float* S = smem + (j % NST) * SK_STAGE + frow * SKK + ((2 * grp + hf) ^ sw) * 4;
+        Frag f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) f.a[mi] = *reinterpret_cast<const f32x4*>(S + (wm * 128 + mi * 32) * SKK);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) f.w[ni] = *reinterpret_cast<const f32x4*>(S + (256 + wn * 64 + ni * 32) * SKK);
+        return f;
+    };
+    auto mma_i = [&](const Frag& f, int i) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[ni][i], f.a[mi][i], acc[mi][ni], 0, 0, 0);
+    };
+    auto wait_dyn = [&](int stages_after) {      // this wave's DMAs of the needed stage have landed when <= 4 x stages_after are in flight
+        if (stages_after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (stages_after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    auto segment = [&](int tile, int kb, int ke) {
+        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * 256;
+        const int n = ke - kb;
+        unsigned vo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = 4 * (wave_u & 3) + q;
+            long grow = (wave_u < 4 ? row0 : col0) + 16 * piece + dr;
+            if (wave_u < 4 && grow >= g.M) grow = g.M - 1;          // ragged last row tile: re-read the last row (never stored)
+            vo[q] = (unsigned)((grow * gld + dc) * 4);
+        }
+        auto issue_q = [&](int j, int q) {
+            const unsigned l = lds0 + (unsigned)(j % NST) * (SK_STAGE * 4) + (unsigned)(4 * wave_u + q) * 1024;
+            dma16(vo[q], gsrc + (long)(kb + j) * SKK, l);
+        };
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        __syncthreads();                                         // every wave is done with the previous segment's stages
+        const int pre = n < NST - 1 ? n : NST - 1;
+        for (int j = 0; j < pre; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue_q(j, q);
+        wait_dyn(pre - 1);
+        __syncthreads();
+        Frag f0 = ld_frag(0, 0), f1;
+        for (int j = 0; j < n; ++j) {
+            const int issued = (j + NST - 1 < n) ? j + NST - 1 : n;        // stages issued so far
+            wait_dyn(j + 1 < n ? issued - (j + 2) : 0);                     // stage j+1 (if any) has landed for this wave
+            __syncthreads();                                                 // ... for every wave; nobody still reads stage j-1
+            const bool more = j + NST - 1 < n;
+            if constexpr (OPT & O_MFMA_FIRST) {
+                mma_i(f0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { issue_q(j + NST - 1, 0); issue_q(j + NST - 1, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { issue_q(j + NST - 1, 2); issue_q(j + NST - 1, 3); }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                f1 = ld_frag(j, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f0, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                f0 = ld_frag(j + 1, 0);                           // (past the last k-tile: stale bytes, never used)
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f1, 1); mma_i(f1, 2); mma_i(f1, 3);
+            } else {
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) issue_q(j + NST - 1, q);
+                }
+                f1 = ld_frag(j, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f0, 0); mma_i(f0, 1); mma_i(f0, 2); mma_i(f0, 3);
+                f0 = ld_frag(j + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_i(f1, 0); mma_i(f1, 1); mma_i(f1, 2); mma_i(f1, 3);
+            }
+        }
+    };
+
+    auto epilogue = [&](int tile) {
+        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * 256;
+        // software pipeline over the 8 (mi, ni) blocks of 4 float4: the residual of block b+1 is requested before block b is
+        // finished and stored (16 + 16 registers beside the 128 accumulators)
+        auto load_res = [&](int b, f32x4 (&rv)[4]) {
+            long m = row0 + wm * 128 + (b >> 1) * 32 + frow;
+            if (m >= g.M) m = g.M - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nn = col0 + wn * 64 + (b & 1) * 32 + 8 * q + 4 * hf;
+                rv[q] = g.R ? *reinterpret_cast<const f32x4*>(g.R + m * g.ldr + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        f32x4 rv[4], rn[4];
+        load_res(0, rv);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int mi = b >> 1, ni = b & 1;
+            if (b + 1 < 8) load_res(b + 1, rn);
+            const long m = row0 + wm * 128 + mi * 32 + frow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nn = col0 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                f32x4 o = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                if (g.bias) o += *reinterpret_cast<const f32x4*>(g.bias + nn);
+                o += rv[q];
+                if (m < g.M) *reinterpret_cast<f32x4*>(g.C + m * g.ldc + nn) = o;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rv[q] = rn[q];
+        }
+    };
+
+    if constexpr (OPT & O_STREAMK) {
+        int it = it0;
+        while (it < it1) {
+            const int tile = it / nk, kb = it - tile * nk;
+            const int rem = it1 - it;
+            const int ke = (rem < nk - kb) ? kb + rem : nk;
+            // head part of a tile that continues in the following workers' first segments: how many of them
+            int ncontrib = 0;
+            if (kb == 0 && ke < nk)
+                for (int u = v + 1; u < G && range_start(u) < (tile + 1) * nk; ++u) ++ncontrib;
+            segment(tile, kb, ke);
+            if (kb > 0) {
+                // non-head part of a tile: the accumulators go to this worker's slab, lane-linear (1 KiB per wave-instruction)
+                f32x4* s4 = reinterpret_cast<f32x4*>(g.slab) + ((long)v * 8 + wave) * 32 * 64 + lane;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            s4[(mi * 8 + ni * 4 + q) * 64] = f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(g.sync + 2 + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                for (int c = 1; c <= ncontrib; ++c) {
+                    const int u = v + c;
+                    unsigned long long w0 = 0;
+                    if (g.stamp) w0 = __builtin_amdgcn_s_memtime();
+                    if (tid == 0) {
+                        unsigned spins = 0;
+#pragma unroll 1
+                        while (__hip_atomic_load(g.sync + 2 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1u << 28)) __builtin_trap();      // (unreachable by the ticket order; bounded anyway)
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        __hip_atomic_store(g.sync + 2 + u, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                    if (g.stamp) t_wait += __builtin_amdgcn_s_memtime() - w0;
+                    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.slab) + ((long)u * 8 + wave) * 32 * 64 + lane;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {              // 8 loads in flight at a time (32 registers beside the accumulators)
+                        f32x4 p[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) p[j] = s4[(mi * 8 + j) * 64];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[mi][j >> 2][4 * (j & 3) + r] += p[j][r];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                epilogue(tile);
+            }
+            it += ke - kb;
+        }
+    } else {
+        for (int tile = v; tile < ntiles; tile += G) { segment(tile, 0, nk); epilogue(tile); }
+    }
+    if (tid == 0) {
+        if (g.stamp) {
+            g.stamp[4 * v] = t_start; g.stamp[4 * v + 1] = __builtin_amdgcn_s_memtime(); g.stamp[4 * v + 2] = t_wait;
+        }
+        // the last worker to finish hands the ticket / done words back zeroed (stream order: the next launch starts after this one)
+        if (__hip_atomic_fetch_add(g.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+            __hip_atomic_store(g.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wp_k (library copy, + bias + residual)
+constexpr int WBK = 16, WSTAGE = 128 * WBK;
+__global__ __launch_bounds__(256, 2) void wp_k(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * WSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ntn = N / 128;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid % ntn, row0 = tm * 128;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* wbase = smem + wave_u * 2 * WSTAGE;
+    const unsigned lds0 = (unsigned)(size_t)wbase;
+    const int dr = lane >> 2, dc = ((lane & 3) ^ ((dr >> 2) & 3)) * 4;
+    unsigned voa[4], vow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        voa[q] = (unsigned)(((long)(row0 + wm * 64 + 16 * q + dr) * K + dc) * 4);
+        vow[q] = (unsigned)(((long)(tn * 128 + wn * 64 + 16 * q + dr) * K + dc) * 4);
+    }
+    auto issue_q = [&](int kt, int st, int q) {
+        dma16(voa[q], A + kt * WBK, lds0 + st * WSTAGE * 4 + q * 1024);
+        dma16(vow[q], W + kt * WBK, lds0 + st * WSTAGE * 4 + 4096 + q * 1024);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int frow = lane & 31, hf = lane >> 5, sw = (frow >> 2) & 3;
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto ld_frag = [&](int st, int j) {
+        const float* S = wbase + st * WSTAGE + frow * WBK + ((2 * j + hf) ^ sw) * 4;
+        Frag f;
+        f.a0 = *reinterpret_cast<const f32x4*>(S);
+        f.a1 = *reinterpret_cast<const f32x4*>(S + 32 * WBK);
+        f.b0 = *reinterpret_cast<const f32x4*>(S + 64 * WBK);
+        f.b1 = *reinterpret_cast<const f32x4*>(S + 96 * WBK);
+        return f;
+    };
+    auto mma2 = [&](const Frag& f, int i0) {
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a0[i], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a0[i], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a1[i], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a1[i], acc[1][1], 0, 0, 0);
+        }
+    };
+    const int nk = K / WBK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_q(0, 0, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Frag f0 = ld_frag(0, 0), f1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        const bool more = kt + 1 < nk;
+        f1 = ld_frag(st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma2(f0, 0);
+        if (more) { issue_q(kt + 1, st ^ 1, 0); issue_q(kt + 1, st ^ 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma2(f0, 2);
+        if (more) { issue_q(kt + 1, st ^ 1, 2); issue_q(kt + 1, st ^ 1, 3); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma2(f1, 0);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f0 = ld_frag(st ^ 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma2(f1, 2);
+    }
+    const int m0 = row0 + wm * 64 + frow;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tn * 128 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+                if (R) v += *reinterpret_cast<const f32x4*>(R + (long)(m0 + mi * 32) * N + n);
+                *reinterpret_cast<f32x4*>(C + (long)(m0 + mi * 32) * N + n) = v;
+            }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static float *dA, *dW, *dB, *dR, *dC, *dC2, *dSlab;
+static int* dSync;
+static unsigned long long* dStamp;
+static int NCU = 256;
+static std::vector<float> hA, hW, hR, hB;
+
+static void check64(int M, int N, int K) {     // sampled entries of dC vs a float64 dot (operand layout of the K = 1536 runs)
+    std::vector<float> c((size_t)M * N);
+    hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    srand(9);
+    for (int s = 0; s < 600; ++s) {
+        const int m = s < 300 ? M - 1 - (s % 150) : rand() % M, n = rand() % N;
+        double d = (double)hB[n] + hR[(size_t)m * N + n];
+        for (int k = 0; k < K; ++k) d += (double)hA[(size_t)m * K + k] * hW[(size_t)n * K + k];
+        worst = std::max(worst, std::fabs(d - c[(size_t)m * N + n]));
+    }
+    printf("      sampled entries (incl. the last 150 rows) vs float64: max abs err %.3e\n", worst);
+}
+
+template <typename F>
+static float time_it(F&& launch, int reps = 7, int inner = 4) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 6; ++r) launch();
+    hipDeviceSynchronize();
+    std::vector<float> ts;
+    for (int rep = 0; rep < reps; ++rep) {
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < inner; ++r) launch();
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        ts.push_back(ms / inner);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+static void compare(int M, int N, const char* what) {
+    std::vector<float> a((size_t)M * N), b((size_t)M * N);
+    hipMemcpy(a.data(), dC, a.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), dC2, b.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0, ref = 0;
+    size_t ndiff = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const double d = std::fabs((double)a[i] - b[i]);
+        if (d > 0) ++ndiff;
+        worst = std::max(worst, d); ref = std::max(ref, (double)std::fabs(b[i]));
+    }
+    printf("      %s vs wp_k: max abs diff %.3e (max |C| %.2f), %zu of %zu elements differ\n", what, worst, ref, ndiff, a.size());
+}
+
+template <int NST, int OPT>
+static void run_sk(const char* name, int M, int N, int K, bool res, bool cmp, bool warm = true) {
+    SkArgs g{dA, dW, dB, res ? dR : nullptr, dC, M, N, K, K, K, N, N, dSlab, dSync, nullptr};
+    auto launch = [&]() { hipLaunchKernelGGL((gemm_sk_k<NST, OPT>), dim3(NCU), dim3(512), 0, 0, g); };
+    if (warm) for (int r = 0; r < 40; ++r) launch();
+    const float ms = time_it(launch);
+    const double tf = 2.0 * M * N * K / ms / 1e9;
+    printf("sk_k  %-52s %6dx%4dx%4d: %8.1f us %6.1f TF (%5.1f %%)\n", name, M, N, K, ms * 1e3, tf, tf / 1.573);
+    g.stamp = dStamp;
+    launch();
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> st(4 * NCU);
+    hipMemcpy(st.data(), dStamp, st.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0; double wsum = 0, wmax = 0, dsum = 0, dmin = 1e30, dmax = 0;
+    for (int v = 0; v < NCU; ++v) {
+        t0 = std::min(t0, st[4 * v]); t1 = std::max(t1, st[4 * v + 1]); wsum += st[4 * v + 2]; wmax = std::max(wmax, (double)st[4 * v + 2]);
+        const double d = double(st[4 * v + 1] - st[4 * v]); dsum += d; dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+    }
+    const double ideal = 2.0 * M * N * K / (NCU * 4 * 4096.0) * 64.0;        // MFMA-bound cycles per CU (4 SIMDs)
+    printf("      span %llu cyc; worker cycles mean %.0f min %.0f max %.0f (MFMA-bound %.0f = %.1f %%); slab wait mean %.0f max %.0f cyc\n", t1 - t0,
+           dsum / NCU, dmin, dmax, ideal, ideal / (dsum / NCU) * 100, wsum / NCU, wmax);
+    if (cmp) compare(M, N, name);
+    if (K == 1536 && res && (M == 25000 || cmp)) {
+        // rows past M must be untouched: poison the tail of dC first
+        g.stamp = nullptr;
+        hipMemset(dC + (size_t)M * N, 0x7f, 256 * N * 4);
+        launch();
+        hipDeviceSynchronize();
+        check64(M, N, K);
+        std::vector<unsigned> tail(256 * (size_t)N);
+        hipMemcpy(tail.data(), dC + (size_t)M * N, tail.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (auto x : tail) bad += x != 0x7f7f7f7fu;
+        if (bad) printf("      !!! %zu words past row M were overwritten\n", bad);
+    }
+}
+
+static void run_wp(int M, int N, int K, bool res) {
+    const int tiles = (M / 128) * (N / 128);
+    auto launch = [&]() { hipLaunchKernelGGL(wp_k, dim3(tiles), dim3(256), 0, 0, dA, dW, dB, res ? dR : nullptr, dC2, M, N, K); };
+    for (int r = 0; r < 40; ++r) launch();
+    const float ms = time_it(launch);
+    const double tf = 2.0 * M * N * K / ms / 1e9;
+    printf("wp_k  %-52s %6dx%4dx%4d: %8.1f us %6.1f TF (%5.1f %%)\n", res ? "bias + residual" : "bias", M, N, K, ms * 1e3, tf, tf / 1.573);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    NCU = prop.multiProcessorCount;
+    printf("CUs: %d\n", NCU);
+    const size_t MMAX = 32768, NMAX = 4096, KMAX = 4096;
+    hipMalloc(&dA, MMAX * KMAX * 4); hipMalloc(&dW, NMAX * KMAX * 4); hipMalloc(&dB, NMAX * 4);
+    hipMalloc(&dR, MMAX * NMAX * 4); hipMalloc(&dC, MMAX * NMAX * 4); hipMalloc(&dC2, MMAX * NMAX * 4);
+    hipMalloc(&dSlab, (size_t)NCU * 8 * 32 * 64 * 16); hipMalloc(&dSync, (2 + NCU) * 4); hipMalloc(&dStamp, NCU * 32);
+    hipMemset(dSync, 0, (2 + NCU) * 4);
+    hA.resize(MMAX * 1536); hR.resize(MMAX * 1536); hW.resize(NMAX * KMAX); hB.resize(NMAX);
+    srand(1);
+    for (auto& x : hA) x = (float)rand() / RAND_MAX * 2.f - 1.f;
+    for (auto& x : hR) x = (float)rand() / RAND_MAX * 2.f - 1.f;
+    for (auto& x : hW) x = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
+    for (auto& x : hB) x = (float)rand() / RAND_MAX * 2.f - 1.f;
+    hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dR, hR.data(), hR.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+    for (int pass = 0; pass < 2; ++pass) {
+        printf("---- pass %d\n", pass);
+        for (int M : {25088, 12544, 32768, 6272, 25000}) {
+            if (M % 128 == 0) run_wp(M, 1536, 1536, true);
+            const bool cmp = pass == 0 && M % 128 == 0;
+            run_sk<4, O_STREAMK | O_MFMA_FIRST>("stream-K, 4 stages, MFMA first", M, 1536, 1536, true, cmp);
+            run_sk<3, O_STREAMK | O_MFMA_FIRST>("stream-K, 3 stages, MFMA first", M, 1536, 1536, true, false);
+            run_sk<4, O_STREAMK>("stream-K, 4 stages, loads first", M, 1536, 1536, true, false);
+            if (M % 256 == 0) run_sk<4, O_MFMA_FIRST>("tile round-robin, 4 stages, MFMA first", M, 1536, 1536, true, cmp);
+        }
+        // determinism: two launches, bit-identical
+        {
+            SkArgs g{dA, dW, dB, dR, dC, 25088, 1536, 1536, 1536, 1536, 1536, 1536, dSlab, dSync, nullptr};
+            hipLaunchKernelGGL((gemm_sk_k<4, 3>), dim3(NCU), dim3(512), 0, 0, g);
+            g.C = dC2;
+            hipLaunchKernelGGL((gemm_sk_k<4, 3>), dim3(NCU), dim3(512), 0, 0, g);
+            hipDeviceSynchronize();
+            compare(25088, 1536, "run-to-run (stream-K twice)");
+        }
+    }
+    printf("---- 4096^3 (no residual)\n");
+    for (int pass = 0; pass < 2; ++pass) {
+        run_wp(4096, 4096, 4096, false);
+        run_sk<4, O_STREAMK | O_MFMA_FIRST>("stream-K, 4 stages, MFMA first", 4096, 4096, 4096, false, pass == 0);
+        run_sk<3, O_STREAMK | O_MFMA_FIRST>("stream-K, 3 stages, MFMA first", 4096, 4096, 4096, false, false);
+        run_sk<4, O_STREAMK>("stream-K, 4 stages, loads first", 4096, 4096, 4096, false, false);
+    }
+    return 0;
+}
