@@ -7,8 +7,8 @@ batch=64 per GPU).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch: denoiser (CFG-doubled) + CFG combine +
-p_sample update, including the per-step noise draw.  K steps are timed between barriers +
-device syncs; MAX over ranks.  `value` = whole-job frames/s of the COMPLETE 1000-step loop:
+p_sample update, including the per-step noise draw (on the device, inside the sampler-update
+kernel: mc_sample_loop).  K steps are timed between barriers + device syncs; MAX over ranks.  `value` = whole-job frames/s of the COMPLETE 1000-step loop:
 
     value = N * B * T / (t_setup + 1000 * t_step + t_gather)
 
@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_FP16_MFMA_TFLOPS = 2500.0        # dense (MI355X_MICROARCH.md)
 TOTAL_DDPM_STEPS = 1000
 
 
@@ -117,11 +118,24 @@ def cpu_baseline(B=8, T=196, steps=6):
         x0 = O.denoise(sd, dims, x, sched.timestep_map[i], xf, mask, text_feats=tf)
         x = O.ddpm_step(sched, i, x, x0, torch.randn(x.shape, generator=g))
     t_step = (time.time() - t0) / steps
-    return dict(value=round(B * T / (t_text + TOTAL_DDPM_STEPS * t_step), 4), unit='frames/s',
-                cores=best, kind='port',
-                sample=f'oracle/stmogen_oracle.py (torch-CPU fp32, {best} threads = fastest of 8/16/32/64 on a '
-                       f'{ncpu}-CPU host), batch {B}, {steps} of 1000 DDPM steps timed ({t_step:.2f} s/step) + text '
-                       f'K/V hoist ({t_text:.2f} s), extrapolated to the full loop')
+    out = dict(value=round(B * T / (t_text + TOTAL_DDPM_STEPS * t_step), 4), unit='frames/s',
+               cores=best, kind='port',
+               sample=f'oracle/stmogen_oracle.py (torch-CPU fp32, {best} threads = fastest of 8/16/32/64 on a '
+                      f'{ncpu}-CPU host), batch {B}, {steps} of 1000 DDPM steps timed ({t_step:.2f} s/step) + text '
+                      f'K/V hoist ({t_text:.2f} s), extrapolated to the full loop')
+    # BASELINE configs[0] ("timed for config 1 exactly"): batch 1, 196 frames, the COMPLETE 50-step DDIM loop
+    # (configs/stmogen/T2M_motionx_align.py:90-98 respace '15,15,8,6,6'; the reference's CPU entry is tools/visualize.sh --device cpu)
+    sched50 = O.Schedule(1000, '15,15,8,6,6')
+    x1, xf1, m1 = x_T[:1], xf[:1], mask[:1]
+    t0 = time.time()
+    tf1 = O.precompute_text(sd, xf1, dims)
+    for i in range(49, -1, -1):
+        x0 = O.denoise(sd, dims, x1, sched50.timestep_map[i], xf1, m1, text_feats=tf1)
+        x1 = O.ddim_step(sched50, i, x1, x0, torch.zeros_like(x1))
+    t_c0 = time.time() - t0
+    out['configs0'] = dict(value=round(T / t_c0, 3), unit='frames/s', loop_s=round(t_c0, 3), cores=best,
+                           sample='the complete loop, timed exactly: batch 1, 196 frames, 50-step DDIM (eta 0), text K/V hoist included')
+    return out
 
 
 def main():
@@ -191,14 +205,15 @@ def main():
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(B, T, C, device=dev, generator=gen)
-    nxt = torch.empty_like(x)
     coefs = {i: diff.step_coefs(i, 'ddpm', DIMS['scale']) for i in range(TOTAL_DDPM_STEPS)}
 
+    NOISE_KEY = 0x5EED0000 + rank          # key of the device-side Philox stream (one draw index per step)
+    draw = [0]
+
     def one_step(i):
-        nonlocal x, nxt
-        eps = torch.randn(B, T, C, device=dev, generator=gen)
-        ctx.sample_step(x, i, coefs[i], eps, x_prev=nxt)
-        x, nxt = nxt, x
+        # one step through the loop entry (x updated in place, the step's randn_like drawn inside the sampler-update kernel)
+        ctx.sample_loop(x, [i], [coefs[i]], noise=None, seed=NOISE_KEY, draw0=draw[0])
+        draw[0] += 1
 
     i = TOTAL_DDPM_STEPS - 1
     for _ in range(a.warmup):
@@ -223,8 +238,8 @@ def main():
         x.normal_(generator=gen)
         barrier()
         t0 = time.perf_counter()
-        for j in range(TOTAL_DDPM_STEPS - 1, -1, -1):
-            one_step(j)
+        order = list(range(TOTAL_DDPM_STEPS - 1, -1, -1))
+        ctx.sample_loop(x, order, [coefs[j] for j in order], noise=None, seed=NOISE_KEY, draw0=draw[0])      # ONE library call
         barrier()
         t_full = time.perf_counter() - t0
         assert bool(torch.isfinite(x).all()), 'the 1000-step loop produced non-finite poses'
@@ -237,34 +252,26 @@ def main():
     t_gather = time.perf_counter() - t0
     assert out.shape[0] == GB and bool(torch.isfinite(out).all())
 
-    # ---- dominant kernel on its own: the FiLM out_layers GEMM h += a W^T + b, [2BT, D] x [D, D] (8 launches per step) ----
+    # ---- dominant kernel, measured IN the step: HIP events around every FiLM out_layers GEMM launch (h += a W^T + b,
+    # stylization_block.py:39) on the stream it is launched on, over 8 steps after the timed region (mc_ctx_profile; the
+    # rocprofv3 --kernel-trace --stats table of this command is profiles/r03_kernel_stats_b64.txt) ----
     dom = None
     if rank == 0 and not a.no_extras:
-        import ctypes
-        from motioncraft_amd import lib as mclib
-        lib_ = mclib.load(require_gpu=True)
         D = DIMS['L'] * DIMS['H']
-        rows = 2 * B * T
-        ga = torch.randn(rows, D, device=dev)
-        gw = torch.randn(D, D, device=dev) / D ** 0.5
-        gb = torch.zeros(D, device=dev)
-        gc = torch.zeros(rows, D, device=dev)
-        P = lambda t_: ctypes.c_void_p(t_.data_ptr())
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        launch = lambda: mclib.check(lib_.mc_op_gemm(P(ga), P(gw), P(gb), P(gc), P(gc), rows, D, D, D, 0, st), 'mc_op_gemm')
-        for _ in range(3):
-            launch()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        nrep = 16
-        e0.record()
-        for _ in range(nrep):
-            launch()
-        e1.record()
+        ctx.profile(True)
+        for j in range(8):
+            one_step(500 + j)
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / nrep * 1e3
-        tf = 2.0 * rows * D * D / (us * 1e-6) / 1e12
-        dom = {'kernel': f'gemm_wp_k (fp32 MFMA, persistent wave-private LDS-DMA pipeline): FiLM out_layers GEMM {rows}x{D}x{D} + bias + residual (8 of the ~125 launches, 35 % of a step)',
-               'avg_us': round(us, 1), 'achieved': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        us, cnt, gf = ctx.profile_read()
+        ctx.profile(False)
+        if cnt:
+            tf = gf / us * 1e-3
+            dom = {'kernel': 'gemm_wp_k (fp32 MFMA, wave-private LDS-DMA pipeline): the FiLM out_layers GEMMs h += a W^T + b as the step '
+                             f'launches them (one launch per sample group: {int(round(gf * 1e9 / (2 * D * D)))} rows x {D} x {D}, bias + residual)',
+                   'launches_timed': cnt, 'avg_us': round(us, 1), 'gflop_per_launch': round(gf, 2), 'achieved': round(tf, 2),
+                   'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                   'how': 'HIP events on the launch stream around each in-step launch (the two sample groups overlap on two streams, so a '
+                          "launch's interval includes the other group's kernels sharing the CUs)"}
 
     # ---- side measurement (NOT `value`): two independent batches of B in flight on this GPU, one HIP stream and one
     # context each -- what a test loop over many batches of 64 can do; each batch keeps its own MoE capacity domain ----
@@ -324,9 +331,36 @@ def main():
             dtp = (time.perf_counter() - t0) / nrep
             reduced[prec] = {'ms_per_step': round(dtp * 1e3, 3),
                              'frames_per_s': round(B * T / (t_setup + TOTAL_DDPM_STEPS * dtp + t_gather), 1)}
+            if prec == 'f16x3':
+                # every fp32 product is three fp16 MFMA products: ceiling = dense fp16 MFMA peak / 3
+                ach16 = algorithmic_flops_per_sample_step(DIMS, T) * B / dtp / 1e12
+                reduced[prec]['roofline'] = {'bound': 'mfma', 'achieved': round(ach16, 2), 'peak': round(PEAK_FP16_MFMA_TFLOPS / 3, 1),
+                                             'unit': 'TFLOP/s (fp32-equivalent)', 'frac': round(ach16 / (PEAK_FP16_MFMA_TFLOPS / 3), 4)}
             cj.close()
         reduced['note'] = ('side measurement, not `value`: mc_ctx_set_precision modes (include/motioncraft_amd.h); the headline '
                            'stays the exact fp32 MFMA path')
+
+    # ---- BASELINE configs[0] on the GPU (NOT `value`): batch 1, 196 frames, the complete 50-step DDIM loop, one library call ----
+    configs0 = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        d50 = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                                   model_var_type='fixed_large', respace='15,15,8,6,6'))
+        c1 = nm.context(1, T, max_steps=50)
+        c1.set_timesteps(d50.timestep_map)
+        c1.set_condition(xf[:1].contiguous(), mask[:1].contiguous())
+        k50 = [d50.step_coefs(j, 'ddim', DIMS['scale'], 0.0) for j in range(49, -1, -1)]
+        x1 = torch.randn(1, T, C, device=dev, generator=gen)
+        ts1 = []
+        for rep in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c1.sample_loop(x1, list(range(49, -1, -1)), k50, noise=None, seed=NOISE_KEY, draw0=10 ** 6 + 50 * rep)
+            torch.cuda.synchronize()
+            ts1.append(time.perf_counter() - t0)
+        c1.close()
+        t1 = sorted(ts1[1:])[len(ts1[1:]) // 2]
+        configs0 = {'loop_ms': round(t1 * 1e3, 2), 'frames_per_s': round(T / t1, 1),
+                    'note': 'side measurement, not `value`: configs[0] (batch 1, 196 frames, 50-step DDIM) as one mc_sample_loop call, median of 5'}
 
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms, t_full or 0.0], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
@@ -346,6 +380,8 @@ def main():
                          'note': 'complete 1000-step loop run once after the timed region (x_T -> x_0, max over ranks); '
                                  '`value` uses the K timed steps as the contract asks'}
         ach = flops_step / (ev_ms * 1e-3) / 1e12
+        D_ = DIMS['L'] * DIMS['H']
+        alg_gb = (127.9e6 * 4 + DIMS['NL'] * 6 * (2 * B * T * D_ * 4) + 5 * B * T * C * 4) / 1e9
         line = {
             'metric': 'sampled SMPL-X frames/sec (196-frame seq, 1000-step DDPM)',
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -357,7 +393,7 @@ def main():
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
-                       'full_loop': full_loop, 'reduced_precision_modes': reduced,
+                       'full_loop': full_loop, 'reduced_precision_modes': reduced, 'configs0_gpu': configs0,
                        'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
                        'exact_reductions': 'results equal the unreduced computation (tests/test_gpu_parity.py): CFG twins of base layer 0 '
                                            'share gate / expert / proj / qkv / body work (identical inputs); the last StylizationBlock '
@@ -365,8 +401,12 @@ def main():
                                            'counted as the reference performs them (DESIGN.md section 4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic_gb if (B, T) == (64, 196) else None,
+                         'algorithmic_bytes': round(alg_gb, 3),
+                         'algorithmic_bytes_unit': 'GB per step (SURVEY.md section 8d): fp32 weights streamed once (0.512) + the residual stream h '
+                                                   '[2B,T,D] once per fused kernel, 6 per layer + the sampler update 5 B T 322 floats',
+                         'traffic_over_algorithmic': round(traffic_gb / alg_gb, 2) if (traffic_gb and (B, T) == (64, 196)) else None,
                          'traffic_unit': f'GB per step, read from {traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction)',
-                         'kernel': 'one denoising step = all kernels of mc_sample_step (dominant: gemm_wp_k fp32 MFMA GEMMs)',
+                         'kernel': 'one denoising step = all kernels of one mc_sample_loop step (dominant: gemm_wp_k fp32 MFMA GEMMs)',
                          'algorithmic_gflop_per_sample_step': round(algorithmic_flops_per_sample_step(DIMS, T) / 1e9, 3),
                          'event_ms_per_step': round(ev_ms, 4), 'dominant_kernel': dom},
         }

@@ -126,6 +126,12 @@ int64_t mc_ctx_workspace_bytes(const mc_ctx* c);
  * Python sampler loops call it once after the last step -- the reference has no counterpart (its routing is tutel's, on the
  * framework's stream: st_attention.py:28-45). */
 int mc_ctx_check(mc_ctx* c, void* stream);
+/* Measurement hook (bench.py `roofline.dominant_kernel`; no reference counterpart): while on, every FiLM out_layers GEMM launch
+ * (h += Linear(a), stylization_block.py:39 -- the dominant kernel of a step) is bracketed by HIP events recorded on the stream it is
+ * launched on.  mc_ctx_profile_read waits for them and returns the average duration (us), the number of launches and the
+ * algorithmic GFLOP of one launch (2 rows D^2); rows_filter > 0 keeps only launches of that many rows. */
+int mc_ctx_profile(mc_ctx* c, int32_t on);
+int mc_ctx_profile_read(mc_ctx* c, int64_t rows_filter, double* avg_us, int32_t* count, double* gflop_per_launch);
 /* 1 if this context routes its layers with the one-launch cooperative kernel (0: one-workgroup kernels or the launch sequence) */
 int mc_ctx_uses_coop_routing(const mc_ctx* c);
 /* tests: keep the routing decisions (expert ids, combine weights; 0 = dropped) of every layer of the
@@ -167,6 +173,19 @@ int mc_denoise(mc_ctx* c, const float* x_t_dev, int32_t step_index, float* out2_
 /* denoise + CFG combine + sampler update in one call; x0_dev may be NULL; x_prev_dev may alias x_t_dev */
 int mc_sample_step(mc_ctx* c, const float* x_t_dev, int32_t step_index, const mc_step_coefs* coefs,
                    const float* noise_dev, float* x_prev_dev, float* x0_dev, void* stream);
+
+/* The sampler LOOP as one call -- GaussianDiffusion.p_sample_loop / ddim_sample_loop, gaussian_diffusion.py:698-797, 925-1049 (the
+ * mode is in coefs[k].mode): runs schedule indices step_indices_host[0 .. num_steps) in order (the reference walks
+ * num_timesteps-1 .. 0) with coefs_host[k], x_dev [B,T,C] updated IN PLACE, no return to the host language between steps.
+ * The per-step th.randn_like(x) (gaussian_diffusion.py:684 / 847) is
+ *   noise_dev != NULL: read from noise_dev [num_steps][B,T,C]  (parity runs on the reference's own seeds), or
+ *   noise_dev == NULL: drawn inside the sampler-update kernel -- Philox4x32-10 keyed by `seed`, counter = (element / 4,
+ *                      noise_draw0 + k), Box-Muller; mc_op_philox_normal writes the same draws to memory (bit for bit).
+ * x0_last_dev (may be NULL) receives the last step's x0 prediction.  Asynchronous on `stream` like every other entry point. */
+int mc_sample_loop(mc_ctx* c, float* x_dev, const int32_t* step_indices_host, const mc_step_coefs* coefs_host, int32_t num_steps,
+                   const float* noise_dev, uint64_t seed, uint64_t noise_draw0, float* x0_last_dev, void* stream);
+/* draw `draw` of the Philox stream keyed by `seed`: out_dev[n] = normals, bits_dev[n] = the raw 32-bit words (either may be NULL) */
+int mc_op_philox_normal(float* out_dev, uint32_t* bits_dev, int64_t n, uint64_t seed, uint64_t draw, void* stream);
 
 /* hipGraph replay of mc_sample_step (BASELINE.json configs[4] "hipGraph-captured 50-step DDIM"): ONE graph serves every step
  * of the schedule -- the step index is a device-side integer, the FiLM tables and the sampler coefficients are addressed

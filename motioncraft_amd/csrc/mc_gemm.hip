@@ -867,7 +867,8 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
         g.lda % 4 == 0 && g.ldw % 4 == 0 && g.a_col % 4 == 0 && vec_out && g.act != ACT_QUICKGELU && !g.act_after_res) {
         // bit 5: wave-private pipeline variant (no k-loop barrier); needs 32-bit byte offsets into A and W
         if ((g.tune & 32) && g.K % WBK == 0 && (long)g.M * g.lda * 4 < (1L << 32) && (long)g.N * g.ldw * 4 < (1L << 32)) {
-            const int persistent = 2 * 256;          // 2 workgroups per CU (64 KB of LDS each) on 256 CUs
+            static const int wp_grid = [] { const char* e = getenv("MC_GEMM_WP_GRID"); return e ? atoi(e) : 512; }();
+            const int persistent = wp_grid > 0 ? wp_grid : (int)grid.x;          // default: 2 workgroups per CU (64 KB of LDS each) on 256 CUs; <= 0: one workgroup per tile
             hipLaunchKernelGGL(gemm_wp_k, dim3(grid.x < persistent ? grid.x : persistent), dim3(256), 0, stream, g);
         } else
             hipLaunchKernelGGL(gemm_dma_k, grid, dim3(256), 0, stream, g);

@@ -43,9 +43,14 @@ struct SamplerCoefs {
 };
 // x_prev = sampler(x_t, x0 = text_coef*out_text + none_coef*out_none, noise); optionally also writes x0
 // table != nullptr (graph replay): the step's coefficients are table[*step_ptr]; only text_coef / none_coef of `c` are used
+// rng (with noise == nullptr): the noise is drawn inside the kernel, Philox4x32-10 keyed by the seed, counter (element / 4, draw index)
+struct RngArgs { uint32_t seed_lo = 0, seed_hi = 0, draw_lo = 0, draw_hi = 0; };
 int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none,
                              const float* noise, float* x_prev, float* x0_out, long n,
-                             SamplerCoefs c, hipStream_t s, const SamplerCoefs* table = nullptr, const int* step_ptr = nullptr);
+                             SamplerCoefs c, hipStream_t s, const SamplerCoefs* table = nullptr, const int* step_ptr = nullptr,
+                             const RngArgs* rng = nullptr);
+// out[n] = the normals / bits[n] = the raw 32-bit words of draw `rng` (either may be null)
+int mc_launch_philox_fill(float* out, uint32_t* bits, long n, RngArgs rng, hipStream_t s);
 // out = table[*step].text_coef * x + table[*step].none_coef * y   (CFG combine of the two halves under graph replay)
 int mc_launch_cfg_combine_tab(const float* x, const float* y, const SamplerCoefs* table, const int* step_ptr, float* out, long n,
                               hipStream_t s);

@@ -51,6 +51,8 @@ struct LayerW {
     HalfW h_ca_out, h_ffn_out, h_fc1, h_fc2, h_w1, h_w2, h_after, h_proj, h_qkv;
 };
 
+struct ProfRec { hipEvent_t e0 = nullptr, e1 = nullptr; long rows = 0; };
+
 struct mc_ctx {
     mc_model* m = nullptr;
     int B = 0, T = 0, S = 0, maxS = 0;
@@ -76,6 +78,8 @@ struct mc_ctx {
     float *te, *e1, *emb, *semb, *ss;   // ss: [NL][2][maxS][2D]
     RouteBufs rb;
     int coop_reserved = 0;      // resident route_coop_k workgroups this context holds (mc_route_coop_reserve)
+    bool prof_on = false;       // mc_ctx_profile: HIP events around the FiLM out_layers GEMM launches (bench.py's dominant-kernel figure)
+    std::vector<ProfRec> prof;
     bool have_cond = false;
     // side stream: the temporal branch of STMA needs only the motion-MoE output, so it runs beside
     // (LN + qkv -> body attention) of the same layer (fork after the MoE projection, join before proj_out)
@@ -466,7 +470,16 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     }
     if (nrows <= 2048 && c->hbuf_floats)       // few output tiles: split K (hbuf is free scratch on the fused path)
         return dense_splitk(c->a + o, out_w, out_b, hs + o, hs + o, nrows, D, D, c->hbuf, c->hbuf_floats, s);
-    return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
+    if (!c->prof_on) return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
+    // mc_ctx_profile: HIP events around this launch ON THE STREAM IT IS LAUNCHED ON (the sample group's stream)
+    ProfRec pr;
+    pr.rows = nrows;
+    if (hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess) { mc_set_error("hipEventCreate failed"); return MC_ERR_HIP; }
+    MC_HIP(hipEventRecord(pr.e0, s));
+    r = dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
+    MC_HIP(hipEventRecord(pr.e1, s));
+    c->prof.push_back(pr);
+    return r;
 }
 
 // Everything of a DecoderLayer AFTER the expert MLP, restricted to residual-stream rows [row0, row0 + nrows)
@@ -888,11 +901,13 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
 }
 
 static void graph_release(mc_ctx* c);
+static void prof_clear(mc_ctx* c);
 
 void mc_ctx_destroy(mc_ctx* c) {
     if (!c) return;
     graph_release(c);
     if (c->coop_reserved) { mc_route_coop_release(c->coop_reserved); c->coop_reserved = 0; }
+    prof_clear(c);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (int k = 1; k < 3; ++k)
         if (c->parts[k]) { (void)hipStreamSynchronize(c->parts[k]); (void)hipStreamDestroy(c->parts[k]); }
@@ -921,6 +936,39 @@ int mc_ctx_check(mc_ctx* c, void* stream) {
 }
 
 int mc_ctx_uses_coop_routing(const mc_ctx* c) { return c && c->coop_reserved > 0 ? 1 : 0; }
+
+static void prof_clear(mc_ctx* c) {
+    for (auto& p : c->prof) { if (p.e0) (void)hipEventDestroy(p.e0); if (p.e1) (void)hipEventDestroy(p.e1); }
+    c->prof.clear();
+}
+
+int mc_ctx_profile(mc_ctx* c, int32_t on) {
+    MC_REQUIRE(c, "null context");
+    MC_REQUIRE(!c->graph_mode, "profiling inside a graph capture");
+    prof_clear(c);
+    c->prof_on = on != 0;
+    return MC_OK;
+}
+
+int mc_ctx_profile_read(mc_ctx* c, int64_t rows_filter, double* avg_us, int32_t* count, double* gflop_per_launch) {
+    MC_REQUIRE(c && avg_us && count && gflop_per_launch, "null argument");
+    const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
+    double sum = 0.0, rows = 0.0;
+    int n = 0;
+    for (auto& p : c->prof) {
+        MC_HIP(hipEventSynchronize(p.e1));
+        if (rows_filter > 0 && p.rows != rows_filter) continue;
+        float ms = 0.f;
+        MC_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+        sum += ms * 1e3;
+        rows += (double)p.rows;
+        ++n;
+    }
+    *count = n;
+    *avg_us = n ? sum / n : 0.0;
+    *gflop_per_launch = n ? 2.0 * (rows / n) * D * D / 1e9 : 0.0;
+    return MC_OK;
+}
 
 int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy) {
     MC_REQUIRE(c, "null context");
@@ -1190,6 +1238,39 @@ int mc_sample_step(mc_ctx* c, const float* x_t, int32_t step, const mc_step_coef
     const long n = (long)c->B * c->T * c->m->cfg.input_feats;
     return mc_launch_sampler_update(x_t, x0a, x0b ? x0b : x0a, noise, x_prev, x0, n, combined_coefs(k, x0b != nullptr), (hipStream_t)stream,
                                     c->graph_mode ? c->gcoefs : nullptr, c->graph_mode ? c->gstep : nullptr);
+}
+
+static RngArgs rng_args(uint64_t seed, uint64_t draw) {
+    RngArgs r;
+    r.seed_lo = (uint32_t)seed; r.seed_hi = (uint32_t)(seed >> 32); r.draw_lo = (uint32_t)draw; r.draw_hi = (uint32_t)(draw >> 32);
+    return r;
+}
+
+// The whole p_sample_loop / ddim_sample_loop of the reference (gaussian_diffusion.py:698-797, 925-1049) as ONE call: x is updated in
+// place through the schedule indices step_indices[0 .. num_steps) (the reference walks num_timesteps-1 .. 0), no return to the host
+// language between steps.  The per-step randn_like (gaussian_diffusion.py:684, 847) is either read from noise_dev
+// [num_steps][B,T,C] (parity runs on the reference's seeds) or, noise_dev == NULL, drawn inside the sampler-update kernel
+// (Philox4x32-10, draw index noise_draw0 + k): no noise tensor, no generator launch.
+int mc_sample_loop(mc_ctx* c, float* x, const int32_t* step_indices, const mc_step_coefs* coefs, int32_t num_steps,
+                   const float* noise, uint64_t seed, uint64_t noise_draw0, float* x0_last, void* stream) {
+    MC_REQUIRE(c && x && step_indices && coefs, "null argument");
+    MC_REQUIRE(num_steps >= 0, "num_steps < 0");
+    const long n = (long)c->B * c->T * c->m->cfg.input_feats;
+    for (int k = 0; k < num_steps; ++k) {
+        const float *x0a = nullptr, *x0b = nullptr;
+        int r = denoise_combined(c, x, step_indices[k], &coefs[k], stream, &x0a, &x0b);
+        if (r != MC_OK) return r;
+        const RngArgs rng = rng_args(seed, noise_draw0 + (uint64_t)k);
+        r = mc_launch_sampler_update(x, x0a, x0b ? x0b : x0a, noise ? noise + (long)k * n : nullptr, x, k + 1 == num_steps ? x0_last : nullptr, n,
+                                     combined_coefs(&coefs[k], x0b != nullptr), (hipStream_t)stream, nullptr, nullptr, noise ? nullptr : &rng);
+        if (r != MC_OK) return r;
+    }
+    return MC_OK;
+}
+
+int mc_op_philox_normal(float* out, uint32_t* bits, int64_t n, uint64_t seed, uint64_t draw, void* stream) {
+    MC_REQUIRE(out || bits, "null argument");
+    return mc_launch_philox_fill(out, bits, n, rng_args(seed, draw), (hipStream_t)stream);
 }
 
 // ---- hipGraph replay of mc_sample_step -------------------------------------------------------------------------------

@@ -148,7 +148,7 @@ class GaussianDiffusion:
         return c
 
     def _loop(self, mode, model, shape, noise, model_kwargs, device, progress, eta, step_noise, generator,
-              num_steps=None, trajectory=None, pre_seq=None, transl_req=None, graph=False):
+              num_steps=None, trajectory=None, pre_seq=None, transl_req=None, graph=False, fused=True):
         if model_kwargs is None:
             model_kwargs = {}
         if not isinstance(shape, (tuple, list)):
@@ -263,6 +263,26 @@ class GaussianDiffusion:
             if getattr(ctx, 'uses_coop_routing', False):
                 ctx.check()
             return img
+        if (fused and inp is None and not seeded and trajectory is None and not progress and all(d for _, d in plan)):
+            # the whole loop inside the library (mc_sample_loop): no return to Python between steps.  Without step_noise the
+            # per-step randn_like is drawn INSIDE the sampler-update kernel (Philox4x32-10; the loop's 64-bit key is one draw from
+            # `generator`, so a seeded generator reproduces the run and successive calls differ); with step_noise the draws are
+            # gathered into [steps, B, T, C] chunks of at most ~512 MB and the same entry point reads them
+            idx = [i for i, _ in plan]
+            coefs = [self.step_coefs(i, mode, model.cfg_scale, eta) for i in idx]
+            if step_noise is None:
+                gdev = generator.device if generator is not None else torch.device('cpu')
+                key = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=gdev).item())
+                ctx.sample_loop(img, idx, coefs, noise=None, seed=key, draw0=0)
+            else:
+                chunk = max(1, int((512 << 20) // (4 * B * T * C)))
+                for k0 in range(0, len(idx), chunk):
+                    part = idx[k0:k0 + chunk]
+                    nz = torch.stack([draw(i) for i in part])
+                    ctx.sample_loop(img, part, coefs[k0:k0 + chunk], noise=nz)
+            if getattr(ctx, 'uses_coop_routing', False):
+                ctx.check()
+            return img
         for i, denoise in plan:
             if not denoise:                                                   # _undo (:429-435)
                 beta = np.float32(self.betas[i])
@@ -305,21 +325,25 @@ class GaussianDiffusion:
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, pre_seq=None, transl_req=None, progress=False,
-                      step_noise=None, generator=None, num_steps=None, trajectory=None, graph=False):
+                      step_noise=None, generator=None, num_steps=None, trajectory=None, graph=False, fused=True):
+        """gaussian_diffusion.py:698-797.  Extras beside the reference's arguments: ``step_noise`` (the per-step draws, for runs on
+        the reference's seeds), ``generator``, ``num_steps``, ``trajectory``, ``graph`` (hipGraph replay) and ``fused`` (default:
+        the whole loop is ONE library call, mc_sample_loop, with the per-step noise drawn on the device when no step_noise is
+        given; False: one mc_sample_step per step with torch.randn draws)."""
         self._check_supported(clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq, transl_req)
         return self._loop('ddpm', model, shape, noise, model_kwargs, device, progress, 0.0, step_noise, generator,
-                          num_steps, trajectory, pre_seq=pre_seq, transl_req=transl_req, graph=graph)
+                          num_steps, trajectory, pre_seq=pre_seq, transl_req=transl_req, graph=graph, fused=fused)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, pre_seq=None,
-                         step_noise=None, generator=None, num_steps=None, trajectory=None, graph=False):
+                         step_noise=None, generator=None, num_steps=None, trajectory=None, graph=False, fused=True):
         self._check_supported(clip_denoised, denoised_fn, cond_fn, model_kwargs, pre_seq)
         if self.opt is not None and getattr(self.opt, 'same_overlap_noisy', False):
             raise NotImplementedError('opt.same_overlap_noisy: the reference writes self.saved_noisy_tail '
                                       '(gaussian_diffusion.py:879-881) without ever creating it, so that option has '
                                       'no defined behaviour to reproduce')
         return self._loop('ddim', model, shape, noise, model_kwargs, device, progress, float(eta), step_noise,
-                          generator, num_steps, trajectory, pre_seq=pre_seq, graph=graph)
+                          generator, num_steps, trajectory, pre_seq=pre_seq, graph=graph, fused=fused)
 
 
 def get_schedule_jump_cjm_ddim(time_respacing=25, jump_length=1, jump_n_sample=1):

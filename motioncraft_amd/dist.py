@@ -44,18 +44,35 @@ def _bcast(t, src):
         dist.broadcast(t, src=src)
 
 
+def _scatter_rows(t, src):
+    """Rank `src` holds the global tensor `t` [B, ...]; every rank gets its own contiguous row block -- 1/W of the bytes per
+    link instead of the whole tensor to everyone (RCCL scatter = grouped send/recv over xGMI)."""
+    rank, ws = world()
+    lo, hi = shard_range(t.shape[0])
+    staged = t.is_cuda and not _device_collectives()
+    out = torch.empty((hi - lo,) + tuple(t.shape[1:]), dtype=t.dtype, device='cpu' if staged else t.device)
+    parts = None
+    if rank == src:
+        g = t.cpu() if staged else t
+        parts = [g[r * (hi - lo):(r + 1) * (hi - lo)].contiguous() for r in range(ws)]
+    dist.scatter(out, parts, src=src)
+    return out.to(t.device) if staged else out
+
+
 def broadcast_condition(xf_out, motion_mask, src=0, c=None):
     """Rank `src` holds the frozen condition embeddings of the GLOBAL batch; every rank returns its own slice.
-    Tensors on other ranks only need the right shape/dtype/device (contents are overwritten).
-    ``c``: the control condition of the S2G / M2D / mixed configs (encoded audio [B, Tc, D] = 1.2 MB per sample at 196
-    frames, or the raw music features [B, Tc, 35]); with it the return value is (xf, mask, c)."""
+    Tensors on other ranks only need the right shape/dtype/device.  The text embeddings and the mask (79 KB per sample) are
+    broadcast -- afterwards every rank holds the global tensors, which `sample_sharded` slices.  ``c``, the control condition
+    of the S2G / M2D / mixed configs (encoded audio [B, Tc, D] = 1.2 MB per sample at 196 frames: 308 MB at B = 256;
+    SURVEY.md section 2.2), is SCATTERED instead: each rank receives only its block (the global `c` stays valid on `src`
+    only); with it the return value is (xf, mask, c_local)."""
     if is_dist():
-        for t in (xf_out, motion_mask) + ((c,) if c is not None else ()):
+        for t in (xf_out, motion_mask):
             _bcast(t, src)
         lo, hi = shard_range(xf_out.shape[0])
         xf_out, motion_mask = xf_out[lo:hi].contiguous(), motion_mask[lo:hi].contiguous()
         if c is not None:
-            c = c[lo:hi].contiguous()
+            c = _scatter_rows(c, src)
     return (xf_out, motion_mask) if c is None else (xf_out, motion_mask, c)
 
 
@@ -74,14 +91,19 @@ def gather_results(local):
     return out.to(local.device)
 
 
-def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, c=None, **kwargs):
+def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, c=None, c_local=None, **kwargs):
     """Shard a global batch over the ranks, sample each shard through `arch` (MotionDiffusion
     mirror) and all-gather the poses.  `noise` / `step_noise` are GLOBAL tensors / callables
     returning global tensors (parity definition of SURVEY.md section 8e: each rank must match the
-    oracle run on its shard alone).  `c` = GLOBAL control condition (ControlT2MHalf), sharded like the batch."""
+    oracle run on its shard alone).  `c` = GLOBAL control condition (ControlT2MHalf), sharded like the batch; `c_local` = this
+    rank's block of it (what `broadcast_condition(..., c=)` returns: the control condition is scattered, not broadcast)."""
     lo, hi = shard_range(motion.shape[0])
     sl = slice(lo, hi)
-    if c is not None:
+    if c_local is not None:
+        if c_local.shape[0] != hi - lo:
+            raise ValueError(f'c_local has {c_local.shape[0]} samples, this rank owns {hi - lo}')
+        kwargs['c'] = c_local
+    elif c is not None:
         kwargs['c'] = c[sl]
     inf = dict(kwargs.pop('inference_kwargs', {}))
     if noise is not None:

@@ -88,6 +88,17 @@ class NativeContext:
         kernel's bounded grid barrier); the sampler loops call it once after the last step."""
         _lib.check(self.lib.mc_ctx_check(self.handle, _stream()), 'mc_ctx_check')
 
+    def profile(self, on=True):
+        """Bracket every FiLM out_layers GEMM launch with HIP events on its launch stream (bench.py's dominant-kernel figure)."""
+        _lib.check(self.lib.mc_ctx_profile(self.handle, int(bool(on))), 'mc_ctx_profile')
+
+    def profile_read(self, rows=0):
+        """(average duration in us, launches, algorithmic GFLOP per launch) of the bracketed launches (of `rows` rows if given)."""
+        us, n, gf = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
+        _lib.check(self.lib.mc_ctx_profile_read(self.handle, int(rows), ctypes.byref(us), ctypes.byref(n), ctypes.byref(gf)),
+                   'mc_ctx_profile_read')
+        return us.value, n.value, gf.value
+
     @property
     def uses_coop_routing(self):
         return bool(self.lib.mc_ctx_uses_coop_routing(self.handle))
@@ -174,6 +185,26 @@ class NativeContext:
         _lib.check(self.lib.mc_sample_step(self.handle, _ptr(x), int(step_index), ctypes.byref(coefs), _ptr(n),
                                            _ptr(x_prev), _ptr(x0), _stream()), 'mc_sample_step')
         return x_prev
+
+    def sample_loop(self, x, step_indices, coefs, noise=None, seed=0, draw0=0, x0=None):
+        """The whole sampler loop in one library call (mc_sample_loop): ``x`` [B,T,C] is updated IN PLACE through the schedule
+        indices ``step_indices`` with ``coefs[k]``; ``noise`` [len, B,T,C] = the per-step draws, or None: drawn on the device
+        (Philox4x32-10 keyed by ``seed``, draw index ``draw0 + k``).  Asynchronous on the current stream."""
+        x = _dev_f32(x, 'x')
+        if tuple(x.shape) != (self.B, self.T, self.C):
+            raise ValueError(f'x shape {tuple(x.shape)} != {(self.B, self.T, self.C)}')
+        n = len(step_indices)
+        if len(coefs) != n:
+            raise ValueError('one StepCoefs per step index')
+        if noise is not None:
+            noise = _dev_f32(noise, 'noise')
+            if tuple(noise.shape) != (n, self.B, self.T, self.C):
+                raise ValueError(f'noise shape {tuple(noise.shape)} != {(n, self.B, self.T, self.C)}')
+        idx = (ctypes.c_int32 * n)(*[int(i) for i in step_indices])
+        arr = (_lib.StepCoefs * n)(*coefs)
+        _lib.check(self.lib.mc_sample_loop(self.handle, _ptr(x), idx, arr, n, _ptr(noise), int(seed) & (2 ** 64 - 1),
+                                           int(draw0) & (2 ** 64 - 1), _ptr(x0), _stream()), 'mc_sample_loop')
+        return x
 
     def graph_capture(self, x, noise, coefs):
         """Capture mc_sample_step into ONE hipGraph for the whole schedule.  ``x`` [B,T,C] is updated in place by every

@@ -73,6 +73,9 @@ _SIGNATURES = {
     'mc_ctx_workspace_bytes': (ctypes.c_int64, [_P]),
     'mc_ctx_check': (ctypes.c_int, [_P, _P]),
     'mc_ctx_uses_coop_routing': (ctypes.c_int, [_P]),
+    'mc_ctx_profile': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'mc_ctx_profile_read': (ctypes.c_int, [_P, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32),
+                                           ctypes.POINTER(ctypes.c_double)]),
     'mc_ctx_enable_capture': (ctypes.c_int, [_P]),
     'mc_ctx_set_tie_policy': (ctypes.c_int, [_P, ctypes.c_int32]),
     'mc_ctx_set_precision': (ctypes.c_int, [_P, ctypes.c_int32]),
@@ -82,6 +85,9 @@ _SIGNATURES = {
     'mc_ctx_set_control': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'mc_denoise': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
     'mc_sample_step': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(StepCoefs), _P, _P, _P, _P]),
+    'mc_sample_loop': (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(StepCoefs), ctypes.c_int32, _P,
+                                      ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'mc_op_philox_normal': (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, _P]),
     'mc_ctx_graph_capture': (ctypes.c_int, [_P, _P, _P, ctypes.POINTER(StepCoefs), ctypes.c_int32, _P]),
     'mc_ctx_graph_step': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'mc_ctx_graph_release': (ctypes.c_int, [_P]),

@@ -53,7 +53,9 @@ def _worker(rank, ws, port, q):
         assert (lo, hi) == (rank * B // ws, (rank + 1) * B // ws)
         xs, ms, cs = mcd.broadcast_condition(xf, mask, src=0, c=c)
         assert torch.equal(xs, xf_src[lo:hi]) and torch.equal(ms, mask_src[lo:hi]) and torch.equal(cs, c_src[lo:hi])
-        out = mcd.sample_sharded(FakeArch(), torch.zeros(B, T, C), mask, xf, noise=noise, step_noise=steps, c=c)
+        if rank != 0:
+            assert bool(torch.isnan(c).all())              # the control condition is scattered: no global copy on the other ranks
+        out = mcd.sample_sharded(FakeArch(), torch.zeros(B, T, C), mask, xf, noise=noise, step_noise=steps, c_local=cs)
         ref = FakeArch()(None, mask_src, None, xf_src, dict(noise=noise, step_noise=steps), c=c_src)
         ref = torch.stack([r['pred_motion'] for r in ref])
         q.put((rank, bool(torch.equal(out, ref)), tuple(out.shape)))

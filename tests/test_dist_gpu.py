@@ -66,7 +66,7 @@ def _worker(rank, ws, port, q):
         assert torch.equal(xs.cpu(), xf_src[lo:hi]) and torch.equal(ms.cpu(), mask_src[lo:hi]) and torch.equal(cs.cpu(), c_src[lo:hi])
         S = 50
         out = mcd.sample_sharded(arch, torch.zeros(B, T, dims['input_feats']), mask.cpu(), xf.cpu(), noise=x_T,
-                                 step_noise=lambda i: steps[S - 1 - i], c=c.cpu(),
+                                 step_noise=lambda i: steps[S - 1 - i], c_local=cs.cpu(),
                                  motion_metas=[{'text': ''}] * (hi - lo), inference_kwargs=dict(num_steps=NSTEPS))
         # the oracle on this rank's shard alone
         sched = O.Schedule(1000, '15,15,8,6,6')

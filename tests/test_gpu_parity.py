@@ -1566,6 +1566,117 @@ print('fallback ok')
     assert r.returncode == 0 and 'fallback ok' in r.stdout, r.stdout + r.stderr
 
 
+def test_device_noise_stream_bits_and_statistics():
+    """The fused sampler loop draws its per-step noise on the device (Philox4x32-10 + Box-Muller inside sampler_update_k).
+    mc_op_philox_normal exposes the same stream: raw words bit-identical to oracle/philox_oracle.py (itself pinned by the
+    published known-answer vectors), normals equal to the fp64 Box-Muller of those words within fp32 round-off, and the usual
+    battery on 2^24 normals: moments, tail mass, Kolmogorov-Smirnov against the normal CDF, serial and cross-draw correlation."""
+    from scipy import stats
+    from motioncraft_amd import lib as L_
+    from oracle import philox_oracle as P
+    lib = L_.load(require_gpu=True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    seed, draw = 0x9e3779b97f4a7c15, (3 << 32) | 41
+    for n in (1, 5, 4096 + 3):
+        z = torch.full((n + 8,), float('nan'), device='cuda')
+        bits = torch.zeros(n + 8, dtype=torch.int32, device='cuda')
+        L_.check(lib.mc_op_philox_normal(ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(bits.data_ptr()), n, seed, draw, st))
+        torch.cuda.synchronize()
+        assert np.array_equal(bits[:n].cpu().numpy().view(np.uint32), P.draw_bits(n, seed, draw))
+        assert int((bits[n:] != 0).sum()) == 0 and bool(torch.isnan(z[n:]).all())             # nothing past n
+        ref = P.draw_normal(n, seed, draw, dtype=np.float64)
+        assert np.abs(z[:n].cpu().numpy().astype(np.float64) - ref).max() <= 4e-6
+    n = 1 << 24
+    z = torch.empty(n, device='cuda')
+    z2 = torch.empty(n, device='cuda')
+    L_.check(lib.mc_op_philox_normal(ctypes.c_void_p(z.data_ptr()), None, n, seed, 0, st))
+    L_.check(lib.mc_op_philox_normal(ctypes.c_void_p(z2.data_ptr()), None, n, seed, 1, st))
+    torch.cuda.synchronize()
+    a, b = z.double(), z2.double()
+    se = 1.0 / n ** 0.5
+    assert abs(float(a.mean())) < 5 * se and abs(float(a.var()) - 1) < 5 * 2 ** 0.5 * se
+    assert abs(float((a ** 3).mean())) < 5 * 15 ** 0.5 * se and abs(float((a ** 4).mean()) - 3) < 5 * 96 ** 0.5 * se
+    for k, p in ((2.0, 0.04550026), (3.0, 0.002699796), (4.0, 6.334248e-5)):
+        frac = float((a.abs() > k).double().mean())
+        assert abs(frac - p) < 5 * (p * (1 - p) / n) ** 0.5, (k, frac, p)
+    assert float(a.abs().max()) < 6.8
+    assert abs(float((a[:-1] * a[1:]).mean())) < 5 * se and abs(float((a[:-4] * a[4:]).mean())) < 5 * se      # inside / across blocks
+    assert abs(float((a * b).mean())) < 5 * se                                                                  # draw 0 vs draw 1
+    ks = stats.kstest(a[::16].cpu().numpy(), 'norm')
+    assert ks.pvalue > 1e-3, ks
+    print(f'device Philox normals, n = 2^24: mean {float(a.mean()):+.2e} var {float(a.var()):.5f} kurt {float((a ** 4).mean()):.4f} '
+          f'max |z| {float(a.abs().max()):.2f} KS p = {ks.pvalue:.3f}')
+
+
+@pytest.mark.parametrize('mode', ['ddpm', 'ddim'])
+def test_fused_sampler_loop_equals_the_per_step_path(small_model, mode):
+    """mc_sample_loop (the whole p_sample_loop / ddim_sample_loop in one C-ABI call, x updated in place) against one
+    mc_sample_step per step from Python: bit-identical when both read the same noise tensors, and -- with the noise drawn
+    inside the sampler kernel (Philox) -- bit-identical to the per-step path fed the draws mc_op_philox_normal writes out.
+    Through the reference API: p_sample_loop / ddim_sample_loop(generator=...) run the fused loop and reproduce under the
+    generator's seed; fused=False keeps the torch.randn per-step path."""
+    from motioncraft_amd import lib as L_
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = small_model
+    lib = L_.load(require_gpu=True)
+    B, T, C = 3, 24, SMALL['input_feats']
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large',
+                             **({'respace': '15,15,8,6,6'} if mode == 'ddim' else {})))
+    x_T, xf, mask = synth_inputs(SMALL, B, T, seed=12, lengths=[24, 17, 9])
+    ctx = nm.context(B, T, max_steps=len(d.timestep_map))
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    idx = list(range(len(d.timestep_map) - 1, len(d.timestep_map) - 13, -1)) if mode == 'ddpm' else list(range(49, -1, -1))
+    coefs = [d.step_coefs(i, mode, SMALL['scale'], 0.0) for i in idx]
+    g = torch.Generator().manual_seed(5)
+    nz = torch.randn(len(idx), B, T, C, generator=g).cuda()
+
+    def per_step(noises):
+        x = x_T.cuda().clone()
+        for k, i in enumerate(idx):
+            x = ctx.sample_step(x, i, coefs[k], noises[k].contiguous())
+        return x
+    ref = per_step(nz)
+    x = x_T.cuda().clone()
+    x0 = torch.empty_like(x)
+    ctx.sample_loop(x, idx, coefs, noise=nz, x0=x0)
+    assert torch.equal(x, ref)
+    assert bool(torch.isfinite(x0).all())
+    # device noise: same bits as the per-step path on the written-out stream
+    seed, draw0 = 77, 1000
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pz = torch.empty(len(idx), B, T, C, device='cuda')
+    for k in range(len(idx)):
+        L_.check(lib.mc_op_philox_normal(ctypes.c_void_p(pz[k].data_ptr()), None, B * T * C, seed, draw0 + k, st))
+    x = x_T.cuda().clone()
+    ctx.sample_loop(x, idx, coefs, noise=None, seed=seed, draw0=draw0)
+    assert torch.equal(x, per_step(pz))
+    ctx.close()
+
+    # through the reference API
+    class _M:      # the two things the loops ask of the model wrapper
+        cfg_scale = SMALL['scale']
+
+        def sampling_context(self, B_, T_, tmap, kw, dev):
+            c = nm.context(B_, T_, max_steps=len(tmap))
+            c.set_timesteps(tmap)
+            c.set_condition(xf.cuda(), mask.cuda())
+            return c
+    loop = d.p_sample_loop if mode == 'ddpm' else d.ddim_sample_loop
+    kw = dict(noise=x_T, num_steps=8, clip_denoised=False)
+    a = loop(_M(), (B, T, C), generator=torch.Generator().manual_seed(3), **kw)
+    b = loop(_M(), (B, T, C), generator=torch.Generator().manual_seed(3), **kw)
+    c = loop(_M(), (B, T, C), generator=torch.Generator().manual_seed(4), **kw)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    if mode == 'ddpm':
+        assert not torch.equal(a, c)                                # (eta = 0 DDIM does not use the draws)
+    # fused with step_noise == per-step with step_noise
+    sn = [torch.randn(B, T, C, generator=torch.Generator().manual_seed(100 + i)) for i in range(len(d.timestep_map))]
+    f1 = loop(_M(), (B, T, C), step_noise=sn, **kw)
+    f0 = loop(_M(), (B, T, C), step_noise=sn, fused=False, **kw)
+    assert torch.equal(f1, f0)
+
+
 def test_control_branch_without_condition_cfg_vs_oracle():
     """condition_encode_cfg.condition_cfg=False: the control condition also drives the unconditional CFG half
     (controlnet.py forward_test: `c * cond_type` only when condition_cfg)."""

@@ -303,3 +303,25 @@ def test_t2m_evaluator_against_reference_golden():
     om = TO.encode_motion(sd, T_(g['motion']), torch.from_numpy(g['lengths']))
     ot = TO.encode_text(sd, T_(g['word_emb']), T_(g['pos_onehot']), torch.from_numpy(g['sent_len']))
     assert maxabs(om, T_(g['motion_emb'])) <= 1e-5 and maxabs(ot, T_(g['text_emb'])) <= 1e-5
+
+
+def test_philox_restatement_against_the_published_known_answer_vectors():
+    """oracle/philox_oracle.py (the CPU restatement of the library's device noise stream) vs the Random123 known-answer vectors
+    of Philox4x32-10, and the moments of the Box-Muller normals built on it."""
+    import numpy as np
+    from oracle import philox_oracle as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = P.philox4x32_10(np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32))
+        assert tuple(int(v) for v in got) == want
+    # counter layout of a draw: block g of draw d under seed s = philox((g_lo, g_hi, d_lo, d_hi), (s_lo, s_hi))
+    seed, d = 0x0123456789abcdef, (5 << 32) | 7
+    b = P.draw_bits(12, seed, d)
+    for g in range(3):
+        want = P.philox4x32_10(np.array([g, 0, 7, 5], dtype=np.uint32), np.array([0x89abcdef, 0x01234567], dtype=np.uint32))
+        assert (b[4 * g:4 * g + 4] == want).all()
+    z = P.draw_normal(2_000_000, 99, 3, dtype=np.float64)
+    assert abs(z.mean()) < 4e-3 and abs(z.var() - 1) < 6e-3 and abs((z ** 3).mean()) < 1.2e-2 and abs((z ** 4).mean() - 3) < 4e-2
+    assert not np.array_equal(P.draw_bits(64, 99, 3), P.draw_bits(64, 99, 4)) and not np.array_equal(P.draw_bits(64, 99, 3), P.draw_bits(64, 98, 3))

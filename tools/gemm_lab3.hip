@@ -35,22 +35,23 @@ struct SkArgs {
     unsigned long long* stamp;   // optional: [G][4] cycles: start, end, wait cycles, (unused)
 };
 
-constexpr int SKK = 16, SK_STAGE = 512 * SKK;
+constexpr int SKK = 16;
 enum { O_STREAMK = 1, O_MFMA_FIRST = 2 };
 
-template <int NST, int OPT>
-__global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
+// BN = 256: 8 waves, one workgroup per CU.  BN = 128: 4 waves (2 x 2 of 128 x 64), 72 KB of LDS at 3 stages -> TWO workgroups
+// per CU with their own barriers: while one sits at its k-tile barrier or in its epilogue the other owns the MFMA pipes.
+template <int NST, int OPT, int BN>
+__global__ __launch_bounds__(BN * 2, 2) void gemm_sk_k(SkArgs g) {
+    constexpr int NWN = BN / 64, NW = 2 * NWN, SROWS = 256 + BN, SK_STAGE = SROWS * SKK, PPW = SROWS / 16 / NW;
     __shared__ __attribute__((aligned(16))) float smem[NST * SK_STAGE + 16];
     int* sm_i = reinterpret_cast<int*>(smem + NST * SK_STAGE);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / NWN, wn = wave % NWN;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int G = (int)gridDim.x;
-    const int ntn = g.N / 256, ntm = (g.M + 255) / 256, ntiles = ntm * ntn, nk = g.K / SKK;
+    const int ntn = g.N / BN, ntm = (g.M + 255) / 256, ntiles = ntm * ntn, nk = g.K / SKK;
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int dr = lane >> 2, dc = ((lane & 3) ^ ((dr >> 2) & 3)) * 4;
     const int frow = lane & 31, hf = lane >> 5, sw = (frow >> 2) & 3;
-    const float* gsrc = wave_u < 4 ? g.A : g.W;
-    const long gld = wave_u < 4 ? g.lda : g.ldw;
     unsigned long long t_start = 0, t_wait = 0;
     if (g.stamp) t_start = __builtin_amdgcn_s_memtime();
     // virtual worker id: tickets are drawn in start order, so worker v + 1 has started (or starts as soon as a slot frees)
@@ -80,26 +81,29 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
             for (int ni = 0; ni < 2; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[ni][i], f.a[mi][i], acc[mi][ni], 0, 0, 0);
     };
-    auto wait_dyn = [&](int stages_after) {      // this wave's DMAs of the needed stage have landed when <= 4 x stages_after are in flight
-        if (stages_after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (stages_after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    auto wait_dyn = [&](int stages_after) {      // this wave's DMAs of the needed stage have landed when <= PPW x stages_after are in flight
+        if (stages_after >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");
+        else if (stages_after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     auto segment = [&](int tile, int kb, int ke) {
-        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * 256;
+        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * BN;
         const int n = ke - kb;
-        unsigned vo[4];
+        // DMA pieces of 16 rows: stage rows [0, 256) = A rows, [256, 256 + BN) = W rows; wave w moves pieces PPW w .. PPW w + PPW - 1
+        unsigned vo[PPW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int piece = 4 * (wave_u & 3) + q;
-            long grow = (wave_u < 4 ? row0 : col0) + 16 * piece + dr;
-            if (wave_u < 4 && grow >= g.M) grow = g.M - 1;          // ragged last row tile: re-read the last row (never stored)
-            vo[q] = (unsigned)((grow * gld + dc) * 4);
+        for (int q = 0; q < PPW; ++q) {
+            const int piece = PPW * wave_u + q;
+            const bool isA = piece < 16;
+            long grow = isA ? row0 + 16 * piece + dr : col0 + 16 * (piece - 16) + dr;
+            if (isA && grow >= g.M) grow = g.M - 1;                  // ragged last row tile: re-read the last row (never stored)
+            vo[q] = (unsigned)((grow * (isA ? g.lda : g.ldw) + dc) * 4);
         }
         auto issue_q = [&](int j, int q) {
-            const unsigned l = lds0 + (unsigned)(j % NST) * (SK_STAGE * 4) + (unsigned)(4 * wave_u + q) * 1024;
-            dma16(vo[q], gsrc + (long)(kb + j) * SKK, l);
+            const int piece = PPW * wave_u + q;
+            const unsigned l = lds0 + (unsigned)(j % NST) * (SK_STAGE * 4) + (unsigned)piece * 1024;
+            dma16(vo[q], (piece < 16 ? g.A : g.W) + (long)(kb + j) * SKK, l);
         };
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
         const int pre = n < NST - 1 ? n : NST - 1;
         for (int j = 0; j < pre; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) issue_q(j, q);
+            for (int q = 0; q < PPW; ++q) issue_q(j, q);
         wait_dyn(pre - 1);
         __syncthreads();
         Frag f0 = ld_frag(0, 0), f1;
@@ -123,11 +127,17 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
             if constexpr (OPT & O_MFMA_FIRST) {
                 mma_i(f0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) { issue_q(j + NST - 1, 0); issue_q(j + NST - 1, 1); }
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < PPW / 2; ++q) issue_q(j + NST - 1, q);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mma_i(f0, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) { issue_q(j + NST - 1, 2); issue_q(j + NST - 1, 3); }
+                if (more) {
+#pragma unroll
+                    for (int q = PPW / 2; q < PPW; ++q) issue_q(j + NST - 1, q);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mma_i(f0, 2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
             } else {
                 if (more) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) issue_q(j + NST - 1, q);
+                    for (int q = 0; q < PPW; ++q) issue_q(j + NST - 1, q);
                 }
                 f1 = ld_frag(j, 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
     };
 
     auto epilogue = [&](int tile) {
-        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * 256;
+        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * BN;
         // software pipeline over the 8 (mi, ni) blocks of 4 float4: the residual of block b+1 is requested before block b is
         // finished and stored (16 + 16 registers beside the 128 accumulators)
         auto load_res = [&](int b, f32x4 (&rv)[4]) {
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
             segment(tile, kb, ke);
             if (kb > 0) {
                 // non-head part of a tile: the accumulators go to this worker's slab, lane-linear (1 KiB per wave-instruction)
-                f32x4* s4 = reinterpret_cast<f32x4*>(g.slab) + ((long)v * 8 + wave) * 32 * 64 + lane;
+                f32x4* s4 = reinterpret_cast<f32x4*>(g.slab) + ((long)v * NW + wave) * 32 * 64 + lane;
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sk_k(SkArgs g) {
                     }
                     __syncthreads();
                     if (g.stamp) t_wait += __builtin_amdgcn_s_memtime() - w0;
-                    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.slab) + ((long)u * 8 + wave) * 32 * 64 + lane;
+                    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.slab) + ((long)u * NW + wave) * 32 * 64 + lane;
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {              // 8 loads in flight at a time (32 registers beside the accumulators)
                         f32x4 p[8];
@@ -408,10 +418,11 @@ static void compare(int M, int N, const char* what) {
     printf("      %s vs wp_k: max abs diff %.3e (max |C| %.2f), %zu of %zu elements differ\n", what, worst, ref, ndiff, a.size());
 }
 
-template <int NST, int OPT>
+template <int NST, int OPT, int BN = 256>
 static void run_sk(const char* name, int M, int N, int K, bool res, bool cmp, bool warm = true) {
     SkArgs g{dA, dW, dB, res ? dR : nullptr, dC, M, N, K, K, K, N, N, dSlab, dSync, nullptr};
-    auto launch = [&]() { hipLaunchKernelGGL((gemm_sk_k<NST, OPT>), dim3(NCU), dim3(512), 0, 0, g); };
+    const int GRID = NCU * (BN == 128 ? 2 : 1);
+    auto launch = [&]() { hipLaunchKernelGGL((gemm_sk_k<NST, OPT, BN>), dim3(GRID), dim3(BN * 2), 0, 0, g); };
     if (warm) for (int r = 0; r < 40; ++r) launch();
     const float ms = time_it(launch);
     const double tf = 2.0 * M * N * K / ms / 1e9;
@@ -419,16 +430,16 @@ static void run_sk(const char* name, int M, int N, int K, bool res, bool cmp, bo
     g.stamp = dStamp;
     launch();
     hipDeviceSynchronize();
-    std::vector<unsigned long long> st(4 * NCU);
+    std::vector<unsigned long long> st(4 * GRID);
     hipMemcpy(st.data(), dStamp, st.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull, t1 = 0; double wsum = 0, wmax = 0, dsum = 0, dmin = 1e30, dmax = 0;
-    for (int v = 0; v < NCU; ++v) {
+    for (int v = 0; v < GRID; ++v) {
         t0 = std::min(t0, st[4 * v]); t1 = std::max(t1, st[4 * v + 1]); wsum += st[4 * v + 2]; wmax = std::max(wmax, (double)st[4 * v + 2]);
         const double d = double(st[4 * v + 1] - st[4 * v]); dsum += d; dmin = std::min(dmin, d); dmax = std::max(dmax, d);
     }
     const double ideal = 2.0 * M * N * K / (NCU * 4 * 4096.0) * 64.0;        // MFMA-bound cycles per CU (4 SIMDs)
-    printf("      span %llu cyc; worker cycles mean %.0f min %.0f max %.0f (MFMA-bound %.0f = %.1f %%); slab wait mean %.0f max %.0f cyc\n", t1 - t0,
-           dsum / NCU, dmin, dmax, ideal, ideal / (dsum / NCU) * 100, wsum / NCU, wmax);
+    printf("      span %llu cyc; worker cycles mean %.0f min %.0f max %.0f (MFMA-bound per CU %.0f = %.1f %% of the span); slab wait mean %.0f max %.0f cyc\n", t1 - t0,
+           dsum / GRID, dmin, dmax, ideal, ideal / double(t1 - t0) * 100, wsum / GRID, wmax);
     if (cmp) compare(M, N, name);
     if (K == 1536 && res && (M == 25000 || cmp)) {
         // rows past M must be untouched: poison the tail of dC first
@@ -454,7 +465,8 @@ static void run_wp(int M, int N, int K, bool res) {
     printf("wp_k  %-52s %6dx%4dx%4d: %8.1f us %6.1f TF (%5.1f %%)\n", res ? "bias + residual" : "bias", M, N, K, ms * 1e3, tf, tf / 1.573);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool pmc = argc > 1;      // any argument: a short pass for rocprofv3 --pmc (few launches per variant)
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     NCU = prop.multiProcessorCount;
@@ -462,34 +474,49 @@ int main() {
     const size_t MMAX = 32768, NMAX = 4096, KMAX = 4096;
     hipMalloc(&dA, MMAX * KMAX * 4); hipMalloc(&dW, NMAX * KMAX * 4); hipMalloc(&dB, NMAX * 4);
     hipMalloc(&dR, MMAX * NMAX * 4); hipMalloc(&dC, MMAX * NMAX * 4); hipMalloc(&dC2, MMAX * NMAX * 4);
-    hipMalloc(&dSlab, (size_t)NCU * 8 * 32 * 64 * 16); hipMalloc(&dSync, (2 + NCU) * 4); hipMalloc(&dStamp, NCU * 32);
-    hipMemset(dSync, 0, (2 + NCU) * 4);
+    hipMalloc(&dSlab, (size_t)NCU * 8 * 32 * 64 * 16); hipMalloc(&dSync, (2 + 2 * NCU) * 4); hipMalloc(&dStamp, 2 * NCU * 32);
+    hipMemset(dSync, 0, (2 + 2 * NCU) * 4);
     hA.resize(MMAX * 1536); hR.resize(MMAX * 1536); hW.resize(NMAX * KMAX); hB.resize(NMAX);
     srand(1);
-    for (auto& x : hA) x = (float)rand() / RAND_MAX * 2.f - 1.f;
-    for (auto& x : hR) x = (float)rand() / RAND_MAX * 2.f - 1.f;
-    for (auto& x : hW) x = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
-    for (auto& x : hB) x = (float)rand() / RAND_MAX * 2.f - 1.f;
+    auto gauss = [] {      // N(0, 1): what torch.randn operands (tools/gemm_ab.py) and the model's LayerNormed activations look like
+        const double u1 = (rand() + 1.0) / (RAND_MAX + 2.0), u2 = (rand() + 1.0) / (RAND_MAX + 2.0);
+        return (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+    };
+    for (auto& x : hA) x = gauss();
+    for (auto& x : hR) x = gauss();
+    for (auto& x : hW) x = gauss() * 0.0255f;          // 1 / sqrt(1536)
+    for (auto& x : hB) x = gauss();
     hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dR, hR.data(), hR.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+    if (pmc) {
+        for (int M : {32768, 25088}) {
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(wp_k, dim3((M / 128) * 12), dim3(256), 0, 0, dA, dW, dB, dR, dC2, M, 1536, 1536);
+            SkArgs g{dA, dW, dB, dR, dC, M, 1536, 1536, 1536, 1536, 1536, 1536, dSlab, dSync, nullptr};
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((gemm_sk_k<4, 3, 256>), dim3(NCU), dim3(512), 0, 0, g);
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((gemm_sk_k<3, 3, 128>), dim3(2 * NCU), dim3(256), 0, 0, g);
+            for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((gemm_sk_k<3, 2, 128>), dim3(2 * NCU), dim3(256), 0, 0, g);
+            hipDeviceSynchronize();
+        }
+        return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         printf("---- pass %d\n", pass);
         for (int M : {25088, 12544, 32768, 6272, 25000}) {
             if (M % 128 == 0) run_wp(M, 1536, 1536, true);
             const bool cmp = pass == 0 && M % 128 == 0;
-            run_sk<4, O_STREAMK | O_MFMA_FIRST>("stream-K, 4 stages, MFMA first", M, 1536, 1536, true, cmp);
-            run_sk<3, O_STREAMK | O_MFMA_FIRST>("stream-K, 3 stages, MFMA first", M, 1536, 1536, true, false);
-            run_sk<4, O_STREAMK>("stream-K, 4 stages, loads first", M, 1536, 1536, true, false);
-            if (M % 256 == 0) run_sk<4, O_MFMA_FIRST>("tile round-robin, 4 stages, MFMA first", M, 1536, 1536, true, cmp);
+            run_sk<4, O_STREAMK | O_MFMA_FIRST, 256>("256x256 x 8 waves, stream-K, 4 stages", M, 1536, 1536, true, false);
+            run_sk<3, O_STREAMK | O_MFMA_FIRST, 128>("256x128 x 4 waves x 2 WG/CU, stream-K, 3 stages", M, 1536, 1536, true, cmp);
+            run_sk<3, O_STREAMK, 128>("256x128 x 4 waves x 2 WG/CU, stream-K, 3 stages, loads first", M, 1536, 1536, true, false);
+            if (M % 256 == 0) run_sk<3, O_MFMA_FIRST, 128>("256x128 x 4 waves x 2 WG/CU, tile round-robin", M, 1536, 1536, true, cmp);
         }
         // determinism: two launches, bit-identical
         {
             SkArgs g{dA, dW, dB, dR, dC, 25088, 1536, 1536, 1536, 1536, 1536, 1536, dSlab, dSync, nullptr};
-            hipLaunchKernelGGL((gemm_sk_k<4, 3>), dim3(NCU), dim3(512), 0, 0, g);
+            hipLaunchKernelGGL((gemm_sk_k<3, 3, 128>), dim3(2 * NCU), dim3(256), 0, 0, g);
             g.C = dC2;
-            hipLaunchKernelGGL((gemm_sk_k<4, 3>), dim3(NCU), dim3(512), 0, 0, g);
+            hipLaunchKernelGGL((gemm_sk_k<3, 3, 128>), dim3(2 * NCU), dim3(256), 0, 0, g);
             hipDeviceSynchronize();
             compare(25088, 1536, "run-to-run (stream-K twice)");
         }
@@ -497,9 +524,9 @@ int main() {
     printf("---- 4096^3 (no residual)\n");
     for (int pass = 0; pass < 2; ++pass) {
         run_wp(4096, 4096, 4096, false);
-        run_sk<4, O_STREAMK | O_MFMA_FIRST>("stream-K, 4 stages, MFMA first", 4096, 4096, 4096, false, pass == 0);
-        run_sk<3, O_STREAMK | O_MFMA_FIRST>("stream-K, 3 stages, MFMA first", 4096, 4096, 4096, false, false);
-        run_sk<4, O_STREAMK>("stream-K, 4 stages, loads first", 4096, 4096, 4096, false, false);
+        run_sk<4, O_STREAMK | O_MFMA_FIRST, 256>("256x256 x 8 waves, stream-K, 4 stages", 4096, 4096, 4096, false, pass == 0);
+        run_sk<3, O_STREAMK | O_MFMA_FIRST, 128>("256x128 x 4 waves x 2 WG/CU, stream-K, 3 stages", 4096, 4096, 4096, false, pass == 0);
+        run_sk<3, O_STREAMK, 128>("256x128 x 4 waves x 2 WG/CU, stream-K, loads first", 4096, 4096, 4096, false, false);
     }
     return 0;
 }
