@@ -265,7 +265,7 @@ def main():
         us, cnt, gf = ctx.profile_read()
         ctx.profile(False)
         if cnt:
-            tf = gf / us * 1e-3
+            tf = gf / us * 1e3          # GFLOP / us = PFLOP/s
             dom = {'kernel': 'gemm_wp_k (fp32 MFMA, wave-private LDS-DMA pipeline): the FiLM out_layers GEMMs h += a W^T + b as the step '
                              f'launches them (one launch per sample group: {int(round(gf * 1e9 / (2 * D * D)))} rows x {D} x {D}, bias + residual)',
                    'launches_timed': cnt, 'avg_us': round(us, 1), 'gflop_per_launch': round(gf, 2), 'achieved': round(tf, 2),

@@ -132,6 +132,9 @@ int mc_ctx_check(mc_ctx* c, void* stream);
  * algorithmic GFLOP of one launch (2 rows D^2); rows_filter > 0 keeps only launches of that many rows. */
 int mc_ctx_profile(mc_ctx* c, int32_t on);
 int mc_ctx_profile_read(mc_ctx* c, int64_t rows_filter, double* avg_us, int32_t* count, double* gflop_per_launch);
+/* the precision the per-step kernels of this context actually run in: MC_PREC_F32 also when a reduced-precision mode is set but
+ * the batch is at most MC_HALF_MIN_ROWS (512) residual rows, where the fp32 small-batch kernels are the faster ones (B = 1) */
+int mc_ctx_effective_precision(const mc_ctx* c);
 /* 1 if this context routes its layers with the one-launch cooperative kernel (0: one-workgroup kernels or the launch sequence) */
 int mc_ctx_uses_coop_routing(const mc_ctx* c);
 /* tests: keep the routing decisions (expert ids, combine weights; 0 = dropped) of every layer of the

@@ -10,6 +10,7 @@
 //   fh   [rows, H*F]    SFFN hidden                             out2 [rows, C]  pose decoder output
 //   tf[layer] [B2*Nt, 2L]  step-invariant text K/V              ss[layer][blk][S][2D] FiLM scale|shift
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,8 @@ struct mc_model {
     mc_model_config cfg;
     std::map<std::string, std::pair<float*, int64_t>> params;
     std::map<std::string, HalfW> half;     // built on the first mc_ctx_set_precision(.., MC_PREC_F16*) (shared by all contexts)
+    std::mutex half_mu;                    // guards `half` (filled from per-context calls)
+    size_t half_bytes = 0;                 // device bytes of the fp16 hi / lo planes (reported by mc_ctx_workspace_bytes of a reduced-precision context)
     bool finalized = false;
     int Cp = 0;  // input_feats padded to a multiple of 32 (row stride of enc.w and of the padded pose rows)
 };
@@ -248,6 +251,9 @@ int build_ctx_weights(mc_ctx* c) {
 // fp16 hi / lo planes of weight `name` ([rows][K] fp32 on the device), built once per model; chain = K axis stored in the
 // chain-permuted order of mc_half.h (second GEMM of the fused MLP)
 int half_weight(mc_model* m, const std::string& name, long rows, int K, bool chain, HalfW* out) {
+    // the plane cache belongs to the MODEL and is filled from per-context calls (mc_ctx_set_precision): one lock per model, so two
+    // contexts switching precision from two threads build each plane once
+    std::lock_guard<std::mutex> lock(m->half_mu);
     auto it = m->half.find(name);
     if (it != m->half.end()) { *out = it->second; return MC_OK; }
     const float* src = nullptr;
@@ -260,6 +266,7 @@ int half_weight(mc_model* m, const std::string& name, long rows, int K, bool cha
     if (r != MC_OK) { (void)hipFree(h.hi); return r; }
     MC_HIP(hipStreamSynchronize(nullptr));
     m->half[name] = h;
+    m->half_bytes += sizeof(mc_half) * 2 * (size_t)rows * K;
     *out = h;
     return MC_OK;
 }
@@ -775,7 +782,12 @@ int mc_model_set_param(mc_model* m, const char* name, const float* host, int64_t
     MC_HIP(hipMalloc(&d, (size_t)numel * sizeof(float)));
     MC_HIP(hipMemcpy(d, host, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
     auto it = m->params.find(name);
-    if (it != m->params.end()) (void)hipFree(it->second.first);
+    if (it != m->params.end()) {
+        // replacing a weight of a finalized model: contexts hold raw pointers into the old allocation and the fp16 planes built from it
+        // would go stale -- the model is immutable once contexts can exist (build a new model for new weights)
+        MC_REQUIRE(!m->finalized, "mc_model_set_param(%s): the model is finalized; weights are immutable from then on", name);
+        (void)hipFree(it->second.first);
+    }
     m->params[name] = std::make_pair(d, numel);
     return MC_OK;
 }
@@ -919,7 +931,7 @@ void mc_ctx_destroy(mc_ctx* c) {
     delete c;
 }
 
-int64_t mc_ctx_workspace_bytes(const mc_ctx* c) { return c ? c->bytes : 0; }
+int64_t mc_ctx_workspace_bytes(const mc_ctx* c) { return c ? (int64_t)(c->bytes + (c->prec != MC_PREC_F32 ? c->m->half_bytes : 0)) : 0; }
 
 int mc_ctx_check(mc_ctx* c, void* stream) {
     MC_REQUIRE(c, "null context");
@@ -934,6 +946,8 @@ int mc_ctx_check(mc_ctx* c, void* stream) {
     }
     return MC_OK;
 }
+
+int mc_ctx_effective_precision(const mc_ctx* c) { return c ? (use_half(c) ? c->prec : MC_PREC_F32) : MC_PREC_F32; }
 
 int mc_ctx_uses_coop_routing(const mc_ctx* c) { return c && c->coop_reserved > 0 ? 1 : 0; }
 

@@ -100,6 +100,12 @@ class NativeContext:
         return us.value, n.value, gf.value
 
     @property
+    def effective_precision(self):
+        """'f32' / 'f16' / 'f16x3' the per-step kernels really run in (a reduced-precision mode falls back to the fp32 small-batch
+        kernels up to 512 residual rows, i.e. B = 1 at 196 frames)."""
+        return {0: 'f32', 1: 'f16', 2: 'f16x3'}[int(self.lib.mc_ctx_effective_precision(self.handle))]
+
+    @property
     def uses_coop_routing(self):
         return bool(self.lib.mc_ctx_uses_coop_routing(self.handle))
 

@@ -73,6 +73,7 @@ _SIGNATURES = {
     'mc_ctx_workspace_bytes': (ctypes.c_int64, [_P]),
     'mc_ctx_check': (ctypes.c_int, [_P, _P]),
     'mc_ctx_uses_coop_routing': (ctypes.c_int, [_P]),
+    'mc_ctx_effective_precision': (ctypes.c_int, [_P]),
     'mc_ctx_profile': (ctypes.c_int, [_P, ctypes.c_int32]),
     'mc_ctx_profile_read': (ctypes.c_int, [_P, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32),
                                            ctypes.POINTER(ctypes.c_double)]),

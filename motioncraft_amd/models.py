@@ -338,7 +338,12 @@ def wrap_fp16_model(model, split=True):
     is not None: wrap_fp16_model(model)``): switches the per-step GEMM-shaped kernels of the denoiser to the fp16 MFMA.
     ``split=True`` (default) keeps fp32-class results (operands split hi + lo, three products, fp32 accumulate:
     'f16x3'); ``split=False`` is the single-rounding fp16 form mmcv's wrapper produces ('f16').  The gate, routing and
-    every normalisation stay fp32 either way.  Accepts a MotionDiffusion, a STMoGenTransformer or a ControlT2MHalf."""
+    every normalisation stay fp32 either way.  Accepts a MotionDiffusion, a STMoGenTransformer or a ControlT2MHalf.
+
+    Two differences from mmcv's wrapper to be aware of: (1) the DEFAULT here is the split form, which is NOT the numerics of
+    mmcv's single-rounding fp16 -- pass ``split=False`` to validate against an fp16 reference run; (2) up to 512 residual rows
+    (2 B T; B = 1 at 196 frames) a reduced-precision context runs the fp32 small-batch kernels, which are faster there, so a
+    B = 1 benchmark of 'fp16' exercises the fp32 path -- ``NativeContext.effective_precision`` reports what really runs."""
     target = getattr(model, 'model', model)
     target = getattr(target, 'base_model', target)
     if not hasattr(target, 'precision'):
