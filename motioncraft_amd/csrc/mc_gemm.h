@@ -39,6 +39,8 @@ struct GemmArgs {
     const int* src_row = nullptr;
     const int* dst_row = nullptr;
     const float* comb_w = nullptr;  // [M][2]
+    float* sk_slab = nullptr;       // stream-K workspace (set by the launcher): per-worker accumulator slabs
+    int* sk_sync = nullptr;         //   [0] ticket, [1] done, [2 + v] slab-ready flag of worker v
     int tune = 0;                   // MC_GEMM_TUNE bits (set by the launcher): 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k
 };
 

@@ -601,6 +601,48 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
+def test_stream_k_gemm_vs_fp64_and_the_tile_kernels():
+    """gemm_sk_k (256 x 256 stream-K tiles; the default for plain GEMMs with K >= 2048 and >= 128 tiles, forced here by
+    MC_GEMM_TUNE bit 7 in a child process -- the variant is chosen at library load) through mc_op_gemm: vs a float64 product on
+    sampled rows, deterministic run to run, activation + bias + residual epilogue, shapes whose tiles are cut by the range
+    borders once / twice / never (25088 x 1536: 2.3 tiles per worker; 1280 x 768: 15 tiles on 256 workers = every tile in ~17
+    parts; 4096^2 x 2048: exactly 1 tile each), K = 16 (one k-tile) and the default selection rule."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, sys, torch
+from motioncraft_amd import lib as L_
+lib = L_.load(require_gpu=True)
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+g = torch.Generator(device='cuda').manual_seed(3)
+for (M, N, K, act, res) in [(25088, 1536, 1536, 0, True), (1280, 768, 528, 1, True), (4096, 4096, 2048, 0, False), (256, 256, 16, 2, True),
+                            (12544, 1536, 1536, 0, True), (384, 512, 4096, 0, False)]:
+    a = torch.randn(M, K, device='cuda', generator=g); w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    b = torch.randn(N, device='cuda', generator=g); r = torch.randn(M, N, device='cuda', generator=g)
+    outs = []
+    for rep in range(2):
+        c = torch.full((M, N), float('nan'), device='cuda')
+        L_.check(lib.mc_op_gemm(P(a), P(w), P(b), P(r if res else None), P(c), M, N, K, K, act, st))
+        torch.cuda.synchronize()
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1]), 'not deterministic'
+    rows = torch.cat([torch.arange(0, min(M, 300)), torch.arange(max(0, M - 300), M)]).cuda()
+    ref = a[rows].double() @ w.double().t() + b.double()
+    ref = torch.nn.functional.gelu(ref) if act == 1 else torch.nn.functional.silu(ref) if act == 2 else ref
+    if res: ref = ref + r[rows].double()
+    err = float((outs[0][rows].double() - ref).abs().max()) / float(ref.abs().max())
+    print(f'{M}x{N}x{K} act={act} res={res}: max rel err {err:.2e}')
+    assert err <= 4e-6, err
+print('stream-k ok')
+"""
+    for tune in ('177', '49'):           # 177 = 49 | 128: stream-K for every eligible plain GEMM; 49: the default rule picks it for the K >= 2048 shapes
+        env = dict(os.environ, MC_GEMM_TUNE=tune, PYTHONPATH=os.path.dirname(HERE))
+        r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and 'stream-k ok' in r.stdout, r.stdout + r.stderr
+        print(r.stdout)
+
+
 def test_fp16_mfma_gemm_op_vs_fp64():
     """mc_half.hip gemm_h_k through the C-ABI: C = A W^T + bias + R with fp16 MFMA operands / fp32 accumulate.  The split form
     (x = hi + lo, three products) must be fp32-class, the single-rounding form fp16-class; ragged M (row guard), K = 32."""
