@@ -643,6 +643,50 @@ print('stream-k ok')
         print(r.stdout)
 
 
+@pytest.mark.parametrize('chain', ['32752', '32759'])
+def test_generic_fallback_path_vs_oracle(chain):
+    """MC_CHAIN with bits 0-2 cleared (32752): the generic path -- plain gemm_k launches + row kernels instead of the fused
+    expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
+    is outside the fused kernels' range, so it keeps its own parity test: small-config denoiser call + 3 DDPM steps vs the CPU
+    oracle in a child process (the mask is read once per process), beside the default mask (32759) on the same inputs."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, 'tests')
+from helpers import SMALL, SMALL_SEED, synth_inputs
+from oracle import stmogen_oracle as O, weights as W
+from motioncraft_amd.engine import NativeModel
+from motioncraft_amd.diffusion import build_diffusion
+dims, B, T = SMALL, 3, 24
+sd = W.make_state_dict(dims, SMALL_SEED)
+x_T, xf, mask = synth_inputs(dims, B, T, seed=31, lengths=[24, 19, 11])
+nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+ctx = nm.context(B, T, max_steps=1000)
+d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+ctx.set_timesteps(d.timestep_map)
+ctx.set_condition(xf.cuda(), mask.cuda())
+out2 = ctx.denoise(x_T.cuda(), 640)
+w = (1 - (1000 - 640) / 1000) * dims['scale'] + 1
+ref = O.denoise(sd, dims, x_T, 640, xf, mask)
+e1 = float((out2[:B].cpu() * w + out2[B:].cpu() * (1 - w) - ref).abs().max())
+g = torch.Generator().manual_seed(1)
+noises = {i: torch.randn(B, T, dims['input_feats'], generator=g) for i in (999, 998, 997)}
+x = x_T.cuda()
+for i in (999, 998, 997):
+    x = ctx.sample_step(x, i, d.step_coefs(i, 'ddpm', dims['scale']), noises[i].cuda())
+ref = O.sample_loop(sd, dims, O.Schedule(1000, None), 'ddpm', x_T, xf, mask, step_noise=lambda i: noises[i], num_steps=3)
+e2 = float((x.cpu() - ref).abs().max())
+print(f'errs {e1:.3e} {e2:.3e}')
+assert e1 <= 2e-4 and e2 <= 1e-3
+print('fallback path ok')
+"""
+    env = dict(os.environ, MC_CHAIN=chain, PYTHONPATH=os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'fallback path ok' in r.stdout, r.stdout + r.stderr
+    print(chain, r.stdout.strip().splitlines()[-2])
+
+
 def test_fp16_mfma_gemm_op_vs_fp64():
     """mc_half.hip gemm_h_k through the C-ABI: C = A W^T + bias + R with fp16 MFMA operands / fp32 accumulate.  The split form
     (x = hi + lo, three products) must be fp32-class, the single-rounding form fp16-class; ragged M (row guard), K = 32."""

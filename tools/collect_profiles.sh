@@ -18,6 +18,7 @@ run() {   # run <name> <rocprof args...> -- <cmd...>
 }
 db=$(run ${tag}_stats --kernel-trace -d $out/prof_${tag}_stats -o s -- $BENCH --steps 12 --warmup 3)
 { echo "# bench.py --steps 12 --warmup 3 (B=64): default schedule = two sample groups on two HIP streams (kernel intervals of the two groups overlap: sum of durations > wall time)"; python tools/rocpd_stats.py $db 24; } > $out/${tag}_kernel_stats_b64.txt
+{ echo "# the same run: launch-by-launch timeline of the last ~1.3 steps (tools/rocpd_timeline.py; queue = HIP stream, gap < 0 = overlap with the previous kernel)"; python tools/rocpd_timeline.py $db 150; } > $out/${tag}_b64_timeline.txt
 db=$(MC_CHAIN=1431 run ${tag}_serial --kernel-trace -d $out/prof_${tag}_serial -o s -- $BENCH --steps 12 --warmup 3)
 { echo "# MC_CHAIN=1431 bench.py --steps 12 --warmup 3 (B=64): single-stream schedule (whole-batch launches, no overlap) -- the clean per-kernel durations"; python tools/rocpd_stats.py $db 24; } > $out/${tag}_kernel_stats_b64_serial.txt
 db=$(MC_CHAIN=3479 run ${tag}_mfma --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $out/prof_${tag}_mfma -o s -- $BENCH --steps 3 --warmup 1)
