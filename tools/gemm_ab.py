@@ -31,6 +31,9 @@ def child():
         ref = (a[:512].double() @ w.double().T + b.double() + r[:512].double())
         ref2 = (a[-512:].double() @ w.double().T + b.double() + r[-512:].double())
         err = max(float((c[:512].double() - ref).abs().max()), float((c[-512:].double() - ref2).abs().max())) / float(ref.abs().max())
+        for _ in range(40):          # steady clock: after a host-side gap (the fp64 reference above) the part re-ramps for tens of ms
+            run()
+        torch.cuda.synchronize()
         ts = []
         for _ in range(7):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

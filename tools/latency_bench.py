@@ -12,7 +12,12 @@ dims = default_dims()
 nm = NativeModel(dims, make_state_dict(dims, 0), cfg_scale=6.5)
 d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
                          model_var_type='fixed_large', respace='15,15,8,6,6'))
-for B in [int(v) for v in (sys.argv[1:] or ['1', '2', '4', '8'])]:
+# usage: latency_bench.py [B ...] [--reps N]   (N > 1: that many back-to-back loops, median and last reported)
+args = sys.argv[1:]
+REPS = 1
+if '--reps' in args:
+    k = args.index('--reps'); REPS = int(args[k + 1]); del args[k:k + 2]
+for B in [int(v) for v in (args or ['1', '2', '4', '8'])]:
     ctx = nm.context(B, 196, max_steps=50)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, 196, 322, generator=g).cuda()
@@ -27,6 +32,10 @@ for B in [int(v) for v in (sys.argv[1:] or ['1', '2', '4', '8'])]:
             ctx.sample_step(x, i, coefs[i], eps, x_prev=nxt)
             x, nxt = nxt, x
     loop(); torch.cuda.synchronize()
-    t0 = time.perf_counter(); loop(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f'B={B}: 50-step DDIM {dt*1e3:.1f} ms  ({dt*1e3/50:.3f} ms/step, {B*196/dt:.0f} frames/s)')
+    ts = []
+    for _ in range(REPS):
+        t0 = time.perf_counter(); loop(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
+    print(f'B={B}: 50-step DDIM {dt*1e3:.1f} ms  ({dt*1e3/50:.3f} ms/step, {B*196/dt:.0f} frames/s)' +
+          (f'  [{REPS} loops: min {min(ts)*1e3:.1f} max {max(ts)*1e3:.1f} last {ts[-1]*1e3:.1f}]' if REPS > 1 else ''))
     ctx.close()
