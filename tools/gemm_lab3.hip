@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <utility>
+#include <type_traits>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -363,6 +365,143 @@ __global__ __launch_bounds__(256, 2) void wp_k(const float* A, const float* W, c
             }
 }
 
+// ------------------------------------------------------------------------------------------------ wp2_k
+// gemm_wp_k with the epilogue of tile t software-pipelined UNDER the k-loop of tile t+1 (persistent static tile list per
+// workgroup): the finished accumulators move to a second register set, and one epilogue micro-op per k-tile -- load a residual
+// float4 / add bias + residual and store it -- is issued right behind the k-tile's DMA wait, so the 64 KB read + 64 KB write of a
+// tile are spread over ~32 k-tiles of the next tile instead of hitting HBM from every CU at once between two k-loops.
+template <bool PIPE>
+__global__ __launch_bounds__(256, 2) void wp2_k(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * WSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ntn = N / 128, ntiles = (M / 128) * ntn;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* wbase = smem + wave_u * 2 * WSTAGE;
+    const unsigned lds0 = (unsigned)(size_t)wbase;
+    const int dr = lane >> 2, dc = ((lane & 3) ^ ((dr >> 2) & 3)) * 4;
+    const int frow = lane & 31, hf = lane >> 5, sw = (frow >> 2) & 3;
+    const int nk = K / WBK;
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto ld_frag = [&](int st, int j) {
+        const float* S = wbase + st * WSTAGE + frow * WBK + ((2 * j + hf) ^ sw) * 4;
+        Frag f;
+        f.a0 = *reinterpret_cast<const f32x4*>(S);
+        f.a1 = *reinterpret_cast<const f32x4*>(S + 32 * WBK);
+        f.b0 = *reinterpret_cast<const f32x4*>(S + 64 * WBK);
+        f.b1 = *reinterpret_cast<const f32x4*>(S + 96 * WBK);
+        return f;
+    };
+    f32x16 acc[2][2], pacc[2][2];          // current tile / previous tile (its epilogue runs under the current k-loop)
+    int prow0 = -1, pcol0 = 0;             // previous tile's origin (-1: none pending)
+    f32x4 rbuf = {0.f, 0.f, 0.f, 0.f};
+    // epilogue item i (0 .. 15) of the pending tile: (mi, ni, q) = (i >> 3, (i >> 2) & 1, i & 3)
+    auto item_ptrs = [&](int i, long& off, int& n) {
+        const int mi = i >> 3, ni = (i >> 2) & 1, q = i & 3;
+        n = pcol0 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+        off = (long)(prow0 + wm * 64 + mi * 32 + frow) * N + n;
+    };
+    auto epi_load = [&](int i) {
+        long off; int n;
+        item_ptrs(i, off, n);
+        rbuf = R ? *reinterpret_cast<const f32x4*>(R + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto epi_store = [&](int i, const f32x16& a) {
+        long off; int n;
+        item_ptrs(i, off, n);
+        const int q = i & 3;
+        f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        v += rbuf;
+        *reinterpret_cast<f32x4*>(C + off) = v;
+    };
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int bid = xcd_remap(t, ntiles);
+        const int tm = bid / ntn, tn = bid % ntn, row0 = tm * 128, col0 = tn * 128;
+        unsigned voa[4], vow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            voa[q] = (unsigned)(((long)(row0 + wm * 64 + 16 * q + dr) * K + dc) * 4);
+            vow[q] = (unsigned)(((long)(col0 + wn * 64 + 16 * q + dr) * K + dc) * 4);
+        }
+        auto issue_q = [&](int kt, int st, int q) {
+            dma16(voa[q], A + kt * WBK, lds0 + st * WSTAGE * 4 + q * 1024);
+            dma16(vow[q], W + kt * WBK, lds0 + st * WSTAGE * 4 + 4096 + q * 1024);
+        };
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        auto mma2 = [&](const Frag& f, int i0) {
+#pragma unroll
+            for (int i = i0; i < i0 + 2; ++i) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a0[i], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a0[i], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[i], f.a1[i], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[i], f.a1[i], acc[1][1], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_q(0, 0, q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Frag f0 = ld_frag(0, 0), f1;
+        // one k-tile; EPI: -1 none, 2 i = load item i, 2 i + 1 = finish + store item i (compile-time: the pending accumulators are
+        // register arrays)
+        auto ktile = [&](int kt, auto epi_tag) {
+            constexpr int EPI = decltype(epi_tag)::value;
+            const int st = kt & 1;
+            const bool more = kt + 1 < nk;
+            f1 = ld_frag(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f0, 0);
+            if (more) { issue_q(kt + 1, st ^ 1, 0); issue_q(kt + 1, st ^ 1, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f0, 2);
+            if (more) { issue_q(kt + 1, st ^ 1, 2); issue_q(kt + 1, st ^ 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f1, 0);
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next stage's DMAs AND the previous epilogue micro-op (one k-tile old)
+                f0 = ld_frag(st ^ 1, 0);
+            }
+            if constexpr (EPI >= 0) {
+                if (prow0 >= 0) {
+                    if constexpr ((EPI & 1) == 0) epi_load(EPI >> 1);
+                    else epi_store(EPI >> 1, pacc[(EPI >> 1) >> 3][((EPI >> 1) >> 2) & 1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma2(f1, 2);
+        };
+        int kt = 0;
+        if (PIPE && nk >= 40) {
+            // k-tiles 2 .. 33 carry the 32 micro-ops of the pending tile's epilogue
+            ktile(0, std::integral_constant<int, -1>{});
+            ktile(1, std::integral_constant<int, -1>{});
+            [&]<int... E>(std::integer_sequence<int, E...>) { (ktile(2 + E, std::integral_constant<int, E>{}), ...); }(std::make_integer_sequence<int, 32>{});
+            kt = 34;
+        }
+        for (; kt < nk; ++kt) ktile(kt, std::integral_constant<int, -1>{});
+        if (PIPE && nk >= 40 && t + (int)gridDim.x < ntiles) {
+            // hand the finished tile to the pending set (its epilogue runs under the next tile's k-loop)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) pacc[mi][ni] = acc[mi][ni];
+            prow0 = row0; pcol0 = col0;
+        } else {
+            // last tile of this workgroup (or no pipelining): the plain epilogue
+            const int sp0 = prow0, sc0 = pcol0;
+            prow0 = row0; pcol0 = col0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { epi_load(i); epi_store(i, acc[i >> 3][(i >> 2) & 1]); }
+            prow0 = sp0; pcol0 = sc0;
+            if (PIPE && nk >= 40) prow0 = -1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static float *dA, *dW, *dB, *dR, *dC, *dC2, *dSlab;
 static int* dSync;
@@ -456,6 +595,18 @@ static void run_sk(const char* name, int M, int N, int K, bool res, bool cmp, bo
     }
 }
 
+template <bool PIPE>
+static void run_wp2(const char* name, int M, int N, int K, bool res, bool cmp) {
+    const int tiles = (M / 128) * (N / 128);
+    const int grid = std::min(tiles, 2 * NCU);
+    auto launch = [&]() { hipLaunchKernelGGL((wp2_k<PIPE>), dim3(grid), dim3(256), 0, 0, dA, dW, dB, res ? dR : nullptr, dC, M, N, K); };
+    for (int r = 0; r < 40; ++r) launch();
+    const float ms = time_it(launch);
+    const double tf = 2.0 * M * N * K / ms / 1e9;
+    printf("wp2_k %-52s %6dx%4dx%4d: %8.1f us %6.1f TF (%5.1f %%)\n", name, M, N, K, ms * 1e3, tf, tf / 1.573);
+    if (cmp) { launch(); hipDeviceSynchronize(); compare(M, N, name); }
+}
+
 static void run_wp(int M, int N, int K, bool res) {
     const int tiles = (M / 128) * (N / 128);
     auto launch = [&]() { hipLaunchKernelGGL(wp_k, dim3(tiles), dim3(256), 0, 0, dA, dW, dB, res ? dR : nullptr, dC2, M, N, K); };
@@ -506,6 +657,10 @@ int main(int argc, char** argv) {
         for (int M : {25088, 12544, 32768, 6272, 25000}) {
             if (M % 128 == 0) run_wp(M, 1536, 1536, true);
             const bool cmp = pass == 0 && M % 128 == 0;
+            if (M % 128 == 0) {
+                run_wp2<false>("persistent, plain epilogue", M, 1536, 1536, true, cmp);
+                run_wp2<true>("persistent, epilogue under the next tile's k-loop", M, 1536, 1536, true, cmp);
+            }
             run_sk<4, O_STREAMK | O_MFMA_FIRST, 256>("256x256 x 8 waves, stream-K, 4 stages", M, 1536, 1536, true, false);
             run_sk<3, O_STREAMK | O_MFMA_FIRST, 128>("256x128 x 4 waves x 2 WG/CU, stream-K, 3 stages", M, 1536, 1536, true, cmp);
             run_sk<3, O_STREAMK, 128>("256x128 x 4 waves x 2 WG/CU, stream-K, 3 stages, loads first", M, 1536, 1536, true, false);
