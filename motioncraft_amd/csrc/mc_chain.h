@@ -76,6 +76,7 @@ struct RowChainArgs {
     const float* bias2 = nullptr;
     float* Y2 = nullptr;           // [N][ldy2]
     long ldy2 = 0;
+    long pad_row = -1;             // projqkv: first of 128 PADDING rows of Y and Y2 (behind the last real token): invalid lanes store there unconditionally
 };
 
 bool mc_chain_enabled(int which);   // 0: fused mlp, 1: gate, 2: rowchain (proj, qkv)   (env MC_CHAIN bitmask, default all)

@@ -684,34 +684,46 @@ __global__ __launch_bounds__(256, 2) void projqkv_k(RowChainArgs g) {
     sp.commit(Ws(0), tid);
     fetch(1);
     __syncthreads();
-    float* orow = g.Y + tok * g.ldy + kq;
+    // Stores are UNCONDITIONAL: invalid lanes (rows past N, aliased twins of a partly aliased tile) write their garbage into the
+    // 128 padding rows the caller allocates behind the last real token (RowChainArgs::pad_row), so every chunk
+    // issues exactly 4 store instructions per wave with no branch around them -- and the weight fetch for chunk c+2 is issued
+    // BEFORE the stores of chunk c, so the (in-order) vmcnt wait in front of the next commit reads "at most the 4 younger stores may
+    // still be in flight" instead of draining them: round 3 measured 0.8 ms per step of store latency exposed through that drain
+    // at B=64 (timing ablation without the stores).
+    const long trow = rok ? tok : g.pad_row + (long)(wave * 32 + (lane & 31));
+    float* orow = g.Y + trow * g.ldy + kq;
+    float* qrow = g.Y2 + trow * g.ldy2 + kq;
     f32x4 bvf[NJ];                                   // body_value fragment = k-groups 4c + q of output chunks c < L/32
-    // one chunk: MFMAs -> commit(next) -> bias + stores -> fetch(next + 1)   (order: see rowchain_k)
+    // one chunk: MFMAs -> commit(next) -> fetch(next + 1) -> bias + stores
 #define MC_PQ_CHUNK(cg, XF, OUT, BIAS0, KEEP)                                                              \
     {                                                                                                      \
         const f32x16 a = chunk_mma<NJ>(Ws((cg) & 1), XF, lane);                                           \
         if ((cg) + 1 < NC0 + NC1) sp.commit(Ws(((cg) & 1) ^ 1), tid);                                     \
+        if ((cg) + 2 < NC0 + NC1) fetch((cg) + 2);                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
             const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + (BIAS0) + 8 * q + kq);              \
             const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]}; \
-            if (rok) *reinterpret_cast<f32x4*>((OUT) + 8 * q) = v;                                        \
+            *reinterpret_cast<f32x4*>((OUT) + 8 * q) = v;                                                 \
             KEEP                                                                                           \
         }                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if ((cg) + 2 < NC0 + NC1) fetch((cg) + 2);                                                         \
         __syncthreads();                                                                                   \
     }
 #pragma unroll
     for (int c = 0; c < NKEEP; ++c) MC_PQ_CHUNK(c, xf, orow + c * 32, c * 32, bvf[4 * c + q] = v;)
+    // (runtime loops: unrolled, the per-chunk weight pointers get hoisted and spill; the loop-entry state of the vmcnt bookkeeping
+    // equals the back-edge state -- the unrolled chunks above leave the same queue -- so the counted waits survive)
+#pragma unroll 1
     for (int c = NKEEP; c < NC0; ++c) MC_PQ_CHUNK(c, xf, orow + c * 32, c * 32, )
     frag_layernorm<NJ>(bvf, g.gamma, g.beta, kq);
-    float* qrow = g.Y2 + tok * g.ldy2 + kq;
+#pragma unroll 1
     for (int c = 0; c < NC1; ++c) MC_PQ_CHUNK(NC0 + c, bvf, qrow + c * 32, 4 * L + c * 32, )
 #undef MC_PQ_CHUNK
 }
 
 int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
     MC_REQUIRE(g.Nout == 4 * g.L && g.ldy % 4 == 0 && g.ldy2 % 4 == 0 && g.W2 && g.bias2 && g.Y2, "projqkv: bad arguments");
+    MC_REQUIRE(g.pad_row >= g.N, "projqkv: pad_row (128 padding rows of Y / Y2 behind the last token) not set");
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv(g.N - g.tok0, 128));
     switch (g.L) {

@@ -519,6 +519,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         p.alias = tok_alias;
         if (pq_fused) {       // + the dynamic body topology's shared LayerNorm and q/k/v on the body_value columns
             p.gamma = w.dyn_g; p.beta = w.dyn_b; p.W2 = w.qkv_w; p.bias2 = w.qkv_b; p.Y2 = c->qkv; p.ldy2 = 3 * L;
+            p.pad_row = c->N;      // mf / qkv carry 128 padding rows (mc_ctx_create): projqkv_k's stores are unconditional
             if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
                 if ((r = mc_launch_projqkv_h(p, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
             } else if ((r = mc_launch_projqkv(p, s))) return r;
@@ -861,8 +862,8 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->hbuf, hsz);
     if (mc_chain_enabled(0) && mc_mlp_supported(L, 4 * L)) c->hbuf_floats = hsz;   // (the text MoE only touches hbuf in set_condition)
     WS(c->y2, 2 * zsz);
-    WS(c->mf, c->N * 4 * L);
-    WS(c->qkv, c->N * 3 * L);
+    WS(c->mf, (c->N + 128) * 4 * L);        // + 128 padding rows: projqkv_k stores unconditionally (invalid lanes land there)
+    WS(c->qkv, (c->N + 128) * 3 * L);
     WS(c->ys, c->rows * D);
     WS(c->yt, c->rows * D);
     WS(c->a, c->rows * D);
