@@ -386,6 +386,8 @@ __device__ __forceinline__ bool grid_sync(int* bar, int nwg, int* s_last, int* s
 }
 
 constexpr int COOP_PER = 10;
+constexpr long COOP_MAX_WG = 512;      // grid limit of route_coop_k: 1.31 M (token, choice) pairs (B <= 139 at 196 frames; M2D 160 windows x 120 frames = 921 600);
+                                       // round 3: was 256 -- beyond it the 12-launch sequence ran (M2D: 196 us per routing instead of ~50)
 __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                     const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit, int E,
                                                     int capacity, int cnt_mul, float* __restrict__ comb_w, int* state,
@@ -943,7 +945,7 @@ static long route_small_pairs() {
 size_t mc_route_state_ints(int) { return ST_TOTAL; }
 bool mc_route_is_small(long N) { return 2 * N <= route_small_pairs(); }
 bool mc_route_cleans_counts(const RouteBufs& rb, long N) {
-    return 2 * N <= (rb.small_pairs >= 0 ? rb.small_pairs : route_small_pairs()) || (rb.coop && 2 * N <= 256L * 256 * COOP_PER);
+    return 2 * N <= (rb.small_pairs >= 0 ? rb.small_pairs : route_small_pairs()) || (rb.coop && 2 * N <= COOP_MAX_WG * 256 * COOP_PER);
 }
 size_t mc_route_barrier_offset() { return ST_BAR; }
 size_t mc_route_barrier_ints() { return 17 * 32; }
@@ -958,7 +960,7 @@ size_t mc_route_error_offset() { return ST_BAR + 1; }
 // GPU) can still starve it, and then the barrier times out into an error flag (grid_sync) instead of hanging.
 #include <atomic>
 static std::atomic<int> g_coop_reserved[64];
-int mc_route_coop_wgs(long N) { return (2 * N <= 256L * 256 * COOP_PER) ? cdiv(2 * N, 256L * COOP_PER) : 0; }
+int mc_route_coop_wgs(long N) { return (2 * N <= COOP_MAX_WG * 256 * COOP_PER) ? cdiv(2 * N, 256L * COOP_PER) : 0; }
 int mc_route_coop_slots() {
     static std::atomic<int> cached[64];
     int dev = 0;
@@ -1023,7 +1025,7 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
         MC_LAUNCH_CHECK();
         return MC_OK;
     }
-    if (rb.coop && 2 * N <= 256L * 256 * COOP_PER) {
+    if (rb.coop && 2 * N <= COOP_MAX_WG * 256 * COOP_PER) {
         const int nwg = cdiv(2 * N, 256L * COOP_PER);
         hipLaunchKernelGGL(route_coop_k, dim3(nwg), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity, (int)(N / Nsrc),
                            rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows, rb.max_tiles, rb.tie_xor,
