@@ -1088,6 +1088,9 @@ static int sk_workspace(hipStream_t stream, SkWs* out) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = pool.find({dev, stream});
     if (it == pool.end()) {
+        // first use on this stream allocates + synchronises: not inside a stream capture (the caller then takes the tile kernels)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { out->G = 0; return MC_OK; }
         hipDeviceProp_t prop;
         MC_HIP(hipGetDeviceProperties(&prop, dev));
         SkWs w;
@@ -1127,7 +1130,7 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
             const long iters = (long)cdiv(g.M, 256) * (g.N / 256) * (g.K / SKK);
             int G = w.G;
             if (iters < G) G = (int)iters;
-            if (iters * G < (1L << 32)) {
+            if (G > 0 && iters * G < (1L << 32)) {
                 g.sk_slab = w.slab;
                 g.sk_sync = w.sync;
                 hipLaunchKernelGGL(gemm_sk_k, dim3(G), dim3(512), 0, stream, g);
