@@ -1091,6 +1091,7 @@ static int sk_workspace(hipStream_t stream, SkWs* out) {
         // first use on this stream allocates + synchronises: not inside a stream capture (the caller then takes the tile kernels)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { out->G = 0; return MC_OK; }
+        if (pool.size() >= 16) { out->G = 0; return MC_OK; }      // 64 MB of slabs per stream: a process that keeps creating streams takes the tile kernels
         hipDeviceProp_t prop;
         MC_HIP(hipGetDeviceProperties(&prop, dev));
         SkWs w;
