@@ -687,6 +687,46 @@ print('fallback path ok')
     print(chain, r.stdout.strip().splitlines()[-2])
 
 
+def test_stream_k_gemm_on_two_streams_concurrently():
+    """gemm_sk_k keeps its slabs + ticket words per (device, stream): two streams running the long-k GEMM at the same time
+    (each launch = 256 persistent workgroups of 128 KB LDS, so the second launch's workers only get CUs as the first one's
+    leave -- the ticket-ordered slab hand-off must not care) give the results of the same launches run alone, three rounds."""
+    from motioncraft_amd import lib as L_
+    lib = L_.load(require_gpu=True)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    g = torch.Generator(device='cuda').manual_seed(11)
+    M, N, K = 4096 + 128, 2048, 2048          # 17 x 8 = 136 tiles of 256 x 256 (the last row tile ragged), 128 k-tiles: split by stream-K
+    ops = []
+    for j in range(2):
+        a = torch.randn(M, K, device='cuda', generator=g)
+        w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+        b = torch.randn(N, device='cuda', generator=g)
+        r = torch.randn(M, N, device='cuda', generator=g)
+        ops.append((a, w, b, r, torch.empty(M, N, device='cuda'), torch.cuda.Stream()))
+
+    def launch(op):
+        a, w, b, r, c, st = op
+        with torch.cuda.stream(st):
+            L_.check(lib.mc_op_gemm(P(a), P(w), P(b), P(r), P(c), M, N, K, K, 0, ctypes.c_void_p(st.cuda_stream)))
+    alone = []
+    for op in ops:
+        launch(op)
+        torch.cuda.synchronize()
+        alone.append(op[4].clone())
+        ref = op[0][:256].double() @ op[1].double().t() + op[2].double() + op[3][:256].double()
+        assert float((alone[-1][:256].double() - ref).abs().max()) / float(ref.abs().max()) <= 4e-6
+    for rnd in range(3):
+        for op in ops:
+            op[4].fill_(float('nan'))
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for op in ops:
+                launch(op)
+        torch.cuda.synchronize()
+        for j, op in enumerate(ops):
+            assert torch.equal(op[4], alone[j]), (rnd, j)
+
+
 def test_fp16_mfma_gemm_op_vs_fp64():
     """mc_half.hip gemm_h_k through the C-ABI: C = A W^T + bias + R with fp16 MFMA operands / fp32 accumulate.  The split form
     (x = hi + lo, three products) must be fp32-class, the single-rounding form fp16-class; ragged M (row guard), K = 32."""
