@@ -138,6 +138,19 @@ def cpu_baseline(B=8, T=196, steps=6):
     return out
 
 
+def self_launch_argv(n, argv, port=None):
+    """argv that re-runs this script as n ranks on this node (torch.distributed.run, rendezvous on 127.0.0.1)."""
+    port = port or int(os.environ.get('MASTER_PORT', 29400 + os.getpid() % 2000))
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def workload_name(B, T):
+    base = ('stmogen 0.125b text-to-motion (L=128, 12 parts, 4 layers, 16 experts top-2), CFG scale 6.5, '
+            f'batch {B} per GPU, {T} frames, 1000-step DDPM')
+    return ('configs[1]: ' if (B, T) == (64, 196) else 'configs[1] at a NON-BASELINE size: ') + base
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -151,11 +164,15 @@ def main():
     ap.add_argument('--backend', default='nccl', help="'nccl' (= RCCL over xGMI); 'gloo' only for plumbing smoke tests")
     a = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, mogen/apis/test.py:36-82 runs under
+        # tools/dist_train.sh:8-10's launcher the same way); rank 0 of the children prints the one JSON line
+        os.execv(sys.executable, self_launch_argv(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    if a.gpus != world:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU')
     if os.environ.get('MC_BENCH_ALL_ON_DEVICE0'):      # plumbing smoke test of the N>1 path on a 1-GPU box (gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -387,8 +404,7 @@ def main():
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(t_step * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: stmogen 0.125b text-to-motion (L=128, 12 parts, 4 layers, 16 experts '
-                                   'top-2), CFG scale 6.5, batch 64 per GPU, 196 frames, 1000-step DDPM',
+            'config': {'workload': workload_name(B, T),
                        'batch_per_gpu': B, 'global_batch': GB, 'frames': T, 'parallelism': f'dp{world}',
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),

@@ -464,3 +464,31 @@ def test_t2m_token_vectorisation_layout():
     assert w[0, :, 0].tolist() == [3, 4, 4, 3, 3, 3, 3]            # sos walk fast eos unk unk unk
     assert w[1, :, 0].tolist() == [3, 1, 1, 1, 1, 1, 3]            # sos + 5 kept + eos
     assert p[0, 1].tolist() == [0, 1, 0] and p[0, 0].tolist() == [1, 0, 0]
+
+
+def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE in the env) re-executes itself under torch.distributed.run with one rank
+    per GPU on 127.0.0.1 (the launcher role of tools/dist_train.sh:8-10 in front of mogen/apis/test.py:36-82)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    argv = bench.self_launch_argv(4, ['--gpus', '4', '--steps', '7'], port=29512)
+    assert argv[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nproc-per-node=4' in argv and '--nnodes=1' in argv
+    assert argv[argv.index('--master-addr') + 1] == '127.0.0.1' and argv[argv.index('--master-port') + 1] == '29512'
+    assert argv[-5:] == [os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '7']
+    seen = {}
+
+    def fake_execv(exe, args):
+        seen['exe'], seen['args'] = exe, args
+        raise SystemExit(0)
+    monkeypatch.setattr(os, 'execv', fake_execv)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--batch', '16'])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen['exe'] == sys.executable and '--nproc-per-node=2' in seen['args'] and seen['args'][-4:] == ['--gpus', '2', '--batch', '16']
+    # the workload string follows the real batch
+    assert 'batch 16 per GPU' in bench.workload_name(16, 196) and bench.workload_name(16, 196).startswith('configs[1] at a NON-BASELINE')
+    assert bench.workload_name(64, 196).startswith('configs[1]: ')
