@@ -121,9 +121,9 @@ bool mc_route_cleans_counts(const RouteBufs& rb, long N);   // the routing kerne
 size_t mc_route_barrier_offset();                          // ints into the state block: grid-barrier words, to be zeroed once
 size_t mc_route_error_offset();                             // ints into the state block: sticky "grid barrier timed out" word of route_coop_k
 int mc_route_coop_wgs(long N);                              // workgroups route_coop_k launches for N tokens (0: beyond its size range)
-int mc_route_coop_slots();                                  // route_coop_k workgroups the current device holds at once (occupancy x CUs)
-bool mc_route_coop_reserve(int nwg);                        // reserve / give back resident workgroups for one context (per device, process-wide)
-void mc_route_coop_release(int nwg);
+int mc_route_coop_slots(int dev);                           // route_coop_k workgroups device `dev` (the current one at the first query) holds at once (occupancy x CUs)
+bool mc_route_coop_reserve(int dev, int nwg);                        // reserve / give back resident workgroups for one context (per device, process-wide)
+void mc_route_coop_release(int dev, int nwg);
 size_t mc_route_barrier_ints();   // routing of N tokens runs as the one-workgroup kernel, which also leaves the (choice, expert) counts zeroed
 // proj [N][256] (cosine_projector output incl. bias) -> idx/gate/key + per-expert choice counts
 int mc_launch_gate_finish(const float* proj, const float* sim_n, const float* logit_scale, long N, int E,

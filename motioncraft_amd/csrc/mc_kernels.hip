@@ -219,7 +219,9 @@ __device__ __forceinline__ float sampler_elem(float x, float x0, float nz, const
 __device__ __forceinline__ float cfg_elem(float a, float b, const SamplerCoefs& c) { return fmaf(a, c.text_coef, __fmul_rn(b, c.none_coef)); }
 
 // x_prev may alias x_t (in-place update: every element is read before it is written by the same thread; no __restrict__ on the two)
-template <bool RNG>
+// VEC: every operand 16-byte aligned (float4 loads / stores); otherwise the same groups of 4 elements go element by element
+// (C = 263 / 251 at odd B*T, or the second partial product of the folded tail at out2 + B*T*C: 8-byte aligned at best)
+template <bool RNG, bool VEC>
 __global__ __launch_bounds__(256) void sampler_update_k(const float* x_t, const float* __restrict__ o_text,
                                                         const float* __restrict__ o_none, const float* __restrict__ noise,
                                                         float* x_prev, float* __restrict__ x0_out, long n,
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void sampler_update_k(const float* x_t, const 
     const long ngroups = (n + 3) >> 2;
     for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long)gridDim.x * blockDim.x) {
         const long i = gi * 4;
-        if (i + 4 <= n) {
+        if (VEC && i + 4 <= n) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(x_t + i);
             const f32x4 a = *reinterpret_cast<const f32x4*>(o_text + i), b = *reinterpret_cast<const f32x4*>(o_none + i);
             f32x4 nz;
@@ -468,14 +470,18 @@ int mc_launch_softmax_rows_small(const float* W, float* out, int rows, int cols,
 int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none, const float* noise, float* x_prev, float* x0_out, long n,
                              SamplerCoefs c, hipStream_t s, const SamplerCoefs* table, const int* step_ptr, const RngArgs* rng) {
     MC_REQUIRE(noise || rng, "sampler update: neither a noise tensor nor a Philox draw given");
-    // float4 path: the three streams 16-byte aligned (torch / workspace allocations are)
-    MC_REQUIRE(((uintptr_t)x_t | (uintptr_t)out_text | (uintptr_t)out_none | (uintptr_t)x_prev | (uintptr_t)x0_out | (uintptr_t)noise) % 16 == 0,
-               "sampler update: operands must be 16-byte aligned");
+    // float4 path when every stream is 16-byte aligned (torch / workspace allocations are; out2 + B*T*C or noise + k*n need not be:
+    // C = 263 / 251 / 322 with an odd B*T) -- otherwise the element-wise form of the same kernel (same groups, same Philox counters)
+    const bool vec = ((uintptr_t)x_t | (uintptr_t)out_text | (uintptr_t)out_none | (uintptr_t)x_prev | (uintptr_t)x0_out | (uintptr_t)noise) % 16 == 0;
     int blocks = cdiv((n + 3) / 4, 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (rng && !noise) hipLaunchKernelGGL(sampler_update_k<true>, dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev, x0_out, n, c, table, step_ptr, *rng);
-    else hipLaunchKernelGGL(sampler_update_k<false>, dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev, x0_out, n, c, table, step_ptr, RngArgs());
+    const bool dev_rng = rng && !noise;
+    const RngArgs ra = dev_rng ? *rng : RngArgs();
+#define MC_SU(R, V) hipLaunchKernelGGL((sampler_update_k<R, V>), dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev, x0_out, n, c, table, step_ptr, ra)
+    if (dev_rng) { if (vec) MC_SU(true, true); else MC_SU(true, false); }
+    else { if (vec) MC_SU(false, true); else MC_SU(false, false); }
+#undef MC_SU
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -80,6 +80,7 @@ struct mc_ctx {
     int* t_orig;
     float *te, *e1, *emb, *semb, *ss;   // ss: [NL][2][maxS][2D]
     RouteBufs rb;
+    int device = 0;             // the HIP device the context was created on (reservations are per device)
     int coop_reserved = 0;      // resident route_coop_k workgroups this context holds (mc_route_coop_reserve)
     bool prof_on = false;       // mc_ctx_profile: HIP events around the FiLM out_layers GEMM launches (bench.py's dominant-kernel figure)
     std::vector<ProfRec> prof;
@@ -779,16 +780,19 @@ void mc_model_destroy(mc_model* m) {
 
 int mc_model_set_param(mc_model* m, const char* name, const float* host, int64_t numel) {
     MC_REQUIRE(m && name && host && numel > 0, "bad argument");
+    auto it = m->params.find(name);
+    // replacing a weight of a finalized model: contexts hold raw pointers into the old allocation and the fp16 planes built from it
+    // would go stale -- the model is immutable once contexts can exist (build a new model for new weights).  Checked BEFORE anything
+    // is allocated (a rejected call must not leak the new buffer).
+    MC_REQUIRE(it == m->params.end() || !m->finalized, "mc_model_set_param(%s): the model is finalized; weights are immutable from then on", name);
     float* d = nullptr;
     MC_HIP(hipMalloc(&d, (size_t)numel * sizeof(float)));
-    MC_HIP(hipMemcpy(d, host, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
-    auto it = m->params.find(name);
-    if (it != m->params.end()) {
-        // replacing a weight of a finalized model: contexts hold raw pointers into the old allocation and the fp16 planes built from it
-        // would go stale -- the model is immutable once contexts can exist (build a new model for new weights)
-        MC_REQUIRE(!m->finalized, "mc_model_set_param(%s): the model is finalized; weights are immutable from then on", name);
-        (void)hipFree(it->second.first);
+    if (hipMemcpy(d, host, (size_t)numel * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        mc_set_error("mc_model_set_param(%s): host-to-device copy failed", name);
+        return MC_ERR_HIP;
     }
+    if (it != m->params.end()) (void)hipFree(it->second.first);
     m->params[name] = std::make_pair(d, numel);
     return MC_OK;
 }
@@ -899,14 +903,19 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     MC_HIP(hipMemset(c->rb.state + mc_route_barrier_offset(), 0, mc_route_barrier_ints() * sizeof(int)));      // grid-barrier words of the cooperative routing kernel
     // the cooperative routing kernel needs its whole grid resident: reserve it out of what the device holds, or run the
     // launch sequence instead (no env var needed: a fifth concurrent B = 64 context, or a CPX partition, simply falls back)
+    // Reserved for the LARGEST grid any routing call of this context can launch cooperatively: the motion MoE routes N tokens, the
+    // text MoE (mc_ctx_set_condition) Ntxt -- either may be the one inside route_coop_k's size range.  Nothing to reserve (both in
+    // the one-workgroup regime or beyond the kernel's range) or no room -> coop off for the context, so no unreserved grid can launch.
+    MC_HIP(hipGetDevice(&c->device));
     if (c->rb.coop) {
         const long small = c->rb.small_pairs >= 0 ? c->rb.small_pairs : -1;
-        const int nwg = mc_route_coop_wgs(c->N);
-        const bool one_wg = small >= 0 ? 2 * c->N <= small : mc_route_is_small(c->N);
-        if (nwg > 0 && !one_wg) {
-            if (mc_route_coop_reserve(nwg)) c->coop_reserved = nwg;
-            else c->rb.coop = false;
+        int nwg = 0;
+        for (long n : {c->N, c->Ntxt}) {
+            const bool one_wg = small >= 0 ? 2 * n <= small : mc_route_is_small(n);
+            if (!one_wg && mc_route_coop_wgs(n) > nwg) nwg = mc_route_coop_wgs(n);
         }
+        if (nwg > 0 && mc_route_coop_reserve(c->device, nwg)) c->coop_reserved = nwg;
+        else c->rb.coop = false;
     }
 #undef WS
     *out = c;
@@ -919,7 +928,7 @@ static void prof_clear(mc_ctx* c);
 void mc_ctx_destroy(mc_ctx* c) {
     if (!c) return;
     graph_release(c);
-    if (c->coop_reserved) { mc_route_coop_release(c->coop_reserved); c->coop_reserved = 0; }
+    if (c->coop_reserved) { mc_route_coop_release(c->device, c->coop_reserved); c->coop_reserved = 0; }
     prof_clear(c);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     for (int k = 1; k < 3; ++k)
@@ -950,7 +959,7 @@ int mc_ctx_check(mc_ctx* c, void* stream) {
 
 int mc_ctx_effective_precision(const mc_ctx* c) { return c ? (use_half(c) ? c->prec : MC_PREC_F32) : MC_PREC_F32; }
 
-int mc_ctx_uses_coop_routing(const mc_ctx* c) { return c && c->coop_reserved > 0 ? 1 : 0; }
+int mc_ctx_uses_coop_routing(const mc_ctx* c) { return c && c->rb.coop && c->coop_reserved > 0 ? 1 : 0; }
 
 static void prof_clear(mc_ctx* c) {
     for (auto& p : c->prof) { if (p.e0) (void)hipEventDestroy(p.e0); if (p.e1) (void)hipEventDestroy(p.e1); }

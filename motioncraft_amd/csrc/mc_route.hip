@@ -961,10 +961,9 @@ size_t mc_route_error_offset() { return ST_BAR + 1; }
 #include <atomic>
 static std::atomic<int> g_coop_reserved[64];
 int mc_route_coop_wgs(long N) { return (2 * N <= COOP_MAX_WG * 256 * COOP_PER) ? cdiv(2 * N, 256L * COOP_PER) : 0; }
-int mc_route_coop_slots() {
+int mc_route_coop_slots(int dev) {
     static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (dev < 0 || dev >= 64) return 0;
     int v = cached[dev].load();
     if (v > 0) return v;
     int per_cu = 0;
@@ -977,18 +976,16 @@ int mc_route_coop_slots() {
     cached[dev].store(v);
     return v;
 }
-bool mc_route_coop_reserve(int nwg) {
-    int dev = 0;
-    if (nwg <= 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    const int slots = mc_route_coop_slots();
+bool mc_route_coop_reserve(int dev, int nwg) {
+    if (nwg <= 0 || dev < 0 || dev >= 64) return false;
+    const int slots = mc_route_coop_slots(dev);
     int cur = g_coop_reserved[dev].load();
     while (cur + nwg <= slots)
         if (g_coop_reserved[dev].compare_exchange_weak(cur, cur + nwg)) return true;
     return false;
 }
-void mc_route_coop_release(int nwg) {
-    int dev = 0;
-    if (nwg > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) g_coop_reserved[dev].fetch_sub(nwg);
+void mc_route_coop_release(int dev, int nwg) {      // dev = the device the reservation was taken on (not whatever is current at destroy time)
+    if (nwg > 0 && dev >= 0 && dev < 64) g_coop_reserved[dev].fetch_sub(nwg);
 }
 const int* mc_route_num_tiles_ptr(const RouteBufs& rb, int group) { return rb.state + ST_NTILES + group; }
 const int* mc_route_split_flag_ptr(const RouteBufs& rb) { return rb.state + ST_SPLIT; }

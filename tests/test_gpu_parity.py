@@ -1803,6 +1803,57 @@ def test_fused_sampler_loop_equals_the_per_step_path(small_model, mode):
     assert torch.equal(f1, f0)
 
 
+@pytest.mark.parametrize('tag', ['hml263', 'kit251', 'smplx322'])
+def test_sampler_entry_points_on_unaligned_shapes_vs_oracle(tag):
+    """B*T*C not a multiple of 4 (B=1, T=25: 263 -> 6575, 251 -> 6275, 322 -> 8050 floats): the second partial product of the
+    folded decoder tail (out2 + B*T*C) and the k-th noise slice (noise + k*n) are then 4- or 8-byte aligned only.  mc_sample_step,
+    mc_sample_loop (host noise and device Philox noise) and the hipGraph replay must take the element-wise form of the sampler
+    kernel and still equal the oracle / each other (the float4 kernel used to be the only one: ADVICE r03)."""
+    from motioncraft_amd import lib as L_
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    kw = dict(max_seq_len=25, L=32, NL=2, F=64, Te=64, Dt=32, Nt=8)
+    dims = {'hml263': W.humanml3d_dims(**kw), 'kit251': W.humanml3d_dims(input_feats=251, dataset='kit_ml', **kw),
+            'smplx322': W.default_dims(**kw)}[tag]
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    B, T, C = 1, 25, dims['input_feats']
+    assert (B * T * C) % 4 != 0
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=44, lengths=[21])
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+    ctx = nm.context(B, T, max_steps=1000)
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    idx = [999, 998, 997, 996, 995]
+    coefs = [d.step_coefs(i, 'ddpm', dims['scale']) for i in idx]
+    g = torch.Generator().manual_seed(6)
+    nz = torch.randn(len(idx), B, T, C, generator=g)
+    ref = O.sample_loop(sd, dims, O.Schedule(1000, None), 'ddpm', x_T, xf, mask, step_noise=lambda i: nz[999 - i], num_steps=len(idx))
+    x = x_T.cuda().clone()
+    for k, i in enumerate(idx):                                    # per-step entry (noise slices individually allocated: aligned)
+        x = ctx.sample_step(x, i, coefs[k], nz[k].cuda().contiguous())
+    assert maxabs(x, ref) <= TOL_FINAL, tag
+    xl = x_T.cuda().clone()
+    x0 = torch.empty_like(xl)
+    ctx.sample_loop(xl, idx, coefs, noise=nz.cuda(), x0=x0)        # loop entry: noise + k*n is misaligned for k = 1, 2, 3
+    assert torch.equal(xl, x) and bool(torch.isfinite(x0).all())
+    # device noise == the written-out Philox stream through the per-step path
+    lib = L_.load(require_gpu=True)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pz = [torch.empty(B, T, C, device='cuda') for _ in idx]
+    for k in range(len(idx)):
+        L_.check(lib.mc_op_philox_normal(ctypes.c_void_p(pz[k].data_ptr()), None, B * T * C, 9, 40 + k, st))
+    xa = x_T.cuda().clone()
+    ctx.sample_loop(xa, idx, coefs, noise=None, seed=9, draw0=40)
+    xb = x_T.cuda().clone()
+    for k, i in enumerate(idx):
+        xb = ctx.sample_step(xb, i, coefs[k], pz[k])
+    assert torch.equal(xa, xb)
+    ctx.close()
+    nm.close()
+
+
 def test_control_branch_without_condition_cfg_vs_oracle():
     """condition_encode_cfg.condition_cfg=False: the control condition also drives the unconditional CFG half
     (controlnet.py forward_test: `c * cond_type` only when condition_cfg)."""
