@@ -160,6 +160,15 @@ int mc_ctx_set_precision(mc_ctx* c, int32_t precision);
 #define MC_TIE_STABLE 0
 #define MC_TIE_REVERSE 1
 int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy);
+/* Kernel-selection switches of ONE context (no reference counterpart: the reference has one code path; these exist for A/B
+ * measurement and for the tests that pin alternative kernels to each other).  The MC_* environment variables of the same
+ * meaning only seed the defaults of contexts created afterwards; two contexts of one process may differ.  Keys:
+ *   "chain" (bit mask), "big_tokens", "split_groups", "small_gemm_rows", "split_rows_expert",
+ *   "split_rows_sffn", "split_expert", "split_sffn", "temporal_split", "rowchain_split", "gemm_tune", "small_tile_n",
+ *   "gemm_wp_grid", "half_min_rows", "gate_small", "route_reg", "route_small", "route_coop".
+ * Results never depend on them beyond fp32 summation order where DESIGN.md says so.  Unknown key -> MC_ERR_ARG.
+ * Not while a captured graph exists (mc_ctx_graph_release first). */
+int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value);
 int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t num_steps, void* stream);
 int mc_ctx_set_condition(mc_ctx* c, const float* xf_out_dev, const float* mask_dev, void* stream);
 /* control condition (ControlT2MHalf.forward_c + controlnet[0].before_proj, controlnet.py:186-199, 66):

@@ -20,16 +20,6 @@ namespace {
 //            with k/q broadcast inside the HD-lane group   (efficient_attention.py:25-46, mask == 1)
 // No LDS, no barriers; every load/store instruction of a wave covers 256 contiguous bytes.
 // ---------------------------------------------------------------------------------------
-template <class F, int... S>
-__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, S...>) {
-    (f(std::integral_constant<int, S>{}), ...);
-}
-// f(integral_constant<int, s>) for s = 0..15: the DPP control word must be an immediate
-template <class F>
-__device__ __forceinline__ void static_for_16(F&& f) {
-    static_for_seq(f, std::make_integer_sequence<int, 16>{});
-}
-
 template <int HD, int H>
 __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, long ldmf, const float* __restrict__ qkv,
                                                    const float* __restrict__ wsm, float* __restrict__ ys, long frames,
@@ -415,13 +405,12 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 }
 
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag) {
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag, long lsplit_max) {
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
     // small batches: a few dozen (sample, part) workgroups, each bound by its waves' serial MFMA chain -> cut the L output
     // columns into 32-wide slices on blockIdx.y (temporal_k<L, true>).  50-step DDIM, 196 frames: B=1 70.4 -> 66.4 ms, B=2 96.1 ->
     // 92.3, B=4 128.3 -> 127.0; from B=8 (192 workgroups) the unsplit kernel is faster again
-    static const long lsplit_max = [] { const char* e = getenv("MC_TEMPORAL_SPLIT"); return e ? atol(e) : 96L; }();
     if (L >= 64 && (long)nb * H <= lsplit_max) {
         grid.y = L / 32;
         grid.z = (long)nb * H * (L / 32) * 2 <= 256 ? 2 : 1;      // still one workgroup per CU: the output rows halved as well (B=1: 96 -> 192 workgroups)

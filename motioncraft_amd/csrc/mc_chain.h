@@ -76,12 +76,16 @@ struct RowChainArgs {
     const float* bias2 = nullptr;
     float* Y2 = nullptr;           // [N][ldy2]
     long ldy2 = 0;
+    // pqbody (projqkv + the body-topology attention in one kernel): softmax(body_weight) [H][H] and the ys output [frames][H*L]
+    const float* wsm = nullptr;
+    float* ys = nullptr;
+    long split_tokens = 20480;     // rowchain: launches of up to this many tokens slice the output chunks 4 ways over blockIdx.y
     long pad_row = -1;             // projqkv: first of 128 PADDING rows of Y and Y2 (behind the last real token): invalid lanes store there unconditionally
 };
 
-bool mc_chain_enabled(int which);   // 0: fused mlp, 1: gate, 2: rowchain (proj, qkv)   (env MC_CHAIN bitmask, default all)
 bool mc_mlp_supported(int L, int hidden);
 int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStream_t s);
 int mc_launch_gate(const GateArgs& g, hipStream_t s);
 int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s);   // 0: combine+GELU+proj, 1: LN+linear
+int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s);        // projqkv + body topology over frame-aligned tiles (L = 128, H = 12): q/k/v stay on chip, ys written
 int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s);              // both in one pass (gamma/beta = the LayerNorm of kind 1)

@@ -565,18 +565,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_k(RowChainArgs g) {
     }
 }
 
-int tune_bits() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MC_CHAIN");
-        v = e ? atoi(e) : 32759;      // bits: 0 fused mlp, 1 gate, 2 rowchain, 3 temporal on the side stream at any batch, 4 CFG twin dedupe in layer 0, 5 CFG halves on two streams, 6 per-group expert launches, 7 last FiLM Linear + decoder on the CFG-combined rows (folded), 8 twin aliasing of mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers, 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel, 12 small batches: the SFFN's split-hidden partial sums are added up by the FiLM row kernel instead of a reduce launch (the same fold into the 4 column slices of rowchain_k was measured slower: B=1 +2.6 ms), 13 B=1 sizes: the expert MLP picks 3 or 4 hidden slices on the device from the real tile count, 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream
-    }
-    return v;
-}
-
 }  // namespace
-
-bool mc_chain_enabled(int which) { return (tune_bits() >> which) & 1; }
 
 bool mc_mlp_supported(int L, int hidden) { return (L == 32 || L == 64 || L == 128) && hidden % 32 == 0 && hidden >= 32 && hidden <= 1024; }
 
@@ -736,15 +725,254 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
     return MC_OK;
 }
 
-static long rowchain_split_tokens() {
-    static const long v = [] { const char* e = getenv("MC_ROWCHAIN_SPLIT"); return e ? atol(e) : 20480L; }();
-    return v;
+// =================================================================================================
+// pqbody_k: projqkv_k AND the body-topology attention (static 12 x 12 + EfficientSelfAttention over the H parts of a frame,
+// st_attention.py:123-134, efficient_attention.py:25-46) in one pass over FRAME-ALIGNED tiles: a workgroup owns FR = 128 / H whole
+// frames (H = 12: 10 frames = 120 token rows, the last 8 rows of the 128-row MFMA tile idle), so every frame's q / k / v meet inside
+// one workgroup.  The q/k/v weight stream is walked per 32-channel group (= 2 dynamic heads) in the order q, k, v; each 32 x 32
+// C^T fragment (lane = token, registers = channels) is parked in one of two 18 KB LDS slots and read back transposed (lane =
+// channel of one (frame, head), registers = the H parts): exactly body_reg_k's register layout, whose DPP-row contractions run
+// unchanged.  q/k/v never exist in HBM and ys is written from here; only the raw body_value chunk comes back from L2 (this
+// workgroup stored it into mf during the projection phase).
+//   slot plan (S0 / S1 swap every channel group; one barrier per weight chunk, as in projqkv_k):
+//     [q chunk -> Sq] b [k chunk -> Sk ; read q(Sq), softmax_16] b [v chunk -> Sq ; read k(Sk), softmax_H] b [read v(Sq): A = k^T v, y = q A]
+//   20 (frame, head) units of 16 lanes per channel group = 5 wave passes over 4 waves: wave w takes frames 2w, 2w+1, the fifth pass
+//   (frames 8, 9) rotates over the waves with the channel group.
+// =================================================================================================
+// NQ = H: the set produces all H parts of its frames; NQ < H: parts [h0, h0 + NQ) only (the fifth pass is cut 4 ways by parts:
+// every wave rebuilds A = k^T v of the two odd frames and projects H / 4 of their query rows)
+template <int H, int NQ>
+struct BodySet {
+    float q[NQ], k[H];
+    int fl;        // frame of this lane inside the tile
+    int h0;        // first part this set projects
+    bool on;       // the frame exists (inside the tile, inside the range, not aliased)
+};
+
+template <int L, int H>
+__global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
+    static_assert(L == 128, "pqbody_k: the body phase maps one dynamic head (16 channels) onto one DPP row");
+    constexpr int NJ = L / 8, NC0 = 4 * L / 32, NG = L / 32, NKEEP = L / 32, NSEQ = NC0 + 3 * NG;
+    constexpr int FR = 128 / H, TR = FR * H;        // frames / token rows of a tile
+    constexpr int NPASS = (FR + 1) / 2;             // wave passes of the body phase (2 frames x 32 channels per pass)
+    constexpr int XS = 36;                          // exchange slot row stride (b128 fragment writes conflict-free)
+    using SP = ChunkStage<32, L>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 7 * L + 2 * 128 * XS + H * H];
+    auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
+    float* s_bias = smem + 2 * 32 * SP::LDS_LD;      // proj bias [4L] | qkv bias [3L]
+    float* s_x = s_bias + 7 * L;                     // two exchange slots [128][XS]
+    float* s_w = s_x + 2 * 128 * XS;                 // softmax(body_weight) [H][H]
+    auto Xs = [&](int slot) { return s_x + slot * 128 * XS; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
+    for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
+    for (int i = tid; i < H * H; i += 256) s_w[i] = g.wsm[i];
+    const long tile_tok0 = g.tok0 + (long)blockIdx.x * TR;
+    const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
+    if (aliasing && tile_tok0 >= g.alias.from) return;
+    const int r = wave * 32 + (lane & 31);
+    const long tok = tile_tok0 + r;
+    const bool rok = r < TR && tok < g.N && !(aliasing && tok >= g.alias.from);
+    const int kq = (lane >> 5) * 4;
+    SP sp;
+    // chunk sequence: 0 .. NC0-1 projection rows; then per channel group cg: q rows 32cg, k rows L + 32cg, v rows 2L + 32cg
+    auto fetch = [&](int seq) {
+        if (seq < NC0) sp.fetch(g.W, L, seq * 32, 0, tid);
+        else {
+            const int u = seq - NC0, cgi = u / 3, j = u - 3 * cgi;
+            sp.fetch(g.W2, L, j * L + cgi * 32, 0, tid);
+        }
+    };
+    fetch(0);
+    f32x4 xf[NJ];
+    {
+        const long tk = tok < g.N ? tok : 0;
+        const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
+        const long ty = (g.twin_from > 0 && tk >= g.twin_from) ? tk - g.twin_from : tk;
+        const float* y0 = g.X + 2 * ty * L + kq;
+        f32x4 ya[NJ], yb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            ya[j] = *reinterpret_cast<const f32x4*>(y0 + 8 * j);
+            yb[j] = *reinterpret_cast<const f32x4*>(y0 + L + 8 * j);
+        }
+        const bool k0 = w0 != 0.f, k1 = w1 != 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[j][i] = gelu_exact((k0 ? w0 * ya[j][i] : 0.f) + (k1 ? w1 * yb[j][i] : 0.f));
+    }
+    sp.commit(Ws(0), tid);
+    fetch(1);
+    __syncthreads();
+    // projection phase: as projqkv_k (unconditional stores, invalid lanes into the padding rows behind the last token)
+    const long trow = rok ? tok : g.pad_row + (long)(wave * 32 + (lane & 31));
+    float* orow = g.Y + trow * g.ldy + kq;
+    f32x4 bvf[NJ];
+#define MC_PB_CHUNK(seq, OUT, BIAS0, KEEP)                                                                 \
+    {                                                                                                      \
+        const f32x16 a = chunk_mma<NJ>(Ws((seq) & 1), xf, lane);                                          \
+        sp.commit(Ws(((seq) & 1) ^ 1), tid);                                                               \
+        fetch((seq) + 2);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + (BIAS0) + 8 * q + kq);              \
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]}; \
+            *reinterpret_cast<f32x4*>((OUT) + 8 * q) = v;                                                 \
+            KEEP                                                                                           \
+        }                                                                                                  \
+        __syncthreads();                                                                                   \
+    }
+#pragma unroll
+    for (int c = 0; c < NKEEP; ++c) MC_PB_CHUNK(c, orow + c * 32, c * 32, bvf[4 * c + q] = v;)
+#pragma unroll 1
+    for (int c = NKEEP; c < NC0; ++c) MC_PB_CHUNK(c, orow + c * 32, c * 32, )
+#undef MC_PB_CHUNK
+    frag_layernorm<NJ>(bvf, g.gamma, g.beta, kq);
+
+    // ---- q/k/v + body phase ----
+    // one weight chunk: MFMAs on the LayerNormed body_value fragment -> commit / fetch of the stream -> fragment (+ bias) into an
+    // exchange slot [token row][32 channels]
+    auto qkv_chunk = [&](int seq, int bias0, float* slot) {
+        const f32x16 a = chunk_mma<NJ>(Ws(seq & 1), bvf, lane);
+        if (seq + 1 < NSEQ) sp.commit(Ws((seq & 1) ^ 1), tid);
+        if (seq + 2 < NSEQ) fetch(seq + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        float* xr = slot + r * XS + kq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + bias0 + 8 * q + kq);
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]};
+            *reinterpret_cast<f32x4*>(xr + 8 * q) = v;
+        }
+    };
+    const int cc = lane & 31;                       // channel inside the group: head (cc >> 4), lane (cc & 15) of its DPP row
+    auto set_init = [&](auto& b, int pass, int h0) {
+        b.fl = 2 * pass + (lane >> 5);
+        b.h0 = h0;
+        const long t0 = tile_tok0 + (long)b.fl * H;
+        b.on = pass < NPASS && b.fl < FR && t0 < g.N && !(aliasing && t0 >= g.alias.from);
+    };
+    auto stage_q = [&](auto& b, const float* slot) {        // query: softmax over the 16 channels of the head
+        constexpr int NQ = sizeof(b.q) / sizeof(float);
+        if (!b.on) return;
+        const float* x = slot + (b.fl * H + b.h0) * XS + cc;
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) b.q[h] = x[h * XS];
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            const float m = group_max(b.q[h], 16);
+            const float e = fast_exp2((b.q[h] - m) * LOG2E);
+            b.q[h] = e * __frcp_rn(group_sum(e, 16));
+        }
+    };
+    auto stage_k = [&](auto& b, const float* slot) {        // key: softmax over the H body parts (in-lane)
+        if (!b.on) return;
+        const float* x = slot + (b.fl * H) * XS + cc;
+#pragma unroll
+        for (int h = 0; h < H; ++h) b.k[h] = x[h * XS];
+        float m = b.k[0];
+#pragma unroll
+        for (int h = 1; h < H; ++h) m = fmaxf(m, b.k[h]);
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) { b.k[h] = fast_exp2((b.k[h] - m) * LOG2E); sum += b.k[h]; }
+        const float rs = __frcp_rn(sum);
+#pragma unroll
+        for (int h = 0; h < H; ++h) b.k[h] *= rs;
+    };
+    auto stage_v = [&](auto& b, const float* slot, int cg) {  // A = k^T v, y = q A (+ static topology + residual) -> ys
+        constexpr int NQ = sizeof(b.q) / sizeof(float);
+        if (!b.on) return;
+        const long t0 = tile_tok0 + (long)b.fl * H;
+        const float* x = slot + (b.fl * H) * XS + cc;
+        const float* bvp = g.Y + t0 * g.ldy + cg * 32 + cc;      // raw body_value: stored by this workgroup in the projection phase
+        float v[H], bv[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) bv[h] = bvp[h * g.ldy];
+#pragma unroll
+        for (int h = 0; h < H; ++h) v[h] = x[h * XS];
+        float A_[16];
+        auto contract_kv = [&](auto S) {
+            float a = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) a += row_ror<decltype(S)::value>(b.k[h]) * v[h];
+            A_[decltype(S)::value] = a;
+        };
+        static_for_16(contract_kv);
+        float* out = g.ys + (t0 / H) * (long)(H * L) + cg * 32 + cc;
+        if constexpr (NQ == H) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float st = 0.f;
+#pragma unroll
+                for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
+                float dy = 0.f;
+                auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(b.q[h]) * A_[decltype(S)::value]; };
+                static_for_16(contract_qa);
+                out[h * L] = st + (bv[h] + dy);
+            }
+        } else {
+#pragma unroll
+            for (int hq = 0; hq < NQ; ++hq) {
+                const int h = b.h0 + hq;               // wave-uniform
+                float st = 0.f;
+#pragma unroll
+                for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
+                float dy = 0.f;
+                auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(b.q[hq]) * A_[decltype(S)::value]; };
+                static_for_16(contract_qa);
+                float bvh = bv[0];                     // bv[h] for a runtime (wave-uniform) h without indexing the register array
+#pragma unroll
+                for (int j = 1; j < H; ++j) bvh = j == h ? bv[j] : bvh;
+                out[h * L] = st + (bvh + dy);
+            }
+        }
+    };
+    static_assert(H % 4 == 0 && NPASS <= 5, "pqbody_k: 4 full passes + one pass cut 4 ways by parts");
+    BodySet<H, H> b0;
+    BodySet<H, H / 4> b1;
+#pragma unroll 1
+    for (int cg = 0; cg < NG; ++cg) {
+        const int seq = NC0 + 3 * cg;
+        float* Sq = Xs(cg & 1);
+        float* Sk = Xs((cg & 1) ^ 1);
+        set_init(b0, wave, 0);
+        set_init(b1, 4, wave * (H / 4));
+        qkv_chunk(seq, 4 * L + cg * 32, Sq);                      // q
+        __syncthreads();
+        qkv_chunk(seq + 1, 5 * L + cg * 32, Sk);                  // k
+        stage_q(b0, Sq);
+        stage_q(b1, Sq);
+        __syncthreads();
+        qkv_chunk(seq + 2, 6 * L + cg * 32, Sq);                  // v (every q read of Sq happened before the barrier above)
+        stage_k(b0, Sk);
+        stage_k(b1, Sk);
+        __syncthreads();
+        stage_v(b0, Sq, cg);
+        stage_v(b1, Sq, cg);
+        // (next group: q -> Sk, whose k reads are behind the barrier above; k -> Sq only after the next barrier, which every wave
+        //  reaches after its v reads)
+    }
+}
+
+int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s) {
+    MC_REQUIRE(g.L == 128 && H == 12, "pqbody: L=%d H=%d unsupported (128, 12)", g.L, H);
+    MC_REQUIRE(g.Nout == 4 * g.L && g.ldy == 4 * g.L && g.W2 && g.bias2 && g.wsm && g.ys, "pqbody: bad arguments");
+    MC_REQUIRE(g.pad_row >= g.N, "pqbody: pad_row (128 padding rows of Y behind the last token) not set");
+    MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
+    if (g.N <= g.tok0) return MC_OK;
+    const long frames = (g.N - g.tok0) / H;
+    dim3 grid(cdiv(frames, 128 / H));
+    hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, g);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
 }
 
 int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s) {
     MC_REQUIRE(g.Nout % 32 == 0 && g.ldy % 4 == 0, "rowchain: Nout=%d / ldy unsupported", g.Nout);
     if (g.N <= g.tok0) return MC_OK;
-    dim3 grid(cdiv(g.N - g.tok0, 128), (g.N - g.tok0 <= rowchain_split_tokens() && (g.Nout / 32) % 4 == 0) ? 4 : 1);
+    dim3 grid(cdiv(g.N - g.tok0, 128), (g.N - g.tok0 <= g.split_tokens && (g.Nout / 32) % 4 == 0) ? 4 : 1);
 #define MC_RC_CASE(LL)                                                                    \
     case LL:                                                                              \
         if (kind == 0) hipLaunchKernelGGL((rowchain_k<LL, 0>), grid, dim3(256), 0, s, g);  \

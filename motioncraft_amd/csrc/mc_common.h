@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -81,6 +82,16 @@ template <int N>
 __device__ __forceinline__ float row_ror(float x) {
     if constexpr (N == 0) return x;
     else return dpp_read<0x120 + N>(x);
+}
+
+// f(integral_constant<int, s>) for s = 0..15: a DPP control word must be an immediate
+template <class F, int... S>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, S...>) {
+    (f(std::integral_constant<int, S>{}), ...);
+}
+template <class F>
+__device__ __forceinline__ void static_for_16(F&& f) {
+    static_for_seq(f, std::make_integer_sequence<int, 16>{});
 }
 
 // all-reduce across `width` consecutive lanes (width a power of two <= 64, groups aligned to width): the

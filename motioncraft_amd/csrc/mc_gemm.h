@@ -39,9 +39,10 @@ struct GemmArgs {
     const int* src_row = nullptr;
     const int* dst_row = nullptr;
     const float* comb_w = nullptr;  // [M][2]
-    float* sk_slab = nullptr;       // stream-K workspace (set by the launcher): per-worker accumulator slabs
-    int* sk_sync = nullptr;         //   [0] ticket, [1] done, [2 + v] slab-ready flag of worker v
-    int tune = 0;                   // MC_GEMM_TUNE bits (set by the launcher): 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k
+    // launch options (a context passes its own, mc_ctx_set_option; the defaults come from the environment once per process)
+    int small_tile_n = 0;           // mc_launch_gemm_small: force the tile width (64, 48, 96); 0 = the load model's choice (env MC_SMALL_TILE_N)
+    int wp_grid = 0;                // workgroups of the persistent gemm_wp_k launch; 0 = default 512 (env MC_GEMM_WP_GRID), < 0 one per tile
+    int tune = -1;                  // -1 = process default (env MC_GEMM_TUNE, 49); bits: 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k
 };
 
 int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream);

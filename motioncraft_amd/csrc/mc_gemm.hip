@@ -550,227 +550,6 @@ __global__ __launch_bounds__(256, 2) void gemm_wp_k(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Stream-K big-tile variant of the plain GEMM (round 3; tools/gemm_lab2.hip / gemm_lab3.hip are its timing labs):
-//   * 256 x 256 x 16 tiles, 512 threads: wave w owns 128 activation rows x 64 weight rows (4 x 2 MFMA tiles, 128 accumulator
-//     registers), so one LDS fragment feeds 2 (weights) / 4 (activations) MFMAs instead of 2 / 2 and a workgroup fetches its
-//     operands ONCE (a quarter of gemm_wp_k's LDS-DMA traffic per MFMA);
-//   * 4-stage LDS-DMA ring (128 KB, one workgroup per CU), ONE barrier per k-tile with the MFMAs first behind it: the next
-//     stage's DMA issue and the fragment reads sit between MFMA groups, the first k-group of the NEXT k-tile is read under the
-//     second MFMA group of the current one (measured in-loop MFMA duty 96 %, 142 TFLOP/s on 4096^3 against 124-132 of gemm_wp_k);
-//   * persistent stream-K: the (tile, k-tile) iteration space is cut into gridDim.x equal contiguous ranges, so the launch
-//     has no partial last round of tiles; a tile cut by a range border is finished by the owner of its k = 0 end, which adds
-//     the other parts' fp32 accumulator slabs in a fixed order (deterministic; differs from the unsplit k order by fp32
-//     round-off).  Workers draw their range by ticket in START order and only ever wait for a slab that worker v + 1 writes
-//     as its FIRST action, so the wait cannot deadlock whatever the dispatch order or co-residency is.
-// Same k order inside a segment as gemm_wp_k / gemm_dma_k: unsplit tiles are bit-identical to those kernels.
-// Needs N % 256 == 0, K % 16 == 0, 16-byte aligned rows, 32-bit byte offsets into A and W; ragged M is fine.
-// ---------------------------------------------------------------------------------------
-constexpr int SKK = 16, SK_NST = 4, SK_STAGE = 512 * SKK;
-__global__ __launch_bounds__(512, 2) void gemm_sk_k(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float smem[SK_NST * SK_STAGE + 16];
-    int* sm_i = reinterpret_cast<int*>(smem + SK_NST * SK_STAGE);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int G = (int)gridDim.x;
-    const int ntn = g.N / 256, ntm = (g.M + 255) / 256, ntiles = ntm * ntn, nk = g.K / SKK;
-    const unsigned lds0 = (unsigned)(size_t)smem;
-    const int dr = lane >> 2, dc = ((lane & 3) ^ ((dr >> 2) & 3)) * 4;
-    const int frow = lane & 31, hf = lane >> 5, sw = (frow >> 2) & 3;
-    const float* Ab = g.A + g.a_col;
-    const float* Wb = g.W;
-    const float* __restrict__ Rb = g.R ? g.R + g.c_col : nullptr;
-    float* __restrict__ Cb = g.C + g.c_col;
-    if (tid == 0) sm_i[0] = __hip_atomic_fetch_add(g.sk_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int v = xcd_remap(__builtin_amdgcn_readfirstlane(sm_i[0]), G);
-    const unsigned I = (unsigned)ntiles * (unsigned)nk;       // (the launcher checks I * G < 2^32)
-    auto range_start = [&](int w) { return (int)((unsigned)w * I / (unsigned)G); };
-    const int it0 = range_start(v), it1 = range_start(v + 1);
-
-    struct Frag { f32x4 a[4], w[2]; };
-    f32x16 acc[4][2];
-    auto ld_frag = [&](int j, int grp) {
-        const float* S = smem + (j % SK_NST) * SK_STAGE + frow * SKK + ((2 * grp + hf) ^ sw) * 4;
-        Frag f;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) f.a[mi] = *reinterpret_cast<const f32x4*>(S + (wm * 128 + mi * 32) * SKK);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) f.w[ni] = *reinterpret_cast<const f32x4*>(S + (256 + wn * 64 + ni * 32) * SKK);
-        return f;
-    };
-    auto mma_i = [&](const Frag& f, int i) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[ni][i], f.a[mi][i], acc[mi][ni], 0, 0, 0);
-    };
-    auto wait_dyn = [&](int stages_after) {      // this wave's DMAs of the needed stage have landed when <= 4 x stages_after are in flight
-        if (stages_after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (stages_after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // k-tiles [kb, ke) of `tile` -> acc
-    auto segment = [&](int tile, int kb, int ke) {
-        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * 256;
-        const int n = ke - kb;
-        // DMA pieces of 16 rows: stage rows [0, 256) = A rows, [256, 512) = W rows; wave w moves pieces 4w .. 4w+3
-        unsigned vo[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int piece = 4 * (wave_u & 3) + q;
-            long grow = (wave_u < 4 ? row0 : col0) + 16 * piece + dr;
-            if (wave_u < 4 && grow >= g.M) grow = g.M - 1;          // ragged last row tile: re-read the last row (never stored)
-            vo[q] = (unsigned)((grow * (wave_u < 4 ? g.lda : g.ldw) + dc) * 4);
-        }
-        const float* gsrc = wave_u < 4 ? Ab : Wb;
-        auto issue_q = [&](int j, int q) {
-            dma16(vo[q], gsrc + (long)(kb + j) * SKK, lds0 + (unsigned)(j % SK_NST) * (SK_STAGE * 4) + (unsigned)(4 * wave_u + q) * 1024);
-        };
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        __syncthreads();                                         // every wave is done with the previous segment's stages
-        const int pre = n < SK_NST - 1 ? n : SK_NST - 1;
-        for (int j = 0; j < pre; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) issue_q(j, q);
-        wait_dyn(pre - 1);
-        __syncthreads();
-        Frag f0 = ld_frag(0, 0), f1;
-        for (int j = 0; j < n; ++j) {
-            const int issued = (j + SK_NST - 1 < n) ? j + SK_NST - 1 : n;      // stages issued so far
-            wait_dyn(j + 1 < n ? issued - (j + 2) : 0);                         // stage j+1 (if any) has landed for this wave
-            __syncthreads();                                                     // ... for every wave; nobody still reads stage j-1
-            const bool more = j + SK_NST - 1 < n;
-            mma_i(f0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { issue_q(j + SK_NST - 1, 0); issue_q(j + SK_NST - 1, 1); }
-            __builtin_amdgcn_sched_barrier(0);
-            mma_i(f0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { issue_q(j + SK_NST - 1, 2); issue_q(j + SK_NST - 1, 3); }
-            __builtin_amdgcn_sched_barrier(0);
-            mma_i(f0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            f1 = ld_frag(j, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_i(f0, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_i(f1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            f0 = ld_frag(j + 1, 0);                               // (past the last k-tile: stale bytes, never used)
-            __builtin_amdgcn_sched_barrier(0);
-            mma_i(f1, 1); mma_i(f1, 2); mma_i(f1, 3);
-        }
-    };
-    // bias, activation, residual, store: software pipeline over the 8 (mi, ni) blocks of 4 float4 -- the residual of block b+1
-    // is requested before block b is finished and stored
-    auto epilogue = [&](int tile) {
-        const int tn = tile % ntn, tm = tile / ntn, row0 = tm * 256, col0 = tn * 256;
-        auto load_res = [&](int b, f32x4 (&rv)[4]) {
-            long m = row0 + wm * 128 + (b >> 1) * 32 + frow;
-            if (m >= g.M) m = g.M - 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nn = col0 + wn * 64 + (b & 1) * 32 + 8 * q + 4 * hf;
-                rv[q] = Rb ? *reinterpret_cast<const f32x4*>(Rb + m * g.ldr + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        f32x4 rv[4], rn[4];
-        load_res(0, rv);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int mi = b >> 1, ni = b & 1;
-            if (b + 1 < 8) load_res(b + 1, rn);
-            const long m = row0 + wm * 128 + mi * 32 + frow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nn = col0 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
-                f32x4 o = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-                if (g.bias) o += *reinterpret_cast<const f32x4*>(g.bias + nn);
-                if (g.act != ACT_NONE) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) o[jj] = apply_act(o[jj], g.act);
-                }
-                o += rv[q];
-                if (m < g.M) *reinterpret_cast<f32x4*>(Cb + m * g.ldc + nn) = o;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rv[q] = rn[q];
-        }
-    };
-
-    int it = it0;
-    while (it < it1) {
-        const int tile = it / nk, kb = it - tile * nk;
-        const int rem = it1 - it;
-        const int ke = (rem < nk - kb) ? kb + rem : nk;
-        int ncontrib = 0;      // head part of a tile that continues in the following workers' first segments: how many of them
-        if (kb == 0 && ke < nk)
-            for (int u = v + 1; u < G && range_start(u) < (tile + 1) * nk; ++u) ++ncontrib;
-        segment(tile, kb, ke);
-        if (kb > 0) {
-            // non-head part of a tile: the accumulators go to this worker's slab, lane-linear (1 KiB per wave-instruction)
-            f32x4* s4 = reinterpret_cast<f32x4*>(g.sk_slab) + ((long)v * 8 + wave) * 32 * 64 + lane;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        s4[(mi * 8 + ni * 4 + q) * 64] = f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {      // guide section 6, Guideline 16: release fence, explicit vmcnt wait, then the flag
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(g.sk_sync + 2 + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            for (int c = 1; c <= ncontrib; ++c) {
-                const int u = v + c;
-                if (tid == 0) {
-                    // worker u drew its ticket after this one and writes the slab as its first action: bounded anyway
-                    unsigned spins = 0;
-#pragma unroll 1
-                    while (__hip_atomic_load(g.sk_sync + 2 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 28)) __builtin_trap();
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __hip_atomic_store(g.sk_sync + 2 + u, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (one reader: hands the flag back clear)
-                }
-                __syncthreads();
-                const f32x4* s4 = reinterpret_cast<const f32x4*>(g.sk_slab) + ((long)u * 8 + wave) * 32 * 64 + lane;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {              // 8 loads in flight at a time (32 registers beside the accumulators)
-                    f32x4 p[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) p[j] = s4[(mi * 8 + j) * 64];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[mi][j >> 2][4 * (j & 3) + r] += p[j][r];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            epilogue(tile);
-        }
-        it += ke - kb;
-    }
-    // the last worker to finish hands the ticket / done words back zeroed (stream order: the next launch on this stream's
-    // workspace starts after this one)
-    if (tid == 0 && __hip_atomic_fetch_add(g.sk_sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
-        __hip_atomic_store(g.sk_sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g.sk_sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // Small-M variant (latency-bound launches of a few hundred rows): 64 x 64 tiles, each wave one 32 x 32 MFMA tile, so
 // the serial MFMA chain per k-tile is 16 instead of 64 instructions and a K = 1536 product takes ~30 us instead of
 // ~105 us per tile; 4x more workgroups fill the chip without splitting K (no partial sums, no reduction pass).
@@ -1058,7 +837,8 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     double best = cost(SN, 30.0);
     if (g.N % 48 == 0 && cost(48, 23.0) < 0.97 * best) { nb = 48; best = cost(48, 23.0); }     // (3 % margin: near ties go to the more efficient kernel)
     if (g.N % 96 == 0 && cost(96, 41.0) < 0.97 * best) { nb = 96; best = cost(96, 41.0); }
-    if (force_nb == 64 || force_nb == 48 || force_nb == 96) nb = force_nb;
+    const int fnb = g.small_tile_n ? g.small_tile_n : force_nb;
+    if (fnb == 64 || fnb == 48 || fnb == 96) nb = fnb;
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
     const bool vec16 = vec && g.N % nb == 0;       // the float4 epilogue has no column guard
     if (nb == 48) {
@@ -1075,42 +855,9 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     return MC_OK;
 }
 
-// stream-K workspace (accumulator slabs + ticket / flag words), one per (device, stream): launches on one stream are ordered, so
-// they can share it; two streams never do
-#include <map>
-#include <mutex>
-struct SkWs { float* slab = nullptr; int* sync = nullptr; int G = 0; };
-static int sk_workspace(hipStream_t stream, SkWs* out) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SkWs> pool;
-    int dev = 0;
-    MC_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = pool.find({dev, stream});
-    if (it == pool.end()) {
-        // first use on this stream allocates + synchronises: not inside a stream capture (the caller then takes the tile kernels)
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { out->G = 0; return MC_OK; }
-        if (pool.size() >= 16) { out->G = 0; return MC_OK; }      // 64 MB of slabs per stream: a process that keeps creating streams takes the tile kernels
-        hipDeviceProp_t prop;
-        MC_HIP(hipGetDeviceProperties(&prop, dev));
-        SkWs w;
-        w.G = prop.multiProcessorCount;
-        MC_HIP(hipMalloc((void**)&w.slab, (size_t)w.G * 8 * 32 * 64 * sizeof(f32x4)));      // 256 KB per worker
-        MC_HIP(hipMalloc((void**)&w.sync, (size_t)(2 + w.G) * sizeof(int)));
-        // zeroed ON the stream that will use it (a non-blocking stream does not wait for a legacy-stream memset), then waited for
-        // once: the words are self-cleaning from then on
-        MC_HIP(hipMemsetAsync(w.sync, 0, (size_t)(2 + w.G) * sizeof(int), stream));
-        MC_HIP(hipStreamSynchronize(stream));
-        it = pool.emplace(std::make_pair(dev, stream), w).first;
-    }
-    *out = it->second;
-    return MC_OK;
-}
-
 int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipStream_t stream) {
     GemmArgs g = g0;
-    g.tune = tune_bits();
+    if (g.tune < 0) g.tune = tune_bits();
     const int ntn = cdiv(g.N, BN);
     int ntm = (mode == GM_EXP1 || mode == GM_EXP2) ? max_tiles : cdiv(g.M, BM);
     if (ntm <= 0 || ntn <= 0) return MC_OK;
@@ -1119,30 +866,11 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
     const bool vec_out = (g.ldc % 4 == 0) && (g.c_col % 4 == 0) && (!g.R || g.ldr % 4 == 0);
     if ((g.tune & 16) && mode == GM_PLAIN && groups <= 1 && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 &&
         g.lda % 4 == 0 && g.ldw % 4 == 0 && g.a_col % 4 == 0 && vec_out && g.act != ACT_QUICKGELU && !g.act_after_res) {
-        // stream-K big tiles where they win (round-3 lab, MI355X): long k (K >= 2048: 4096^3 142 vs 124-132 TFLOP/s) -- on the
-        // FiLM shape (K = 1536, 2.3 tiles of 256 x 256 per CU) the 64 KB-per-tile residual epilogues of gemm_wp_k overlap better
-        // and the two kernels tie at ~125 TFLOP/s; bit 7 of MC_GEMM_TUNE forces it for any eligible launch (A/B)
-        const bool sk_ok = g.N % 256 == 0 && g.K % SKK == 0 && g.ldc % 4 == 0 && (long)g.M * g.lda * 4 < (1L << 32) &&
-                           (long)g.N * g.ldw * 4 < (1L << 32) && g.act != ACT_QUICKGELU;
-        if (sk_ok && ((g.tune & 128) || (g.K >= 2048 && (long)cdiv(g.M, 256) * (g.N / 256) >= 128))) {
-            SkWs w;
-            int r = sk_workspace(stream, &w);
-            if (r != MC_OK) return r;
-            const long iters = (long)cdiv(g.M, 256) * (g.N / 256) * (g.K / SKK);
-            int G = w.G;
-            if (iters < G) G = (int)iters;
-            if (G > 0 && iters * G < (1L << 32)) {
-                g.sk_slab = w.slab;
-                g.sk_sync = w.sync;
-                hipLaunchKernelGGL(gemm_sk_k, dim3(G), dim3(512), 0, stream, g);
-                MC_LAUNCH_CHECK();
-                return MC_OK;
-            }
-        }
         // bit 5: wave-private pipeline variant (no k-loop barrier); needs 32-bit byte offsets into A and W
         if ((g.tune & 32) && g.K % WBK == 0 && (long)g.M * g.lda * 4 < (1L << 32) && (long)g.N * g.ldw * 4 < (1L << 32)) {
             static const int wp_grid = [] { const char* e = getenv("MC_GEMM_WP_GRID"); return e ? atoi(e) : 512; }();
-            const int persistent = wp_grid > 0 ? wp_grid : (int)grid.x;          // default: 2 workgroups per CU (64 KB of LDS each) on 256 CUs; <= 0: one workgroup per tile
+            const int wpg = g.wp_grid ? g.wp_grid : wp_grid;
+            const int persistent = wpg > 0 ? wpg : (int)grid.x;          // default: 2 workgroups per CU (64 KB of LDS each) on 256 CUs; <= 0: one workgroup per tile
             hipLaunchKernelGGL(gemm_wp_k, dim3(grid.x < persistent ? grid.x : persistent), dim3(256), 0, stream, g);
         } else
             hipLaunchKernelGGL(gemm_dma_k, grid, dim3(256), 0, stream, g);

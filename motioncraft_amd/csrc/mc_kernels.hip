@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void sampler_update_k(const float* x_t, const 
         } else {
             f32x4 nz = {0.f, 0.f, 0.f, 0.f};
             if constexpr (RNG) nz = philox_normal4(gi, rng);
-            for (int j = 0; i + j < n; ++j) {
+            for (int j = 0; j < 4 && i + j < n; ++j) {
                 const float x0 = cfg_elem(o_text[i + j], o_none[i + j], c);
                 const float z = RNG ? nz[j] : noise[i + j];
                 x_prev[i + j] = sampler_elem(x_t[i + j], x0, z, c, d);

@@ -54,10 +54,46 @@ struct LayerW {
     HalfW h_ca_out, h_ffn_out, h_fc1, h_fc2, h_w1, h_w2, h_after, h_proj, h_qkv;
 };
 
+// Per-context switches (mc_ctx_set_option).  Defaults = the measured best; a variable of the same meaning in the environment
+// (MC_CHAIN, MC_SPLIT, MC_GEMM_TUNE, ...) overrides the default of contexts created afterwards, mc_ctx_set_option overrides both for
+// one context -- two models of one process can run different kernel selections.
+struct McOptions {
+    // chain bits: 0 fused expert / SFFN MLP (mlp2_k), 1 fused gate (gate_k), 2 chained proj / qkv (rowchain_k), 3 temporal branch on the
+    // side stream at any batch size, 4 CFG twin dedupe in base layer 0, 5 two sample groups on two streams (large batches), 6 one
+    // expert-MLP launch per sample group, 7 last FiLM Linear + pose decoder on the CFG-combined rows (folded), 8 twin aliasing of the
+    // mf / qkv / ys rows in base layer 0, 9 the sample groups stay on their streams across the control-branch ops between layers,
+    // 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel,
+    // 12 small batches: the SFFN's split-hidden partial sums are added up by the FiLM row kernel, 13 B=1 sizes: the expert MLP picks
+    // 3 or 4 hidden slices on the device, 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream,
+    // 15 (round 4) pqbody_k: bit 10's kernel also runs the body-topology attention (q/k/v never in HBM; L = 128, 12 parts, fp32)
+    int chain = 65527;                 // (all but bit 3)
+    long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
+    long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
+    long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
+    long big_tokens = 65536;           // above this many motion tokens: the large-batch schedule (two sample groups on two streams, projqkv / pqbody)
+    long rowchain_split = 20480;       // tokens up to which rowchain_k slices its output chunks over blockIdx.y
+    int gemm_tune = -1, small_tile_n = 0, gemm_wp_grid = 0;      // GemmArgs::tune / small_tile_n / wp_grid (-1 / 0: library defaults)
+};
+static McOptions default_options() {
+    McOptions o;
+    if (const char* e = getenv("MC_CHAIN")) o.chain = atoi(e);
+    if (const char* e = getenv("MC_SMALL_GEMM_ROWS")) o.small_gemm_rows = atol(e);
+    if (const char* e = getenv("MC_SPLIT_ROWS_EXPERT")) o.split_rows_expert = atol(e);
+    if (const char* e = getenv("MC_SPLIT_ROWS_SFFN")) o.split_rows_sffn = atol(e);
+    if (const char* e = getenv("MC_TEMPORAL_SPLIT")) o.temporal_split = atol(e);
+    if (const char* e = getenv("MC_BIG_TOKENS")) o.big_tokens = atol(e);
+    if (const char* e = getenv("MC_ROWCHAIN_SPLIT")) o.rowchain_split = atol(e);
+    if (const char* e = getenv("MC_GEMM_TUNE")) o.gemm_tune = atoi(e);
+    if (const char* e = getenv("MC_SMALL_TILE_N")) o.small_tile_n = atoi(e);
+    if (const char* e = getenv("MC_GEMM_WP_GRID")) o.gemm_wp_grid = atoi(e);
+    return o;
+}
+
 struct ProfRec { hipEvent_t e0 = nullptr, e1 = nullptr; long rows = 0; };
 
 struct mc_ctx {
     mc_model* m = nullptr;
+    McOptions opt = default_options();
     int B = 0, T = 0, S = 0, maxS = 0;
     long N = 0, rows = 0, Ntxt = 0;
     std::vector<LayerW> lw;
@@ -72,6 +108,7 @@ struct mc_ctx {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2, *xpad;
+    size_t hbuf_cap = 0;        // floats allocated behind hbuf
     size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
     bool cnt_clean = false;     // the routing state's (choice, expert) counts are known to be zero on the stream (route_small_k cleans up after itself)
     float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
@@ -306,23 +343,25 @@ int bind_half_weights(mc_ctx* c) {
 static bool use_half(const mc_ctx* c) { return c->prec != MC_PREC_F32 && c->rows > c->half_min_rows; }
 
 // residual rows up to which the fused MLPs split their hidden dimension over workgroups (which = 0 experts, 1 SFFN)
-static long split_rows(int which) {
-    static const long v[2] = {[] { const char* e = getenv("MC_SPLIT_ROWS_EXPERT"); return e ? atol(e) : 2048L; }(),
-                              [] { const char* e = getenv("MC_SPLIT_ROWS_SFFN"); return e ? atol(e) : 8192L; }()};
-    return v[which];
+static long split_rows(const mc_ctx* c, int which) { return which ? c->opt.split_rows_sffn : c->opt.split_rows_expert; }
+static const McOptions& options_of(const mc_ctx* c) {
+    static const McOptions dflt = default_options();      // context-free ops (mc_op_gemm)
+    return c ? c->opt : dflt;
+}
+static long small_gemm_rows(const mc_ctx* c) { return options_of(c).small_gemm_rows; }
+static bool chain_on(const mc_ctx* c, int which) { return (options_of(c).chain >> which) & 1; }
+static void gemm_opts(const mc_ctx* c, GemmArgs& g) {
+    const McOptions& o = options_of(c);
+    g.tune = o.gemm_tune; g.small_tile_n = o.small_tile_n; g.wp_grid = o.gemm_wp_grid;
 }
 
-static long small_gemm_rows() {
-    static const long v = [] { const char* e = getenv("MC_SMALL_GEMM_ROWS"); return e ? atol(e) : 6400L; }();
-    return v;
-}
-
-int dense(const float* A, long lda, const float* W, long ldw, const float* bias, const float* R, long ldr,
+int dense(const mc_ctx* c, const float* A, long lda, const float* W, long ldw, const float* bias, const float* R, long ldr,
           float* C, long ldc, long M, int N, int K, int act, hipStream_t s) {
     GemmArgs g;
+    gemm_opts(c, g);
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R = R; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
-    if (M <= small_gemm_rows() && act == ACT_NONE && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0)
+    if (M <= small_gemm_rows(c) && act == ACT_NONE && K % 32 == 0 && lda % 4 == 0 && ldw % 4 == 0)
         return mc_launch_gemm_small(g, s);          // latency-bound sizes: 64 x 64 tiles (see gemm_small_k)
     return mc_launch_gemm(GM_PLAIN, g, 1, 0, s);
 }
@@ -339,14 +378,15 @@ int dense_h(const mc_ctx* c, const float* A, const HalfW& hw, const float* bias,
 // Small batches: a [M x K] x [K x N] GEMM with fewer than ~128 output tiles leaves most of the 256 CUs idle while each
 // tile walks the whole K serially.  Split K across workgroups (the grouped launch with column offsets as "group"
 // strides), partial sums in `ws`, reduced in a fixed order: C = sum_s A[:, s] W[:, s]^T + bias + R.
-int dense_splitk(const float* A, const float* W, const float* bias, const float* R, float* C, long M, int N, int K,
+int dense_splitk(const mc_ctx* c, const float* A, const float* W, const float* bias, const float* R, float* C, long M, int N, int K,
                  float* ws, size_t ws_floats, hipStream_t s) {
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
     int S = 1;
     // (up to two rounds of the 512 workgroup slots: measured better than stopping at one, B=4 -4.5 %)
     while (S < 8 && tiles * (S * 2) <= 1024 && K % (S * 2 * 32) == 0 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
-    if (S == 1) return dense(A, K, W, K, bias, R, N, C, N, M, N, K, ACT_NONE, s);
+    if (S == 1) return dense(c, A, K, W, K, bias, R, N, C, N, M, N, K, ACT_NONE, s);
     GemmArgs g;
+    gemm_opts(c, g);
     g.A = A; g.lda = K; g.a_gstride = K / S;          // split s reads columns [s K/S, (s+1) K/S) of A and of W
     g.W = W; g.ldw = K; g.w_gstride = K / S;
     g.C = ws; g.ldc = N; g.c_gstride = M * N;
@@ -366,7 +406,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
     const int max_tiles = cdiv(2 * Ntok, 128) + E;
     const long to = (long)group * c->rb.max_tiles;
     int r;
-    if (mc_chain_enabled(0) && mc_mlp_supported(din, hid)) {
+    if (chain_on(c, 0) && mc_mlp_supported(din, hid)) {
         // fused expert FFN: hidden activations stay on chip (mc_chain.hip)
         MlpArgs m;
         m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
@@ -391,11 +431,11 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
             S = 4;
             if (hid / 32 >= 4 && load(3) < 0.92 * load(4) && tiles * 3 > 300) S = 3;     // (tiles * 3 <= 300: B = 1, see above)
         }
-        if (z == c->z && c->rows <= split_rows(0) && c->N <= 65536 && S > 1 && hid / 32 >= S &&      // (c->N <= 65536: the one-stream schedule, one user of hbuf)
+        if (z == c->z && c->rows <= split_rows(c, 0) && c->N <= c->opt.big_tokens && S > 1 && hid / 32 >= S &&      // (N <= big_tokens: the one-stream schedule, one user of hbuf)
             c->hbuf_floats >= (size_t)S * 2 * Ntok * din) {
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = 2 * Ntok * din;
             // B = 1 sizes (the estimated tile count straddles 256 / 3): 3 or 4 ways decided on the device from the real count
-            const bool dyn = S == 4 && c->split_expert == 0 && (2 * Ntok / 128 + E / 2) * 3 <= 300 && mc_chain_enabled(13);
+            const bool dyn = S == 4 && c->split_expert == 0 && (2 * Ntok / 128 + E / 2) * 3 <= 300 && chain_on(c, 13);
             m.dyn_split = dyn ? 1 : 0;
             if ((r = mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s))) return r;
             return mc_launch_splitk_reduce(c->hbuf, S, 2 * Ntok, din, nullptr, nullptr, c->y2, s,
@@ -404,6 +444,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         return mc_launch_mlp(MLP_EXPERT, m, 1, max_tiles, s);
     }
     GemmArgs a;
+    gemm_opts(c, a);
     a.A = z; a.lda = din; a.src_row = c->rb.src_row;
     a.W = w.fc1_w; a.ldw = din; a.w_gstride = (long)hid * din;
     a.bias = w.fc1_b; a.b_gstride = hid; a.act = ACT_GELU;
@@ -412,6 +453,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
     a.num_tiles = mc_route_num_tiles_ptr(c->rb, group);
     if ((r = mc_launch_gemm(GM_EXP1, a, 1, max_tiles, s))) return r;
     GemmArgs b;
+    gemm_opts(c, b);
     b.A = c->hbuf; b.lda = hid; b.W = w.fc2_wt; b.ldw = hid; b.w_gstride = (long)din * hid;
     b.bias = w.fc2_b; b.b_gstride = din; b.dst_row = c->rb.dst_row;
     b.C = c->y2; b.ldc = din; b.N = din; b.K = hid;
@@ -430,7 +472,7 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     int r;
     if (!gated) {
         // cosine projector (tutel/gates/cosine_top.py): proj = z Wp^T + bp
-        if ((r = dense(z, din, w.gate_w, din, w.gate_b, nullptr, 0, c->proj, 256, Ntok, 256, din, ACT_NONE, s))) return r;
+        if ((r = dense(c, z, din, w.gate_w, din, w.gate_b, nullptr, 0, c->proj, 256, Ntok, 256, din, ACT_NONE, s))) return r;
         if ((r = mc_launch_gate_finish(c->proj, w.sim_n, w.scale, Ntok, E, c->rb, s))) return r;
     }
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
@@ -440,14 +482,16 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     if (gsplit < Ntok) return MC_OK;
     if ((r = moe_experts(c, w, z, Ntok, 0, s, hw, hw2))) return r;
     if (!out) return MC_OK;                        // the caller launches the projection itself (row ranges)
-    if (mc_chain_enabled(2) && mc_mlp_supported(din, 32) && w.dout % 32 == 0) {
+    if (chain_on(c, 2) && mc_mlp_supported(din, 32) && w.dout % 32 == 0) {
         RowChainArgs p;
+        p.split_tokens = c->opt.rowchain_split;
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.proj_w; p.bias = w.proj_b;
         p.Y = out; p.ldy = ldout; p.N = Ntok; p.L = din; p.Nout = w.dout;
         p.twin_from = twin ? Ntok / 2 : 0;
         return mc_launch_rowchain(0, p, s);
     }
     GemmArgs p;
+    gemm_opts(c, p);
     p.A = c->y2; p.lda = din; p.comb_w = c->rb.comb_w;
     p.W = w.proj_w; p.ldw = din; p.bias = w.proj_b;
     p.C = out; p.ldc = ldout; p.M = (int)Ntok; p.N = w.dout; p.K = din;
@@ -470,21 +514,22 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
     if (hw && hw->hi && use_half(c))
         return dense_h(c, c->a + o, *hw, out_b, hs + o, hs + o, nrows, D, D, s);
-    if (nrows <= small_gemm_rows() && D % 64 == 0) {     // up to a few thousand rows: 64 x 64 tiles, short MFMA chains, no K split (B=8: -11 % per step)
+    if (nrows <= small_gemm_rows(c) && D % 64 == 0) {     // up to a few thousand rows: 64 x 64 tiles, short MFMA chains, no K split (B=8: -11 % per step)
         GemmArgs q;
+        gemm_opts(c, q);
         q.A = c->a + o; q.lda = D; q.W = out_w; q.ldw = D; q.bias = out_b; q.R = hs + o; q.ldr = D; q.C = hs + o; q.ldc = D;
         q.M = (int)nrows; q.N = D; q.K = D;
         return mc_launch_gemm_small(q, s);
     }
     if (nrows <= 2048 && c->hbuf_floats)       // few output tiles: split K (hbuf is free scratch on the fused path)
-        return dense_splitk(c->a + o, out_w, out_b, hs + o, hs + o, nrows, D, D, c->hbuf, c->hbuf_floats, s);
-    if (!c->prof_on) return dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
+        return dense_splitk(c, c->a + o, out_w, out_b, hs + o, hs + o, nrows, D, D, c->hbuf, c->hbuf_floats, s);
+    if (!c->prof_on) return dense(c, c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
     // mc_ctx_profile: HIP events around this launch ON THE STREAM IT IS LAUNCHED ON (the sample group's stream)
     ProfRec pr;
     pr.rows = nrows;
     if (hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess) { mc_set_error("hipEventCreate failed"); return MC_ERR_HIP; }
     MC_HIP(hipEventRecord(pr.e0, s));
-    r = dense(c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
+    r = dense(c, c->a + o, D, out_w, D, out_b, hs + o, D, hs + o, D, nrows, D, D, ACT_NONE, s);
     MC_HIP(hipEventRecord(pr.e1, s));
     c->prof.push_back(pr);
     return r;
@@ -497,7 +542,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     // twin layer: rows of the second CFG half whose routing equals their twin's are aliased, not recomputed
     TwinAlias tok_alias, frame_alias;
     const int* twin_flag = nullptr;
-    if (twin && mc_chain_enabled(8) && !c->no_alias) {
+    if (twin && chain_on(c, 8) && !c->no_alias) {
         twin_flag = mc_route_split_flag_ptr(c->rb);
         tok_alias.split_flag = frame_alias.split_flag = twin_flag;
         tok_alias.from = c->N / 2;
@@ -511,9 +556,13 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     // ---- post-score combine + GELU + MOE.proj -> mf [N][4L] ----
     // large batches: proj + body LayerNorm + q/k/v as one kernel (small ones keep them apart: the temporal branch then
     // starts on the side stream right after the projection)
-    const bool pq_fused = mc_chain_enabled(2) && mc_chain_enabled(10) && c->N > 65536 && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0;
-    if (mc_chain_enabled(2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
+    const bool pq_fused = chain_on(c, 2) && chain_on(c, 10) && c->N > c->opt.big_tokens && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0;
+    // ... and the body-topology attention too (pqbody_k: frame-aligned tiles, q/k/v never leave the chip): fp32 path, L = 128, 12 parts
+    const bool body_fused = pq_fused && chain_on(c, 15) && L == 128 && H == 12 && g.dyn_heads == 8 &&
+                            !(use_half(c) && w.h_proj.hi && w.h_qkv.hi);
+    if (chain_on(c, 2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
         RowChainArgs p;
+        p.split_tokens = c->opt.rowchain_split;
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.mm.proj_w; p.bias = w.mm.proj_b;
         p.Y = c->mf; p.ldy = 4 * L; p.tok0 = tok0; p.N = tok0 + ntok; p.L = L; p.Nout = 4 * L;
         p.twin_from = twin ? c->N / 2 : 0;
@@ -521,12 +570,16 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         if (pq_fused) {       // + the dynamic body topology's shared LayerNorm and q/k/v on the body_value columns
             p.gamma = w.dyn_g; p.beta = w.dyn_b; p.W2 = w.qkv_w; p.bias2 = w.qkv_b; p.Y2 = c->qkv; p.ldy2 = 3 * L;
             p.pad_row = c->N;      // mf / qkv carry 128 padding rows (mc_ctx_create): projqkv_k's stores are unconditional
-            if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
+            if (body_fused) {
+                p.wsm = w.wsm; p.ys = c->ys;
+                if ((r = mc_launch_pqbody(p, H, s))) return r;
+            } else if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
                 if ((r = mc_launch_projqkv_h(p, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
             } else if ((r = mc_launch_projqkv(p, s))) return r;
         } else if ((r = mc_launch_rowchain(0, p, s))) return r;
     } else {
         GemmArgs p;
+        gemm_opts(c, p);
         p.A = c->y2 + 2 * tok0 * L; p.lda = L; p.comb_w = c->rb.comb_w + 2 * tok0;
         p.W = w.mm.proj_w; p.ldw = L; p.bias = w.mm.proj_b;
         p.C = c->mf + tok0 * 4 * L; p.ldc = 4 * L; p.M = (int)ntok; p.N = 4 * L; p.K = L;
@@ -542,26 +595,28 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     if (st != s) {
         MC_HIP(hipEventRecord(c->ev_fork, s));
         MC_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
-        if (mc_chain_enabled(14) && c->rows <= 1200) sb = st; else stt = st;      // (B <= 3 at 196 frames: -1.5 .. -3 %; B = 4: +1 %)
+        if (chain_on(c, 14) && c->rows <= 1200) sb = st; else stt = st;      // (B <= 3 at 196 frames: -1.5 .. -3 %; B = 4: +1 %)
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
     if (pq_fused) {
         // q/k/v were produced by projqkv_k above
-    } else if (mc_chain_enabled(2) && mc_mlp_supported(L, 32)) {
+    } else if (chain_on(c, 2) && mc_mlp_supported(L, 32)) {
         RowChainArgs q;
+        q.split_tokens = c->opt.rowchain_split;
         q.X = c->mf; q.ldx = 4 * L; q.gamma = w.dyn_g; q.beta = w.dyn_b; q.W = w.qkv_w; q.bias = w.qkv_b;
         q.Y = c->qkv; q.ldy = 3 * L; q.tok0 = tok0; q.N = tok0 + ntok; q.L = L; q.Nout = 3 * L;
         q.alias = tok_alias;
         if ((r = mc_launch_rowchain(1, q, sb))) return r;
     } else {
         if ((r = mc_launch_ln_rows(c->mf + tok0 * 4 * L, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z + tok0 * L, L, ntok, L, sb))) return r;
-        if ((r = dense(c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, sb))) return r;
+        if ((r = dense(c, c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, sb))) return r;
     }
-    if ((r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, sb,
+    if (!body_fused &&
+        (r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, sb,
                             frame_alias, row0))) return r;
     if (sb != s) MC_HIP(hipEventRecord(c->ev_join, sb));
     if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
-                                g.max_text_len, H, L, stt, twin_flag))) return r;
+                                g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split))) return r;
     if (stt != s) MC_HIP(hipEventRecord(c->ev_join, stt));
     if (st != s) MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
     return MC_OK;
@@ -574,12 +629,12 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
     int r;
     const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
     TwinAlias ys_alias;
-    if (twin && mc_chain_enabled(8) && !c->no_alias) { ys_alias.split_flag = mc_route_split_flag_ptr(c->rb); ys_alias.from = c->rows / 2; }
+    if (twin && chain_on(c, 8) && !c->no_alias) { ys_alias.split_flag = mc_route_split_flag_ptr(c->rb); ys_alias.from = c->rows / 2; }
     if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias, &w.h_ca_out))) return r;
     // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
     const long o = row0 * D;
     int z2_parts = 1;
-    if (mc_chain_enabled(0) && mc_mlp_supported(L, F)) {
+    if (chain_on(c, 0) && mc_mlp_supported(L, F)) {
         MlpArgs m;
         m.X = hs + o; m.ldx = D; m.x_gstride = L;
         m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
@@ -590,7 +645,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         int S = c->split_sffn;                     // env MC_SPLIT_SFFN at context creation (0: the model below)
         if (S <= 0) {
             S = 1;
-            if (nrows <= split_rows(1) && nrows == c->rows) {      // (one launch over the whole batch: the partial planes live in the one hbuf -- not in the two-stream schedule)
+            if (nrows <= split_rows(c, 1) && nrows == c->rows) {      // (one launch over the whole batch: the partial planes live in the one hbuf -- not in the two-stream schedule)
                 auto load = [&](int ways) {
                     const long n = cdiv((long)cdiv(nrows, 128) * H * ways, 256);
                     return (1.45 * (double)(n / 2) + (double)(n % 2)) * ((double)cdiv(F / 32, ways) + 2.0);
@@ -603,14 +658,15 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         if (use_half(c) && w.h_w1.hi && w.h_w2.hi) {
             if ((r = mc_launch_mlp_h(MLP_PARTS, m, w.h_w1.hi, w.h_w1.lo, w.h_w2.hi, w.h_w2.lo, c->prec == MC_PREC_F16X3, H, 0, s))) return r;
         } else
-        if (nrows <= split_rows(1) && nrows == c->rows && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
+        if (nrows <= split_rows(c, 1) && nrows == c->rows && S > 1 && F / 32 >= S && c->hbuf_floats >= (size_t)S * nrows * D) {     // small batches: see moe_experts
             m.Y = c->hbuf; m.nsplit = S; m.y_sstride = nrows * D;
             if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
-            if (mc_chain_enabled(12)) z2_parts = S;          // the FiLM row kernel adds the partial planes up itself
+            if (chain_on(c, 12)) z2_parts = S;          // the FiLM row kernel adds the partial planes up itself
             else if ((r = mc_launch_splitk_reduce(c->hbuf, S, nrows, D, nullptr, nullptr, c->z2 + o, s))) return r;
         } else if ((r = mc_launch_mlp(MLP_PARTS, m, H, 0, s))) return r;
     } else {
         GemmArgs f1;
+        gemm_opts(c, f1);
         f1.A = hs + o; f1.lda = D; f1.a_gstride = L;
         f1.W = w.ffn_w1; f1.ldw = L; f1.w_gstride = (long)F * L;
         f1.bias = w.ffn_b1; f1.b_gstride = F; f1.act = ACT_GELU;
@@ -618,6 +674,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
         f1.M = (int)nrows; f1.N = F; f1.K = L;
         if ((r = mc_launch_gemm(GM_PLAIN, f1, H, 0, s))) return r;
         GemmArgs f2;
+        gemm_opts(c, f2);
         f2.A = c->fh + row0 * H * F; f2.lda = (long)H * F; f2.a_gstride = F;
         f2.W = w.ffn_w2; f2.ldw = F; f2.w_gstride = (long)L * F;
         f2.bias = w.ffn_b2; f2.b_gstride = L;
@@ -657,11 +714,11 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     const LayerW& w = c->lw[i];
     int r;
     // ---- STMA: gate + routing + experts (the only part that couples tokens across the batch) ----
-    const bool fused_gate = mc_chain_enabled(1) && mc_mlp_supported(L, 32);
+    const bool fused_gate = chain_on(c, 1) && mc_mlp_supported(L, 32);
     // The two CFG halves enter base layer 0 with the same residual stream (the pose encoder output is written to
     // both, stmogen.py:736-740), so gate scores and expert outputs of token i + N/2 equal those of token i:
     // gate and experts run on the first half only, routing still ranks all N tokens ("twin" mode, mc_route.hip).
-    const bool twin = twin_ok && fused_gate && mc_chain_enabled(2) && mc_chain_enabled(4) && (c->N % 2 == 0) &&
+    const bool twin = twin_ok && fused_gate && chain_on(c, 2) && chain_on(c, 4) && (c->N % 2 == 0) &&
                       c->rb.tie_xor == 0xFFFFFFFFu;   // (the dedupe relies on a twin ranking right behind its original: stable tie order)
     if (fused_gate) {
         GateArgs ga;
@@ -689,7 +746,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         if ((r = mc_launch_ln_rows(hs, L, 0, w.norm_g, w.norm_b, w.mm.emb, c->T * H, c->z, L, c->N, L, s))) return r;
     }
     // two slot groups when the two sample groups run on two streams: each group's expert MLP joins its own chain
-    const bool grouped = split == 2 && c->nparts == 2 && mc_chain_enabled(6);
+    const bool grouped = split == 2 && c->nparts == 2 && chain_on(c, 6);
     const long gsplit = grouped ? part_row0(c, 1) * H : c->N;
     if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, gsplit, s, &w.h_fc1, &w.h_fc2))) return r;   // routing (+ experts if one group)
     if (c->cap_idx) {
@@ -720,7 +777,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         for (int k = 0; k < c->nparts; ++k) {
             hipStream_t sk = part_stream(c, k, s);
             if ((r = layer_rows(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), sk, sk))) return r;
-            if (k == 0 && twin && mc_chain_enabled(8) && !c->no_alias) {
+            if (k == 0 && twin && chain_on(c, 8) && !c->no_alias) {
                 // twin aliasing: the other groups read group 0's mf / ys instead of producing their own
                 MC_HIP(hipEventRecord(c->ev_join, s));
                 for (int j = 1; j < c->nparts; ++j) MC_HIP(hipStreamWaitEvent(c->parts[j - 1], c->ev_join, 0));
@@ -732,7 +789,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         return MC_OK;
     }
     // Small batches: the temporal branch runs on the side stream beside LN + qkv + body (measured +2.4 % at B=8).
-    const bool side_temporal = c->side && (mc_chain_enabled(3) || c->N <= 65536);
+    const bool side_temporal = c->side && (chain_on(c, 3) || c->N <= c->opt.big_tokens);
     if ((r = layer_rows(c, i, hs, step, twin, 0, 2 * half, s, side_temporal ? c->side : s))) return r;
     return layer_rows_tail(c, i, hs, step, twin, 0, 2 * half, s);
 }
@@ -864,7 +921,8 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     WS(c->z, zsz);
     WS(c->proj, Nmax * 256);
     WS(c->hbuf, hsz);
-    if (mc_chain_enabled(0) && mc_mlp_supported(L, 4 * L)) c->hbuf_floats = hsz;   // (the text MoE only touches hbuf in set_condition)
+    c->hbuf_cap = hsz;
+    if (chain_on(c, 0) && mc_mlp_supported(L, 4 * L)) c->hbuf_floats = hsz;   // (the text MoE only touches hbuf in set_condition)
     WS(c->y2, 2 * zsz);
     WS(c->mf, (c->N + 128) * 4 * L);        // + 128 padding rows: projqkv_k stores unconditionally (invalid lanes land there)
     WS(c->qkv, (c->N + 128) * 3 * L);
@@ -1013,6 +1071,59 @@ int mc_ctx_set_precision(mc_ctx* c, int32_t precision) {
     return MC_OK;
 }
 
+// Per-context kernel-selection switches (the MC_* environment variables only seed the defaults of contexts created later).
+int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value) {
+    MC_REQUIRE(c && key, "null argument");
+    MC_REQUIRE(!c->graph_exec, "mc_ctx_set_option: a captured graph holds the old kernel selection (mc_ctx_graph_release first)");
+    const std::string k(key);
+    McOptions& o = c->opt;
+    if (k == "chain") {
+        o.chain = (int)value;
+        c->hbuf_floats = (chain_on(c, 0) && mc_mlp_supported(c->m->cfg.latent_dim, 4 * c->m->cfg.latent_dim)) ? c->hbuf_cap : 0;
+    } else if (k == "big_tokens") o.big_tokens = value;
+    else if (k == "small_gemm_rows") o.small_gemm_rows = value;
+    else if (k == "split_rows_expert") o.split_rows_expert = value;
+    else if (k == "split_rows_sffn") o.split_rows_sffn = value;
+    else if (k == "temporal_split") o.temporal_split = value;
+    else if (k == "rowchain_split") o.rowchain_split = value;
+    else if (k == "gemm_tune") o.gemm_tune = (int)value;
+    else if (k == "small_tile_n") o.small_tile_n = (int)value;
+    else if (k == "gemm_wp_grid") o.gemm_wp_grid = (int)value;
+    else if (k == "half_min_rows") c->half_min_rows = value;
+    else if (k == "gate_small") c->gate_small_tokens = value;
+    else if (k == "split_expert") c->split_expert = (int)value;
+    else if (k == "split_sffn") c->split_sffn = (int)value;
+    else if (k == "route_reg") c->rb.reg_kernel = value != 0;
+    else if (k == "route_small") { MC_REQUIRE(value <= 131072, "route_small: the one-workgroup kernels hold at most 131072 pairs"); c->rb.small_pairs = value; }
+    else if (k == "route_coop") {
+        // off: give the reservation back; on: only if the grid can be reserved now
+        if (!value) {
+            if (c->coop_reserved) { mc_route_coop_release(c->device, c->coop_reserved); c->coop_reserved = 0; }
+            c->rb.coop = false;
+        } else if (!c->rb.coop) {
+            int nwg = 0;
+            for (long n : {c->N, c->Ntxt})
+                if (mc_route_coop_wgs(n) > nwg) nwg = mc_route_coop_wgs(n);
+            MC_REQUIRE(nwg > 0 && mc_route_coop_reserve(c->device, nwg), "route_coop: the cooperative routing grid cannot be reserved on this device");
+            c->coop_reserved = nwg;
+            c->rb.coop = true;
+        }
+    } else if (k == "split_groups") {
+        MC_REQUIRE(value >= 2 && value <= 4 && value <= 2 * c->B, "split_groups: 2..4 groups of whole samples (batch %d)", c->B);
+        for (int j = 1; j < (int)value - 1; ++j) {
+            if (!c->parts[j]) MC_HIP(hipStreamCreateWithFlags(&c->parts[j], hipStreamNonBlocking));
+        }
+        for (int j = 0; j < (int)value - 1; ++j) {
+            if (!c->ev_parts[j]) MC_HIP(hipEventCreateWithFlags(&c->ev_parts[j], hipEventDisableTiming));
+        }
+        c->nparts = (int)value;
+    } else {
+        mc_set_error("mc_ctx_set_option: unknown key '%s'", key);
+        return MC_ERR_ARG;
+    }
+    return MC_OK;
+}
+
 int mc_ctx_enable_capture(mc_ctx* c) {
     MC_REQUIRE(c, "null context");
     if (c->cap_idx) return MC_OK;
@@ -1034,15 +1145,15 @@ int mc_ctx_set_timesteps(mc_ctx* c, const int32_t* t_orig_host, int32_t S, void*
     MC_HIP(hipStreamSynchronize(s));  // t_orig_host may be a temporary of the caller
     int r;
     if ((r = mc_launch_timestep_embedding(c->t_orig, c->te, S, D, s))) return r;
-    if ((r = dense(c->te, D, c->time_w0, D, c->time_b0, nullptr, 0, c->e1, Te, S, Te, D, ACT_SILU, s))) return r;
-    if ((r = dense(c->e1, Te, c->time_w2, Te, c->time_b2, nullptr, 0, c->emb, Te, S, Te, Te, ACT_NONE, s))) return r;
+    if ((r = dense(c, c->te, D, c->time_w0, D, c->time_b0, nullptr, 0, c->e1, Te, S, Te, D, ACT_SILU, s))) return r;
+    if ((r = dense(c, c->e1, Te, c->time_w2, Te, c->time_b2, nullptr, 0, c->emb, Te, S, Te, Te, ACT_NONE, s))) return r;
     if ((r = mc_launch_silu(c->emb, c->semb, (long)S * Te, s))) return r;
     for (int i = 0; i < c->NLA; ++i) {
         const LayerW& w = c->lw[i];
         float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS) * 2 * D;
         float* ss1 = c->ss + ((long)(i * 2 + 1) * c->maxS) * 2 * D;
-        if ((r = dense(c->semb, Te, w.ca_film_w, Te, w.ca_film_b, nullptr, 0, ss0, 2 * D, S, 2 * D, Te, ACT_NONE, s))) return r;
-        if ((r = dense(c->semb, Te, w.ffn_film_w, Te, w.ffn_film_b, nullptr, 0, ss1, 2 * D, S, 2 * D, Te, ACT_NONE, s))) return r;
+        if ((r = dense(c, c->semb, Te, w.ca_film_w, Te, w.ca_film_b, nullptr, 0, ss0, 2 * D, S, 2 * D, Te, ACT_NONE, s))) return r;
+        if ((r = dense(c, c->semb, Te, w.ffn_film_w, Te, w.ffn_film_b, nullptr, 0, ss1, 2 * D, S, 2 * D, Te, ACT_NONE, s))) return r;
     }
     c->S = S;
     return MC_OK;
@@ -1084,7 +1195,8 @@ int mc_ctx_set_control(mc_ctx* c, const float* c_feat_dev, int32_t Tc, void* str
     int r;
     MC_HIP(hipMemsetAsync(c->cenc, 0, sizeof(float) * BT * D, s));           // zero padding for t >= Tc
     {
-        GemmArgs e;   // per sample: [Tc, Fc] x [D, Fc]^T + bias + sequence_embedding[:Tc]
+        GemmArgs e;
+        gemm_opts(c, e);   // per sample: [Tc, Fc] x [D, Fc]^T + bias + sequence_embedding[:Tc]
         e.A = c_feat_dev; e.lda = Fc; e.a_gstride = (long)Tc * Fc;
         e.W = c->ctrl_in_w; e.ldw = (Fc + 3) / 4 * 4; e.bias = c->ctrl_in_b;
         e.add = c->seq_emb; e.add_mod = Tc; e.ld_add = D;
@@ -1094,7 +1206,7 @@ int mc_ctx_set_control(mc_ctx* c, const float* c_feat_dev, int32_t Tc, void* str
     }
     const LayerW& w0 = c->lw[g.num_layers];
     // text-conditioned half: before_proj(c); unconditional half: before_proj(c * 0) = bias when condition_cfg
-    if ((r = dense(c->cenc, D, w0.before_w, D, w0.before_b, nullptr, 0, c->cb, D, BT, D, D, ACT_NONE, s))) return r;
+    if ((r = dense(c, c->cenc, D, w0.before_w, D, w0.before_b, nullptr, 0, c->cb, D, BT, D, D, ACT_NONE, s))) return r;
     if (g.ctrl_condition_cfg) {
         if ((r = mc_launch_add_rows(c->cb + BT * D, nullptr, nullptr, w0.before_b, BT, D, s))) return r;
     } else {
@@ -1129,12 +1241,13 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
         if (seed) { if ((r = mc_launch_pad_rows_seeded(const_cast<float*>(x_t), c->xpad, BT, C, c->m->Cp, *seed, s))) return r; }
         else if ((r = mc_launch_pad_rows(x_t, c->xpad, BT, C, c->m->Cp, s))) return r;
         GemmArgs e;
+        gemm_opts(c, e);
         e.A = c->xpad; e.lda = c->m->Cp;
         e.W = c->enc_w; e.ldw = c->m->Cp; e.bias = c->enc_b;
         e.add = c->seq_emb; e.add_mod = c->T; e.ld_add = D;
         e.C = c->h; e.ldc = D; e.dup_rows = BT;
         e.M = (int)BT; e.N = D; e.K = c->m->Cp;
-        if (BT <= small_gemm_rows() && D % 64 == 0 && c->m->Cp % 32 == 0) { if ((r = mc_launch_gemm_small(e, s))) return r; }
+        if (BT <= small_gemm_rows(c) && D % 64 == 0 && c->m->Cp % 32 == 0) { if ((r = mc_launch_gemm_small(e, s))) return r; }
         else if ((r = mc_launch_gemm(GM_ENC, e, 1, 0, s))) return r;
     }
     const int nl = stop_after >= 0 ? (stop_after < g.num_layers ? stop_after : g.num_layers) : g.num_layers;
@@ -1142,8 +1255,8 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
     const int NC = c->have_ctrl ? g.num_ctrl_layers : 0;
     // large batches: the CFG halves run on two streams (see run_layer); with a control branch the extra whole-batch
     // ops between layers need both halves, so the halves re-join after every layer
-    const bool fused = mc_chain_enabled(1) && mc_chain_enabled(2) && mc_mlp_supported(L, 32);
-    const int split = (c->side && mc_chain_enabled(5) && c->N > 65536 && fused) ? ((NC > 0 && !mc_chain_enabled(9)) ? 1 : 2) : 0;
+    const bool fused = chain_on(c, 1) && chain_on(c, 2) && mc_mlp_supported(L, 32);
+    const int split = (c->side && chain_on(c, 5) && c->N > c->opt.big_tokens && fused) ? ((NC > 0 && !chain_on(c, 9)) ? 1 : 2) : 0;
     // row-wise op between layers, on the stream of the sample group that owns the rows (one launch when not split)
     auto by_group = [&](auto&& fn) -> int {
         if (split != 2) return fn(0L, c->rows, s);
@@ -1168,7 +1281,7 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
             if ((r = by_group([&](long r0, long n, hipStream_t sk) {                                   // h += after_proj(c)
                      if (use_half(c) && cw.h_after.hi)
                          return dense_h(c, c->hc + r0 * D, cw.h_after, cw.after_b, c->h + r0 * D, c->h + r0 * D, n, D, D, sk);
-                     return dense(c->hc + r0 * D, D, cw.after_w, D, cw.after_b, c->h + r0 * D, D, c->h + r0 * D, D, n, D, D, ACT_NONE, sk); })))
+                     return dense(c, c->hc + r0 * D, D, cw.after_w, D, cw.after_b, c->h + r0 * D, D, c->h + r0 * D, D, n, D, D, ACT_NONE, sk); })))
                 return r;
         }
         if ((r = run_layer(c, i, c->h, step, i == 0, split, s))) return r;
@@ -1177,7 +1290,7 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
     if (stop_after >= 0) return MC_OK;
     // PoseDecoder as one dense [D -> C] GEMM (stmogen.py:505-544), /2 folded into the packed weight
     float* o = out2_dev ? out2_dev : c->out2;
-    return dense(c->h, D, c->dec_w, D, c->dec_b, nullptr, 0, o, C, c->rows, C, D, ACT_NONE, s);
+    return dense(c, c->h, D, c->dec_w, D, c->dec_b, nullptr, 0, o, C, c->rows, C, D, ACT_NONE, s);
 }
 
 static SamplerCoefs to_coefs(const mc_step_coefs* k) {
@@ -1197,7 +1310,7 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
     const mc_model_config& g = c->m->cfg;
     // ... and so is the Linear of the very last StylizationBlock (h += a W^T + b): it, too, runs once on the combined
     // rows  h_c = comb(h) + comb(a) W^T + b  instead of on both halves.
-    const bool defer = mc_chain_enabled(7);
+    const bool defer = chain_on(c, 7);
     c->defer_last_gemm = defer;
     int r = denoise_impl(c, x_t, step, nullptr, g.num_layers, stream, seed);   // all layers (minus that GEMM), no decoder
     c->defer_last_gemm = false;
@@ -1211,18 +1324,19 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
         if (c->graph_mode) return mc_launch_cfg_combine_tab(x, y, c->gcoefs, c->gstep, out, BT * D, s);
         return mc_launch_axpby(x, y, k->text_coef, k->none_coef, out, BT * D, s);
     };
-    if (defer && c->dec_cat_w && mc_chain_enabled(11)) {
+    if (defer && c->dec_cat_w && chain_on(c, 11)) {
         // h_c and a_c in one launch
         if ((r = mc_launch_axpby_pair(c->h, c->h + BT * D, c->z2, c->a, c->a + BT * D, c->z2 + BT * D, k->text_coef, k->none_coef,
                                       c->graph_mode ? c->gcoefs : nullptr, c->graph_mode ? c->gstep : nullptr, BT * D, s))) return r;
     } else if ((r = combine(c->h, c->h + BT * D, c->z2))) return r;     // h_c
     if (defer) {
-        if (c->dec_cat_w && mc_chain_enabled(11)) {
+        if (c->dec_cat_w && chain_on(c, 11)) {
             // ... and that Linear composed with the decoder is one [C, D] matrix (folded at pack time):
             //   x0 = [dec(h_c) + Wd b] + [a_c (Wd W)^T]
             // the two skinny products (N = C = 322: 294 tiles each, half a chip) are the two groups of ONE grouped GEMM
             // over (h_c | a_c) x (Wd | Wd W); the sampler kernel adds the two partial outputs
             GemmArgs t;
+            gemm_opts(c, t);
             t.A = c->z2; t.lda = D; t.a_gstride = BT * D; t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D;
             t.bias = c->dec_cat_b; t.b_gstride = C; t.C = c->out2; t.ldc = C; t.c_gstride = BT * C;
             t.M = (int)BT; t.N = C; t.K = D;
@@ -1234,14 +1348,14 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
         }
         if ((r = combine(c->a, c->a + BT * D, c->a))) return r;      // a_c
         if (c->dec_wf) {
-            if ((r = dense(c->z2, D, c->dec_w, D, c->dec_bf, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
-            if ((r = dense(c->a, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+            if ((r = dense(c, c->z2, D, c->dec_w, D, c->dec_bf, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+            if ((r = dense(c, c->a, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
             *x0a = c->out2;
             return MC_OK;
         }
-        if ((r = dense(c->a, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
+        if ((r = dense(c, c->a, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
     }
-    if ((r = dense(c->z2, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+    if ((r = dense(c, c->z2, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
     *x0a = c->out2;
     return MC_OK;
 }
@@ -1453,7 +1567,7 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
 int mc_op_gemm(const float* a, const float* w, const float* bias, const float* res, float* cdev, int32_t M, int32_t N,
                int32_t K, int32_t ldw, int32_t act, void* stream) {
     MC_REQUIRE(a && w && cdev && M > 0 && N > 0 && K > 0 && K % 4 == 0 && ldw % 4 == 0 && ldw >= K, "bad gemm args");
-    return dense(a, K, w, ldw, bias, res, N, cdev, N, M, N, K, act, (hipStream_t)stream);
+    return dense(nullptr, a, K, w, ldw, bias, res, N, cdev, N, M, N, K, act, (hipStream_t)stream);
 }
 
 int mc_op_gemm_f16(const float* a, const float* w, const float* bias, const float* res, float* cdev, int32_t M, int32_t N,

@@ -127,6 +127,12 @@ class NativeContext:
         _lib.check(self.lib.mc_ctx_set_precision(self.handle, code), 'mc_ctx_set_precision')
         self.precision = precision
 
+    def set_option(self, key, value):
+        """Kernel-selection switch of THIS context (include/motioncraft_amd.h, mc_ctx_set_option): 'chain', 'big_tokens',
+        'split_groups', 'gemm_tune', 'route_coop', ... -- the MC_* environment variables only seed the defaults."""
+        self._drop_graph()
+        _lib.check(self.lib.mc_ctx_set_option(self.handle, str(key).encode(), int(value)), 'mc_ctx_set_option')
+
     def set_tie_policy(self, policy):
         """'stable' (default) or 'reverse': order of equal-importance tokens at a capacity cut (tutel boundary, a16).
         Call before set_condition."""

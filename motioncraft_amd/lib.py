@@ -79,6 +79,7 @@ _SIGNATURES = {
                                            ctypes.POINTER(ctypes.c_double)]),
     'mc_ctx_enable_capture': (ctypes.c_int, [_P]),
     'mc_ctx_set_tie_policy': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'mc_ctx_set_option': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int64]),
     'mc_ctx_set_precision': (ctypes.c_int, [_P, ctypes.c_int32]),
     'mc_op_gemm_f16': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P]),
     'mc_ctx_set_timesteps': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, _P]),

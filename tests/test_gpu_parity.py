@@ -601,130 +601,81 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-def test_stream_k_gemm_vs_fp64_and_the_tile_kernels():
-    """gemm_sk_k (256 x 256 stream-K tiles; the default for plain GEMMs with K >= 2048 and >= 128 tiles, forced here by
-    MC_GEMM_TUNE bit 7 in a child process -- the variant is chosen at library load) through mc_op_gemm: vs a float64 product on
-    sampled rows, deterministic run to run, activation + bias + residual epilogue, shapes whose tiles are cut by the range
-    borders once / twice / never (25088 x 1536: 2.3 tiles per worker; 1280 x 768: 15 tiles on 256 workers = every tile in ~17
-    parts; 4096^2 x 2048: exactly 1 tile each), K = 16 (one k-tile) and the default selection rule."""
-    import subprocess
-    import sys
-    code = r"""
-import ctypes, sys, torch
-from motioncraft_amd import lib as L_
-lib = L_.load(require_gpu=True)
-P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-g = torch.Generator(device='cuda').manual_seed(3)
-for (M, N, K, act, res) in [(25088, 1536, 1536, 0, True), (1280, 768, 528, 1, True), (4096, 4096, 2048, 0, False), (256, 256, 16, 2, True),
-                            (12544, 1536, 1536, 0, True), (384, 512, 4096, 0, False)]:
-    a = torch.randn(M, K, device='cuda', generator=g); w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
-    b = torch.randn(N, device='cuda', generator=g); r = torch.randn(M, N, device='cuda', generator=g)
-    outs = []
-    for rep in range(2):
-        c = torch.full((M, N), float('nan'), device='cuda')
-        L_.check(lib.mc_op_gemm(P(a), P(w), P(b), P(r if res else None), P(c), M, N, K, K, act, st))
-        torch.cuda.synchronize()
-        outs.append(c)
-    assert torch.equal(outs[0], outs[1]), 'not deterministic'
-    rows = torch.cat([torch.arange(0, min(M, 300)), torch.arange(max(0, M - 300), M)]).cuda()
-    ref = a[rows].double() @ w.double().t() + b.double()
-    ref = torch.nn.functional.gelu(ref) if act == 1 else torch.nn.functional.silu(ref) if act == 2 else ref
-    if res: ref = ref + r[rows].double()
-    err = float((outs[0][rows].double() - ref).abs().max()) / float(ref.abs().max())
-    print(f'{M}x{N}x{K} act={act} res={res}: max rel err {err:.2e}')
-    assert err <= 4e-6, err
-print('stream-k ok')
-"""
-    for tune in ('177', '49'):           # 177 = 49 | 128: stream-K for every eligible plain GEMM; 49: the default rule picks it for the K >= 2048 shapes
-        env = dict(os.environ, MC_GEMM_TUNE=tune, PYTHONPATH=os.path.dirname(HERE))
-        r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and 'stream-k ok' in r.stdout, r.stdout + r.stderr
-        print(r.stdout)
-
-
-@pytest.mark.parametrize('chain', ['32752', '32759'])
+@pytest.mark.parametrize('chain', [65520, 65527])
 def test_generic_fallback_path_vs_oracle(chain):
-    """MC_CHAIN with bits 0-2 cleared (32752): the generic path -- plain gemm_k launches + row kernels instead of the fused
+    """chain mask with bits 0-2 cleared (65520): the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
     is outside the fused kernels' range, so it keeps its own parity test: small-config denoiser call + 3 DDPM steps vs the CPU
-    oracle in a child process (the mask is read once per process), beside the default mask (32759) on the same inputs."""
-    import subprocess
-    import sys
-    code = r"""
-import sys, torch
-sys.path.insert(0, 'tests')
-from helpers import SMALL, SMALL_SEED, synth_inputs
-from oracle import stmogen_oracle as O, weights as W
-from motioncraft_amd.engine import NativeModel
-from motioncraft_amd.diffusion import build_diffusion
-dims, B, T = SMALL, 3, 24
-sd = W.make_state_dict(dims, SMALL_SEED)
-x_T, xf, mask = synth_inputs(dims, B, T, seed=31, lengths=[24, 19, 11])
-nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
-ctx = nm.context(B, T, max_steps=1000)
-d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
-ctx.set_timesteps(d.timestep_map)
-ctx.set_condition(xf.cuda(), mask.cuda())
-out2 = ctx.denoise(x_T.cuda(), 640)
-w = (1 - (1000 - 640) / 1000) * dims['scale'] + 1
-ref = O.denoise(sd, dims, x_T, 640, xf, mask)
-e1 = float((out2[:B].cpu() * w + out2[B:].cpu() * (1 - w) - ref).abs().max())
-g = torch.Generator().manual_seed(1)
-noises = {i: torch.randn(B, T, dims['input_feats'], generator=g) for i in (999, 998, 997)}
-x = x_T.cuda()
-for i in (999, 998, 997):
-    x = ctx.sample_step(x, i, d.step_coefs(i, 'ddpm', dims['scale']), noises[i].cuda())
-ref = O.sample_loop(sd, dims, O.Schedule(1000, None), 'ddpm', x_T, xf, mask, step_noise=lambda i: noises[i], num_steps=3)
-e2 = float((x.cpu() - ref).abs().max())
-print(f'errs {e1:.3e} {e2:.3e}')
-assert e1 <= 2e-4 and e2 <= 1e-3
-print('fallback path ok')
-"""
-    env = dict(os.environ, MC_CHAIN=chain, PYTHONPATH=os.path.dirname(HERE))
-    r = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and 'fallback path ok' in r.stdout, r.stdout + r.stderr
-    print(chain, r.stdout.strip().splitlines()[-2])
+    oracle, beside the default mask (65527) on the same inputs.  The mask is a per-context option (mc_ctx_set_option): both
+    contexts live in this one process."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    dims, B, T = SMALL, 3, 24
+    sd = W.make_state_dict(dims, SMALL_SEED)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=31, lengths=[24, 19, 11])
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    ctx = nm.context(B, T, max_steps=1000)
+    ctx.set_option('chain', chain)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    out2 = ctx.denoise(x_T.cuda(), 640)
+    w = (1 - (1000 - 640) / 1000) * dims['scale'] + 1
+    ref = O.denoise(sd, dims, x_T, 640, xf, mask)
+    e1 = maxabs(out2[:B] * w + out2[B:] * (1 - w), ref)
+    g = torch.Generator().manual_seed(1)
+    noises = {i: torch.randn(B, T, dims['input_feats'], generator=g) for i in (999, 998, 997)}
+    x = x_T.cuda()
+    for i in (999, 998, 997):
+        x = ctx.sample_step(x, i, d.step_coefs(i, 'ddpm', dims['scale']), noises[i].cuda())
+    ref = O.sample_loop(sd, dims, O.Schedule(1000, None), 'ddpm', x_T, xf, mask, step_noise=lambda i: noises[i], num_steps=3)
+    e2 = maxabs(x, ref)
+    print(f'chain {chain}: errs {e1:.3e} {e2:.3e}')
+    assert e1 <= TOL_STEP and e2 <= TOL_FINAL
+    with pytest.raises(RuntimeError):
+        ctx.set_option('no_such_switch', 1)
+    ctx.close()
+    nm.close()
 
 
-def test_stream_k_gemm_on_two_streams_concurrently():
-    """gemm_sk_k keeps its slabs + ticket words per (device, stream): two streams running the long-k GEMM at the same time
-    (each launch = 256 persistent workgroups of 128 KB LDS, so the second launch's workers only get CUs as the first one's
-    leave -- the ticket-ordered slab hand-off must not care) give the results of the same launches run alone, three rounds."""
-    from motioncraft_amd import lib as L_
-    lib = L_.load(require_gpu=True)
-    P = lambda t: ctypes.c_void_p(t.data_ptr())
-    g = torch.Generator(device='cuda').manual_seed(11)
-    M, N, K = 4096 + 128, 2048, 2048          # 17 x 8 = 136 tiles of 256 x 256 (the last row tile ragged), 128 k-tiles: split by stream-K
-    ops = []
-    for j in range(2):
-        a = torch.randn(M, K, device='cuda', generator=g)
-        w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
-        b = torch.randn(N, device='cuda', generator=g)
-        r = torch.randn(M, N, device='cuda', generator=g)
-        ops.append((a, w, b, r, torch.empty(M, N, device='cuda'), torch.cuda.Stream()))
-
-    def launch(op):
-        a, w, b, r, c, st = op
-        with torch.cuda.stream(st):
-            L_.check(lib.mc_op_gemm(P(a), P(w), P(b), P(r), P(c), M, N, K, K, 0, ctypes.c_void_p(st.cuda_stream)))
-    alone = []
-    for op in ops:
-        launch(op)
+def test_fused_proj_qkv_body_kernel_is_bit_identical_to_the_separate_kernels():
+    """pqbody_k (round 4: combine + proj + body LayerNorm + q/k/v + static / dynamic body topology over frame-aligned tiles of 10
+    frames, q/k/v exchanged through LDS, never in HBM) against projqkv_k + body_reg_k on the same context inputs: the mf rows it
+    stores and the ys it writes must be the SAME BITS (same MFMA k order, same softmax / contraction arithmetic), the denoiser output
+    too.  0.125b widths (L = 128, 12 parts) at a small batch pushed into the large-batch schedule by big_tokens = 0: sample groups
+    of 72 frames = 7 full tiles + one of 2 frames (ragged), CFG twin aliasing in layer 0 on and (stop_after_layers) off, masked
+    tails, and one whole-batch launch (split off: a tile that straddles nothing but ends ragged)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = FULL
+    sd = W.make_state_dict(dims, 0)
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    B, T = 3, 24
+    x, xf, mask = synth_inputs(dims, B, T, seed=5, lengths=[24, 20, 13])
+    got = {}
+    for tag, chain in (('fused', 65527), ('separate', 65527 & ~(1 << 15)), ('fused_one_stream', 65527 & ~(1 << 5)),
+                       ('separate_one_stream', 65527 & ~((1 << 15) | (1 << 5)))):
+        ctx = nm.context(B, T, max_steps=2)
+        ctx.set_option('big_tokens', 0)
+        ctx.set_option('chain', chain)
+        ctx.set_timesteps([800, 30])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out = ctx.denoise(x.cuda(), 1).clone()
+        ctx.denoise(x.cuda(), 0, stop_after_layers=1)            # layer 0 without twin aliasing: every row produced
         torch.cuda.synchronize()
-        alone.append(op[4].clone())
-        ref = op[0][:256].double() @ op[1].double().t() + op[2].double() + op[3][:256].double()
-        assert float((alone[-1][:256].double() - ref).abs().max()) / float(ref.abs().max()) <= 4e-6
-    for rnd in range(3):
-        for op in ops:
-            op[4].fill_(float('nan'))
+        ys0, mf0 = ctx.buffer('ys').clone(), ctx.buffer('mf').clone()
+        ctx.denoise(x.cuda(), 0, stop_after_layers=2)
         torch.cuda.synchronize()
-        for rep in range(3):
-            for op in ops:
-                launch(op)
-        torch.cuda.synchronize()
-        for j, op in enumerate(ops):
-            assert torch.equal(op[4], alone[j]), (rnd, j)
+        got[tag] = (out, ys0, mf0, ctx.buffer('ys').clone(), ctx.buffer('mf').clone(), ctx.buffer('h').clone())
+        ctx.close()
+    names = ('x0', 'ys layer 0', 'mf layer 0', 'ys layer 1', 'mf layer 1', 'h after 2 layers')
+    for a, b, ks in (('fused', 'separate', range(6)), ('fused_one_stream', 'separate_one_stream', range(6)),
+                     ('fused', 'fused_one_stream', (1, 2))):       # (later stages: the FiLM GEMM's tile width follows the launch's row count)
+        for k in ks:
+            assert bool(torch.isfinite(got[a][k]).all()), (a, names[k])
+            assert torch.equal(got[a][k], got[b][k]), (a, b, names[k], float((got[a][k] - got[b][k]).abs().max()))
+    nm.close()
 
 
 def test_fp16_mfma_gemm_op_vs_fp64():
