@@ -65,8 +65,9 @@ struct McOptions {
     // 10 proj + body LN + q/k/v in one kernel (large batches), 11 folded decoder tail as one grouped GEMM + sum in the sampler kernel,
     // 12 small batches: the SFFN's split-hidden partial sums are added up by the FiLM row kernel, 13 B=1 sizes: the expert MLP picks
     // 3 or 4 hidden slices on the device, 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream,
-    // 15 (round 4) pqbody_k: bit 10's kernel also runs the body-topology attention (q/k/v never in HBM; L = 128, 12 parts, fp32)
-    int chain = 65527;                 // (all but bit 3)
+    // 15 (round 4) pqbody_k: bit 10's kernel also runs the body-topology attention (q/k/v never in HBM; L = 128, 12 parts, fp32),
+    // 16 (round 4) the twin layer's gate / experts / front kernels run as two sample sub-groups on the two streams
+    int chain = 65527 | (1 << 16);     // (all but bit 3)
     long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
@@ -538,7 +539,9 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
 // Everything of a DecoderLayer AFTER the expert MLP, restricted to residual-stream rows [row0, row0 + nrows)
 // (whole samples): MoE combine + proj, body LN + q/k/v, body and temporal attention, proj_out FiLM block, SFFN, its
 // FiLM block.  Every kernel here is row-independent, so disjoint row ranges can run on different streams.
-int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st) {
+// `phase`: 0 = everything; 1 = the front only (combine + proj, LN + q/k/v, body topology); 2 = the temporal attention only
+// (the twin layer of the large-batch schedule runs the front per sample sub-group and the rest per CFG half: run_layer)
+int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st, int phase = 0) {
     // twin layer: rows of the second CFG half whose routing equals their twin's are aliased, not recomputed
     TwinAlias tok_alias, frame_alias;
     const int* twin_flag = nullptr;
@@ -560,7 +563,9 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     // ... and the body-topology attention too (pqbody_k: frame-aligned tiles, q/k/v never leave the chip): fp32 path, L = 128, 12 parts
     const bool body_fused = pq_fused && chain_on(c, 15) && L == 128 && H == 12 && g.dyn_heads == 8 &&
                             !(use_half(c) && w.h_proj.hi && w.h_qkv.hi);
-    if (chain_on(c, 2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
+    if (phase == 2) {
+        // (front done elsewhere)
+    } else if (chain_on(c, 2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
         RowChainArgs p;
         p.split_tokens = c->opt.rowchain_split;
         p.X = c->y2; p.comb_w = c->rb.comb_w; p.W = w.mm.proj_w; p.bias = w.mm.proj_b;
@@ -598,7 +603,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         if (chain_on(c, 14) && c->rows <= 1200) sb = st; else stt = st;      // (B <= 3 at 196 frames: -1.5 .. -3 %; B = 4: +1 %)
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
-    if (pq_fused) {
+    if (pq_fused || phase == 2) {
         // q/k/v were produced by projqkv_k above
     } else if (chain_on(c, 2) && mc_mlp_supported(L, 32)) {
         RowChainArgs q;
@@ -611,10 +616,11 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         if ((r = mc_launch_ln_rows(c->mf + tok0 * 4 * L, 4 * L, 0, w.dyn_g, w.dyn_b, nullptr, 1, c->z + tok0 * L, L, ntok, L, sb))) return r;
         if ((r = dense(c, c->z + tok0 * L, L, w.qkv_w, L, w.qkv_b, nullptr, 0, c->qkv + tok0 * 3 * L, 3 * L, ntok, 3 * L, L, ACT_NONE, sb))) return r;
     }
-    if (!body_fused &&
+    if (!body_fused && phase != 2 &&
         (r = mc_launch_body(c->mf + tok0 * 4 * L, 4 * L, c->qkv + tok0 * 3 * L, w.wsm, c->ys + row0 * D, nrows, H, L, g.dyn_heads, sb,
                             frame_alias, row0))) return r;
     if (sb != s) MC_HIP(hipEventRecord(c->ev_join, sb));
+    if (phase == 1) return MC_OK;
     if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
                                 g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split))) return r;
     if (stt != s) MC_HIP(hipEventRecord(c->ev_join, stt));
@@ -720,19 +726,27 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     // gate and experts run on the first half only, routing still ranks all N tokens ("twin" mode, mc_route.hip).
     const bool twin = twin_ok && fused_gate && chain_on(c, 2) && chain_on(c, 4) && (c->N % 2 == 0) &&
                       c->rb.tie_xor == 0xFFFFFFFFu;   // (the dedupe relies on a twin ranking right behind its original: stable tie order)
+    // Twin layer of the large-batch schedule: gate, experts and the front kernels exist for the FIRST CFG half only (the second one
+    // aliases it), so the half is cut into two sample sub-groups that go down the two streams (otherwise one stream idles for the
+    // first ~1.75 ms of every step at B=64); the streams cross-join behind the front (the temporal kernel of either CFG half reads
+    // mf rows of the whole first half) and continue per CFG half as in every other layer.
+    const long sub_rows = ((long)c->B / 2) * c->T;          // rows of the first sub-group (whole samples)
+    const bool twin_split = twin && split == 2 && c->nparts == 2 && chain_on(c, 6) && chain_on(c, 8) && chain_on(c, 16) && !c->no_alias &&
+                            sub_rows > 0;
     if (fused_gate) {
         GateArgs ga;
         ga.X = hs; ga.ldx = L; ga.gamma = w.norm_g; ga.beta = w.norm_b; ga.emb = w.mm.emb; ga.emb_mod = c->T * H;
         ga.Z = c->z; ga.Wp = w.mm.gate_w; ga.bp = w.mm.gate_b; ga.sim_nT = w.mm.sim_nT; ga.logit_scale = w.mm.scale;
         ga.E = g.num_experts; ga.L = L; ga.small_tokens = c->gate_small_tokens;
         ga.idx = c->rb.idx; ga.gate = c->rb.gate; ga.key = c->rb.key; ga.cnt = c->rb.state;
-        if (split == 2 && !twin) {
+        if (split == 2 && (!twin || twin_split)) {
             if (!c->cnt_clean) MC_HIP(hipMemsetAsync(ga.cnt, 0, sizeof(int) * 32, s));
             c->cnt_clean = false;
             if ((r = parts_fork(c, s))) return r;
             ga.zero_cnt = 0;
             for (int k = 0; k < c->nparts; ++k) {
-                ga.tok0 = part_row0(c, k) * H; ga.N = part_row0(c, k + 1) * H;
+                if (twin_split) { ga.tok0 = k ? sub_rows * H : 0; ga.N = k ? c->N / 2 : sub_rows * H; }
+                else { ga.tok0 = part_row0(c, k) * H; ga.N = part_row0(c, k + 1) * H; }
                 if ((r = mc_launch_gate(ga, part_stream(c, k, s)))) return r;
             }
         } else {
@@ -747,7 +761,7 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     }
     // two slot groups when the two sample groups run on two streams: each group's expert MLP joins its own chain
     const bool grouped = split == 2 && c->nparts == 2 && chain_on(c, 6);
-    const long gsplit = grouped ? part_row0(c, 1) * H : c->N;
+    const long gsplit = twin_split ? sub_rows * H : grouped ? part_row0(c, 1) * H : c->N;
     if ((r = run_moe(c, w.mm, c->z, c->N, nullptr, 0, fused_gate, twin, gsplit, s, &w.h_fc1, &w.h_fc2))) return r;   // routing (+ experts if one group)
     if (c->cap_idx) {
         if (twin) {     // expert ids exist for the first half only: the twins have the same ones
@@ -764,6 +778,27 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
         // Large batches: the two CFG halves go down two streams.  Each kernel of the chain fills 4.59 "waves" of
         // workgroups at B=64, so ~8 % of every launch is a tail on a partly idle chip; with two independent chains in
         // flight the next kernel of one half starts inside the tail of the other (same effect as two batches in flight).
+        if (twin_split) {
+            const long half_rows = (long)c->B * c->T;
+            hipStream_t s1 = c->parts[0];
+            if ((r = parts_fork(c, s))) return r;
+            if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s, &w.h_fc1, &w.h_fc2))) return r;
+            if ((r = moe_experts(c, w.mm, c->z, c->N, 1, s1, &w.h_fc1, &w.h_fc2))) return r;
+            if ((r = layer_rows(c, i, hs, step, twin, 0, sub_rows, s, s, 1))) return r;
+            if ((r = layer_rows(c, i, hs, step, twin, sub_rows, half_rows - sub_rows, s1, s1, 1))) return r;
+            // cross-join: each stream waits for the other's front
+            MC_HIP(hipEventRecord(c->ev_join, s));
+            MC_HIP(hipEventRecord(c->ev_parts[0], s1));
+            MC_HIP(hipStreamWaitEvent(s1, c->ev_join, 0));
+            MC_HIP(hipStreamWaitEvent(s, c->ev_parts[0], 0));
+            // the second CFG half's own front: exits at once while no twin pair was split by a capacity cut (the usual case)
+            if ((r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 1))) return r;
+            if ((r = layer_rows(c, i, hs, step, twin, 0, half_rows, s, s, 2))) return r;
+            if ((r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 2))) return r;
+            for (int k = 0; k < c->nparts; ++k)
+                if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+            return MC_OK;
+        }
         if (grouped && twin) {         // group 1 combines group 0's expert rows (its own tokens have no slots): fork after them
             if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s, &w.h_fc1, &w.h_fc2))) return r;
             if ((r = parts_fork(c, s))) return r;

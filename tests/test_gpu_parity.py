@@ -601,12 +601,12 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [65520, 65527])
+@pytest.mark.parametrize('chain', [131056, 131063])
 def test_generic_fallback_path_vs_oracle(chain):
-    """chain mask with bits 0-2 cleared (65520): the generic path -- plain gemm_k launches + row kernels instead of the fused
+    """chain mask with bits 0-2 cleared (131056): the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
     is outside the fused kernels' range, so it keeps its own parity test: small-config denoiser call + 3 DDPM steps vs the CPU
-    oracle, beside the default mask (65527) on the same inputs.  The mask is a per-context option (mc_ctx_set_option): both
+    oracle, beside the default mask (131063) on the same inputs.  The mask is a per-context option (mc_ctx_set_option): both
     contexts live in this one process."""
     from motioncraft_amd.diffusion import build_diffusion
     from motioncraft_amd.engine import NativeModel
@@ -654,8 +654,9 @@ def test_fused_proj_qkv_body_kernel_is_bit_identical_to_the_separate_kernels():
     B, T = 3, 24
     x, xf, mask = synth_inputs(dims, B, T, seed=5, lengths=[24, 20, 13])
     got = {}
-    for tag, chain in (('fused', 65527), ('separate', 65527 & ~(1 << 15)), ('fused_one_stream', 65527 & ~(1 << 5)),
-                       ('separate_one_stream', 65527 & ~((1 << 15) | (1 << 5)))):
+    DFL = 131063                                               # the default mask (McOptions::chain)
+    for tag, chain in (('fused', DFL), ('separate', DFL & ~(1 << 15)), ('fused_one_stream', DFL & ~(1 << 5)),
+                       ('separate_one_stream', DFL & ~((1 << 15) | (1 << 5))), ('fused_no_twin_split', DFL & ~(1 << 16))):
         ctx = nm.context(B, T, max_steps=2)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('chain', chain)
@@ -671,6 +672,7 @@ def test_fused_proj_qkv_body_kernel_is_bit_identical_to_the_separate_kernels():
         ctx.close()
     names = ('x0', 'ys layer 0', 'mf layer 0', 'ys layer 1', 'mf layer 1', 'h after 2 layers')
     for a, b, ks in (('fused', 'separate', range(6)), ('fused_one_stream', 'separate_one_stream', range(6)),
+                     ('fused', 'fused_no_twin_split', range(6)),      # round 4: the twin layer's front as two sample sub-groups on two streams
                      ('fused', 'fused_one_stream', (1, 2))):       # (later stages: the FiLM GEMM's tile width follows the launch's row count)
         for k in ks:
             assert bool(torch.isfinite(got[a][k]).all()), (a, names[k])
