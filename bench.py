@@ -379,6 +379,57 @@ def main():
         configs0 = {'loop_ms': round(t1 * 1e3, 2), 'frames_per_s': round(T / t1, 1),
                     'note': 'side measurement, not `value`: configs[0] (batch 1, 196 frames, 50-step DDIM) as one mc_sample_loop call, median of 5'}
 
+    # ---- BASELINE configs[4] as a measured workload (NOT `value`): mixed text + audio plug-and-play control (0.125b base + 2
+    # control copies, pre-encoded audio condition of width D through ControlT2MHalf, controlnet.py:340-424), fp16 MFMA
+    # (tools/test.py:95-97 wrap_fp16_model), the COMPLETE 50-step DDIM loop as hipGraph replays (one captured step, device-side step
+    # index), per-GPU batch 32 (configs[2]'s 256 / 8), 196 frames ----
+    configs4 = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        from motioncraft_amd.synthetic import control_param_shapes
+        copy, feats, B4 = 2, DIMS['L'] * DIMS['H'], 32
+        nm4 = NativeModel(DIMS, make_state_dict(DIMS, 0, shapes=control_param_shapes(DIMS, copy, feats)), cfg_scale=DIMS['scale'], device=local_rank)
+        d50 = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                                   model_var_type='fixed_large', respace='15,15,8,6,6'))
+        k50 = [d50.step_coefs(j, 'ddim', DIMS['scale'], 0.0) for j in range(50)]
+        D_ = DIMS['L'] * DIMS['H']
+        # algorithmic FLOPs per sample per step: 4 + 2 DecoderLayers (the formula of SURVEY.md section 8d with NL = 6) + the two
+        # after_proj Linear layers of the copies on both CFG halves (before_proj(c) is hoisted: once per batch)
+        fl4 = algorithmic_flops_per_sample_step(dict(DIMS, NL=DIMS['NL'] + copy), T) + copy * 2 * T * 2 * D_ * D_
+        configs4 = {'workload': f'configs[4]: 0.125b + {copy} control copies, text + audio condition, batch {B4} per GPU, {T} frames, complete 50-step DDIM '
+                                'loop, hipGraph replay', 'algorithmic_gflop_per_sample_step': round(fl4 / 1e9, 3)}
+        gs = torch.cuda.Stream()
+        with torch.cuda.stream(gs):
+            for prec, peak in (('f16x3', PEAK_FP16_MFMA_TFLOPS / 3), ('f16', PEAK_FP16_MFMA_TFLOPS)):
+                c4 = nm4.context(B4, T, max_steps=50)
+                c4.set_precision(prec)
+                c4.set_timesteps(d50.timestep_map)
+                c4.set_condition(xf[:B4].contiguous(), mask[:B4].contiguous())
+                c4.set_control(torch.randn(B4, T, feats, device=dev, generator=gen))
+                x4 = torch.randn(B4, T, C, device=dev, generator=gen)
+                n4 = torch.zeros_like(x4)                   # eta = 0: the draws are not used
+                c4.graph_capture(x4, n4, k50)
+                ts4 = []
+                for rep in range(4):
+                    x4.normal_(generator=gen)
+                    gs.synchronize()
+                    t0 = time.perf_counter()
+                    for j in range(49, -1, -1):
+                        c4.graph_step(j)
+                    gs.synchronize()
+                    ts4.append(time.perf_counter() - t0)
+                assert bool(torch.isfinite(x4).all()), 'configs[4] loop produced non-finite poses'
+                t4 = sorted(ts4[1:])[1]
+                ach4 = fl4 * B4 * 50 / t4 / 1e12
+                configs4[prec] = {'loop_ms': round(t4 * 1e3, 2), 'ms_per_step': round(t4 * 20, 3), 'frames_per_s': round(B4 * T / t4, 1),
+                                  'roofline': {'bound': 'mfma', 'achieved': round(ach4, 1), 'peak': round(peak, 1),
+                                               'unit': 'TFLOP/s' + (' (fp32-equivalent: three fp16 products per fp32 product)' if prec == 'f16x3' else ''),
+                                               'frac': round(ach4 / peak, 4)}}
+                c4.graph_release()
+                c4.close()
+        nm4.close()
+        configs4['note'] = ('side measurement, not `value`: median of 3 complete loops after a warm-up loop; gate / routing / normalisations / softmaxes '
+                            'stay fp32 in both modes, so the fp16 MFMA ceiling bounds only the GEMM-shaped ~95 % of the FLOPs')
+
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms, t_full or 0.0], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -409,7 +460,7 @@ def main():
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
-                       'full_loop': full_loop, 'reduced_precision_modes': reduced, 'configs0_gpu': configs0,
+                       'full_loop': full_loop, 'reduced_precision_modes': reduced, 'configs0_gpu': configs0, 'configs4': configs4,
                        'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
                        'exact_reductions': 'results equal the unreduced computation (tests/test_gpu_parity.py): CFG twins of base layer 0 '
                                            'share gate / expert / proj / qkv / body work (identical inputs); the last StylizationBlock '

@@ -717,8 +717,9 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     oracle -- teacher-forced to the HIP path's routing decisions, from the HIP path's own x_t: every x_{t-1} within
     1e-3, routing flips of the free-running oracle reported (all 50 steps at the small size, the first 30 at the 0.125b
     width; the replay test below runs all 50 there).  Plain 'f16' (one rounding to fp16 per operand, what
-    mmcv's wrap_fp16_model does to the reference, tools/test.py:95-97) is measured on the first steps and held to the
-    fp16-class bound it can meet."""
+    mmcv's wrap_fp16_model does to the reference, tools/test.py:95-97) is walked over the first steps and held to the SAME 1e-3
+    per sampler step (observed 1.1e-4: the update damps the x0 error; the x0 prediction itself is fp16-class, see
+    test_fp16_mfma_large_batch_kernels_single_step_vs_oracle)."""
     from motioncraft_amd.diffusion import build_diffusion
     from motioncraft_amd.engine import NativeModel
     from oracle import stmogen_oracle as O, weights as W
@@ -738,7 +739,7 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     NL = dims['NL']
     torch.set_num_threads(min(32, os.cpu_count()))
     noises = step_noise_from_seed(93, (B, T, dims['input_feats']), 50)
-    for prec, nsteps, tol in (('f16x3', 50 if size == 'small' else 30, TOL_FINAL), ('f16', 4, 3e-2)):
+    for prec, nsteps, tol in (('f16x3', 50 if size == 'small' else 30, TOL_FINAL), ('f16', 4, TOL_FINAL)):      # (f16: 1.1e-4 per step observed)
         ctx = nm.context(B, T, max_steps=50)
         ctx.set_precision(prec)
         ctx.enable_capture()
@@ -770,7 +771,10 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
 def test_fp16_mfma_large_batch_kernels_single_step_vs_oracle(full_model):
     """The large-batch kernel selection of the reduced-precision mode (N > 65 536 tokens: proj + body LayerNorm + q/k/v in
     one chained fp16-MFMA kernel, two sample groups on two streams, twin dedupe in layer 0): one denoiser call at B=16,
-    196 frames, mixed lengths, against the fp32 oracle teacher-forced to the HIP path's routing."""
+    196 frames, mixed lengths, against the fp32 oracle teacher-forced to the HIP path's routing.  'f16x3' meets the fp32 path's
+    bound on the x0 PREDICTION; plain 'f16' does not (8e-3 observed: one fp16 rounding per operand, amplified by the CFG weights
+    5.16 / -4.16 at t = 640) and is documented as outside the north-star tolerance on x0 (include/motioncraft_amd.h) -- what it
+    does meet is 1e-3 on x_{t-1} of the sampler step, asserted here through the DDPM update of both predictions."""
     from oracle import stmogen_oracle as O
     sd, nm = full_model
     B, T = 16, 196
@@ -780,7 +784,7 @@ def test_fp16_mfma_large_batch_kernels_single_step_vs_oracle(full_model):
     torch.set_num_threads(min(32, os.cpu_count()))
     tf = O.precompute_text(sd, xf, FULL)
     w = (1 - (1000 - 640) / 1000) * FULL['scale'] + 1
-    for prec, tol in (('f16x3', TOL_STEP), ('f16', 3e-2)):
+    for prec, tol in (('f16x3', TOL_STEP), ('f16', 2e-2)):
         ctx = nm.context(B, T, max_steps=1)
         ctx.set_precision(prec)
         ctx.enable_capture()
@@ -791,8 +795,12 @@ def test_fp16_mfma_large_batch_kernels_single_step_vs_oracle(full_model):
         forced = [ctx.routing(i) for i in range(FULL['NL'])]
         ref = O.denoise(sd, FULL, x_T, 640, xf, mask, text_feats=tf, forced_routing=forced)
         err = maxabs(out2[:B] * w + out2[B:] * (1 - w), ref)
-        print(f'B=16 single step, precision {prec}: |hip - fp32 oracle (teacher-forced)| {err:.2e}')
-        assert err <= tol, (prec, err)
+        sched = O.Schedule(1000, None)
+        eps = torch.randn(x_T.shape, generator=torch.Generator().manual_seed(3))
+        got0 = (out2[:B] * w + out2[B:] * (1 - w)).cpu()
+        err_prev = maxabs(O.ddpm_step(sched, 640, x_T, got0, eps), O.ddpm_step(sched, 640, x_T, ref, eps))
+        print(f'B=16 single step, precision {prec}: |hip - fp32 oracle (teacher-forced)| x0 {err:.2e}, x_(t-1) {err_prev:.2e}')
+        assert err <= tol and err_prev <= TOL_FINAL, (prec, err, err_prev)
         ctx.close()
 
 

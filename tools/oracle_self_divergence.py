@@ -106,10 +106,12 @@ for name, th, gate in VARIANTS:
     print(f'# variant {name:9s} ({th} threads): {time.time() - t0:.0f} s', flush=True)
 base_traj, base_r = res['base']
 # how close are neighbouring importance scores at the cut?  (layer 0 of the first call)
-imp = torch.sort(base_r[0][2]).values
-gaps = (imp[1:] - imp[:-1])
-print(f'# layer-0 importance scores (max gate score per token): median gap between neighbours in rank order {float(gaps.median()):.2e}, '
-      f'{int((gaps == 0).sum())} exact ties (CFG twins), fp32 ulp at the median score {float(torch.finfo(torch.float32).eps * imp.median()):.2e}')
+half = base_r[0][2].shape[0] // 2
+for l in (0, dims['NL'] - 1):
+    imp = torch.sort(base_r[l][2][:half] if l == 0 else base_r[l][2]).values      # (layer 0: the second CFG half repeats the first exactly)
+    gaps = (imp[1:] - imp[:-1])
+    print(f'# layer-{l} importance scores (max gate score per token{", first CFG half" if l == 0 else ""}): median gap between neighbours in rank order '
+          f'{float(gaps.median()):.2e}, {int((gaps == 0).sum())} exact ties, fp32 ulp at the median score {float(torch.finfo(torch.float32).eps * imp.median()):.2e}')
 print('variant    | first call, identical input: differing (token, choice) pairs per layer [expert id / keep]      | free-running max|x - x_base| per step')
 for name, _, _ in VARIANTS[1:]:
     traj, r = res[name]
