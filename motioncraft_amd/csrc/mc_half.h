@@ -22,8 +22,10 @@ int mc_launch_split_f16(const float* x, mc_half* hi, mc_half* lo, long n, hipStr
 int mc_launch_split_f16_chainperm(const float* x, mc_half* hi, mc_half* lo, long rows, int K, hipStream_t s);
 
 struct GemmHArgs {
-    const float* A = nullptr;     // [M][lda] fp32 activations (converted while staging)
+    const float* A = nullptr;     // [M][lda] fp32 activations (converted while staging) ...
     long lda = 0;
+    const mc_half* Ah = nullptr;  // ... or, when set, fp16 planes [M][K] written by the producer (film_rows_k): hi
+    const mc_half* Al = nullptr;  //     and lo (split mode)
     const mc_half* Wh = nullptr;  // [N][K] fp16 hi plane of the weight (nn.Linear layout)
     const mc_half* Wl = nullptr;  // lo plane (split mode)
     const float* bias = nullptr;  // [N]

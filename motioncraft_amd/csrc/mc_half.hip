@@ -180,6 +180,125 @@ __global__ __launch_bounds__(256, 2) void gemm_h_k(GemmHArgs g) {
 }
 
 // =================================================================================================
+// gemm_hd_k: the same product fed from fp16 PLANES of A (written once by the producer: film_rows_k in a reduced-precision
+// context) instead of splitting the fp32 activations while staging -- gemm_h_k converts every A element once per COLUMN tile (12
+// times at N = 1536) and that VALU work was ~30 % of its MFMA time.  Both operands arrive by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers, no ds_write): the LDS image of a plane tile is the unpadded [128 rows][BK halves], BK = 64 (f16: 128-byte
+// rows, 16-byte chunk c of row r at position c ^ (r & 7), gemm_dma_k's layout) or 32 (split: 64-byte rows, c ^ ((r >> 2) & 3),
+// gemm_wp_k's layout), double buffered: 2 x 32 KB in either mode, one barrier per k-tile (16 / 24 MFMAs per wave).
+// =================================================================================================
+// 16 bytes per lane from sbase + voff (bytes) straight into LDS at lds_byte + 16 lane (M0 form; asm: the builtin does not survive host-side
+// instantiation inside a kernel TEMPLATE, and the compiler must not count / drain it as an ordinary load anyway -- mc_gemm.hip dma16)
+__device__ __forceinline__ void dma16h(unsigned voff, const mc_half* sbase, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
+    constexpr int P = SPLIT ? 2 : 1;
+    constexpr int BKH = SPLIT ? 32 : 64;            // halves per k-tile
+    constexpr int CH = BKH / 8;                     // 16-byte chunks per row
+    constexpr int RPI = 64 / CH;                    // rows per wave-wide DMA instruction
+    constexpr int PT = 128 * BKH;                   // halves per plane tile
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 2 * P * PT];      // [buf][A | W][plane][128][BKH] = 64 KB
+    auto tile = [&](int buf, int op, int p) { return smem + ((buf * 2 + op) * P + p) * PT; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, frow = lane & 31, hf = lane >> 5;
+    const int ntn = g.N / 128;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * 128, nrows = min(128, g.M - row0);
+    // DMA: wave w moves rows [32 w, 32 w + 32) of every plane tile, RPI rows per instruction: lane -> row q RPI + lane / CH,
+    // LDS position lane % CH, global chunk (lane % CH) ^ swz(row)
+    const int dr = lane / CH, dpos = lane % CH;
+    auto swz = [&](int r) { return SPLIT ? ((r >> 2) & 3) : (r & 7); };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int NQ = 32 / RPI;                    // instructions per plane tile per wave (2 / 4)
+    unsigned goa[NQ], gow[NQ];                      // byte offsets into the planes (< 2^32: checked by the launcher)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int r = 32 * wave + q * RPI + dr;     // row inside the tile
+        const int ar = min(row0 + r, g.M - 1);      // rows past M re-read the last row (never stored)
+        goa[q] = (unsigned)(((long)ar * g.K + (dpos ^ swz(r)) * 8) * 2);
+        gow[q] = (unsigned)(((long)(tn * 128 + r) * g.K + (dpos ^ swz(r)) * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const mc_half* ap = (p ? g.Al : g.Ah) + kt * BKH;
+            const mc_half* wp = (p ? g.Wl : g.Wh) + kt * BKH;
+            const unsigned la = lds0 + (unsigned)((((buf * 2 + 0) * P + p) * PT + 32 * wave_u * BKH) * 2);
+            const unsigned lw = lds0 + (unsigned)((((buf * 2 + 1) * P + p) * PT + 32 * wave_u * BKH) * 2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                dma16h(goa[q], ap, la + q * RPI * BKH * 2);
+                dma16h(gow[q], wp, lw + q * RPI * BKH * 2);
+            }
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int nk = g.K / BKH;
+    const int sw = swz(frow);                        // rows frow, frow + 32, + 64, + 96 share the swizzle term
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);     // in flight during the MFMAs below; drained in front of the barrier
+        const int ra = (wm * 64 + frow) * BKH, rw = (wn * 64 + frow) * BKH;
+#pragma unroll
+        for (int s = 0; s < BKH / 16; ++s) {
+            const int pos = ((2 * s + hf) ^ sw) * 8;
+            f16x8 fa[2][P], fw[2][P];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    fa[i][p] = *reinterpret_cast<const f16x8*>(tile(buf, 0, p) + ra + i * 32 * BKH + pos);
+                    fw[i][p] = *reinterpret_cast<const f16x8*>(tile(buf, 1, p) + rw + i * 32 * BKH + pos);
+                }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = mma3<SPLIT>(fw[ni][0], fw[ni][P - 1], fa[mi][0], fa[mi][P - 1], acc[mi][ni]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile kt + 1 has landed
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = wm * 64 + mi * 32 + frow;
+        if (m >= nrows) continue;
+        float* crow = g.C + (long)(row0 + m) * g.ldc;
+        const float* rrow = g.R ? g.R + (long)(row0 + m) * g.ldr : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tn * 128 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (g.act != ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], g.act);
+                }
+                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+                *reinterpret_cast<f32x4*>(crow + n) = v;
+            }
+    }
+}
+
+// =================================================================================================
 // Fused 2-layer MLP on the fp16 MFMA (structure of mlp2_k, mc_chain.hip): X fragment in VGPRs, hidden in 32-wide chunks
 // whose FC1 accumulator -- bias + exact GELU in fp32, then split -- is directly the B operand of FC2
 // =================================================================================================
@@ -500,6 +619,18 @@ int mc_launch_split_f16_chainperm(const float* x, mc_half* hi, mc_half* lo, long
 }
 
 int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
+    if (g.Ah) {            // A comes as fp16 planes [M][K] (K contiguous, no padding): the LDS-DMA kernel
+        MC_REQUIRE(g.Wh && g.C && (!split || (g.Wl && g.Al)), "fp16 gemm (planes): null operand");
+        MC_REQUIRE(g.N % 128 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.R || g.ldr % 4 == 0) && (long)g.M * g.K * 2 < (1L << 31) &&
+                       (long)g.N * g.K * 2 < (1L << 31),
+                   "fp16 gemm (planes): unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
+        if (g.M <= 0) return MC_OK;
+        dim3 grid(cdiv(g.M, 128) * (g.N / 128));
+        if (split) hipLaunchKernelGGL(gemm_hd_k<true>, grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(gemm_hd_k<false>, grid, dim3(256), 0, s, g);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
     MC_REQUIRE(g.A && g.Wh && g.C && (!split || g.Wl), "fp16 gemm: null operand");
     MC_REQUIRE(g.N % 128 == 0 && g.K % 32 == 0 && g.lda % 4 == 0 && g.ldc % 4 == 0 && (!g.R || g.ldr % 4 == 0),
                "fp16 gemm: unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ ss, float* __restrict__ A,
                                                    long rows, int D, TwinAlias y1_alias, long row0, StepRef step, int y1_parts,
-                                                   long y1_pstride) {
+                                                   long y1_pstride, int planes, long plane_stride) {
     if (step.ptr) ss += (long)(*step.ptr) * step.stride;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -104,7 +104,27 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = silu_f((v[c][j] * rstd * g[j] + b[j]) * (1.0f + sc[j]) + sh[j]);
-            *reinterpret_cast<f32x4*>(A + r * D + ch * 4) = o;
+            if (planes == 0) *reinterpret_cast<f32x4*>(A + r * D + ch * 4) = o;
+            else {
+                // reduced-precision contexts: the GEMM that consumes `a` wants fp16 operand planes (hi, and lo = fp16(x - hi) in the
+                // split mode: the arithmetic of split8, mc_half.hip) -- written here ONCE instead of converted by every column tile
+                // of the GEMM.  A then is [rows][D] halves, the lo plane plane_stride halves behind it.
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = o[j];
+                    asm volatile("" : "+v"(x));          // pinned: hi and lo must see the SAME fp32 value (no fused convert of the producer's product)
+                    const _Float16 hx = (_Float16)x;
+                    float hxf = (float)hx;
+                    asm volatile("" : "+v"(hxf));
+                    hi[j] = hx;
+                    lo[j] = (_Float16)(x - hxf);
+                }
+                _Float16* Ah = reinterpret_cast<_Float16*>(A);
+                *reinterpret_cast<h4*>(Ah + r * D + ch * 4) = hi;
+                if (planes == 2) *reinterpret_cast<h4*>(Ah + plane_stride + r * D + ch * 4) = lo;
+            }
         }
     }
 }
@@ -430,11 +450,12 @@ int mc_launch_ln_rows(const float* X, long ldx, int x_col, const float* gamma, c
 
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
                         const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0, StepRef step,
-                        int y1_parts, long y1_pstride) {
+                        int y1_parts, long y1_pstride, int planes, long plane_stride) {
     MC_REQUIRE(D % 4 == 0 && D <= FILM_MAXC * 256, "film_rows: unsupported D=%d", D);
+    MC_REQUIRE(planes >= 0 && planes <= 2, "film_rows: planes=%d", planes);
     if (rows <= 0) return MC_OK;
     hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step,
-                       y1_parts < 1 ? 1 : y1_parts, y1_pstride);
+                       y1_parts < 1 ? 1 : y1_parts, y1_pstride, planes, plane_stride);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

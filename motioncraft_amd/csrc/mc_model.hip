@@ -67,7 +67,8 @@ struct McOptions {
     // 3 or 4 hidden slices on the device, 14 small batches: temporal branch on the main stream, LN + q/k/v + body on the side stream,
     // 15 (round 4) pqbody_k: bit 10's kernel also runs the body-topology attention (q/k/v never in HBM; L = 128, 12 parts, fp32),
     // 16 (round 4) the twin layer's gate / experts / front kernels run as two sample sub-groups on the two streams
-    int chain = 65527 | (1 << 16);     // (all but bit 3)
+    // 17 (round 4) reduced-precision contexts: film_rows_k writes the FiLM GEMM's A operand as fp16 planes, gemm_hd_k reads them by LDS-DMA
+    int chain = 65527 | (1 << 16) | (1 << 17);     // (all but bit 3)
     long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
@@ -509,11 +510,24 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     int r;
     StepRef sref;
     if (c->graph_mode) { sref.ptr = c->gstep; sref.stride = 2L * D; }     // `ss` then is the table's row of step 0
-    if ((r = mc_launch_film_rows(y1_parts > 1 ? y1 : y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, c->a + o, nrows, D, s, y1_alias, row0, sref,
-                                 y1_parts, nrows * D))) return r;
+    // reduced-precision contexts: `a` is consumed by the fp16-MFMA GEMM only -> written as fp16 planes (hi [rows][D] | lo) into the same
+    // buffer: the rows of this range start at halves offset o, the lo plane sits rows * D halves behind the hi plane
+    const bool half_gemm = !prologue_only && hw && hw->hi && use_half(c);
+    const bool planes = half_gemm && chain_on(c, 17) && D % 64 == 0;
+    const long pstride = c->rows * D;
+    float* a_out = planes ? reinterpret_cast<float*>(reinterpret_cast<mc_half*>(c->a) + o) : c->a + o;
+    if ((r = mc_launch_film_rows(y1_parts > 1 ? y1 : y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, a_out, nrows, D, s, y1_alias, row0, sref,
+                                 y1_parts, nrows * D, planes ? (c->prec == MC_PREC_F16X3 ? 2 : 1) : 0, pstride))) return r;
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
-    if (hw && hw->hi && use_half(c))
+    if (planes) {
+        GemmHArgs g;
+        g.Ah = reinterpret_cast<mc_half*>(c->a) + o; g.Al = g.Ah + pstride;
+        g.Wh = hw->hi; g.Wl = hw->lo; g.bias = out_b; g.R = hs + o; g.ldr = D; g.C = hs + o; g.ldc = D;
+        g.M = (int)nrows; g.N = D; g.K = D;
+        return mc_launch_gemm_h(g, c->prec == MC_PREC_F16X3, s);
+    }
+    if (half_gemm)
         return dense_h(c, c->a + o, *hw, out_b, hs + o, hs + o, nrows, D, D, s);
     if (nrows <= small_gemm_rows(c) && D % 64 == 0) {     // up to a few thousand rows: 64 x 64 tiles, short MFMA chains, no K split (B=8: -11 % per step)
         GemmArgs q;
