@@ -15,6 +15,7 @@
 //   rowchain_k<1> qkv = LN(mf[:, :L]) Wqkv^T + b
 #include "mc_common.h"
 #include "mc_chain.h"
+#include "mc_bodyphase.h"
 #include <stdlib.h>
 
 namespace {
@@ -741,28 +742,18 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
 // =================================================================================================
 // NQ = H: the set produces all H parts of its frames; NQ < H: parts [h0, h0 + NQ) only (the fifth pass is cut 4 ways by parts:
 // every wave rebuilds A = k^T v of the two odd frames and projects H / 4 of their query rows)
-template <int H, int NQ>
-struct BodySet {
-    float q[NQ], k[H];
-    int fl;        // frame of this lane inside the tile
-    int h0;        // first part this set projects
-    bool on;       // the frame exists (inside the tile, inside the range, not aliased)
-};
-
 template <int L, int H>
 __global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
     static_assert(L == 128, "pqbody_k: the body phase maps one dynamic head (16 channels) onto one DPP row");
     constexpr int NJ = L / 8, NC0 = 4 * L / 32, NG = L / 32, NKEEP = L / 32, NSEQ = NC0 + 3 * NG;
-    constexpr int FR = 128 / H, TR = FR * H;        // frames / token rows of a tile
-    constexpr int NPASS = (FR + 1) / 2;             // wave passes of the body phase (2 frames x 32 channels per pass)
-    constexpr int XS = 36;                          // exchange slot row stride (b128 fragment writes conflict-free)
+    using BP = BodyPhase<L, H>;
+    constexpr int TR = BP::TR, XS = BP::XS;         // token rows of a tile, exchange slot row stride
     using SP = ChunkStage<32, L>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 7 * L + 2 * 128 * XS + H * H];
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * SP::LDS_LD + 7 * L + BP::LDS_FLOATS];
     auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
     float* s_bias = smem + 2 * 32 * SP::LDS_LD;      // proj bias [4L] | qkv bias [3L]
     float* s_x = s_bias + 7 * L;                     // two exchange slots [128][XS]
     float* s_w = s_x + 2 * 128 * XS;                 // softmax(body_weight) [H][H]
-    auto Xs = [&](int slot) { return s_x + slot * 128 * XS; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
     for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
@@ -846,111 +837,22 @@ __global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
             *reinterpret_cast<f32x4*>(xr + 8 * q) = v;
         }
     };
-    const int cc = lane & 31;                       // channel inside the group: head (cc >> 4), lane (cc & 15) of its DPP row
-    auto set_init = [&](auto& b, int pass, int h0) {
-        b.fl = 2 * pass + (lane >> 5);
-        b.h0 = h0;
-        const long t0 = tile_tok0 + (long)b.fl * H;
-        b.on = pass < NPASS && b.fl < FR && t0 < g.N && !(aliasing && t0 >= g.alias.from);
-    };
-    auto stage_q = [&](auto& b, const float* slot) {        // query: softmax over the 16 channels of the head
-        constexpr int NQ = sizeof(b.q) / sizeof(float);
-        if (!b.on) return;
-        const float* x = slot + (b.fl * H + b.h0) * XS + cc;
-#pragma unroll
-        for (int h = 0; h < NQ; ++h) b.q[h] = x[h * XS];
-#pragma unroll
-        for (int h = 0; h < NQ; ++h) {
-            const float m = group_max(b.q[h], 16);
-            const float e = fast_exp2((b.q[h] - m) * LOG2E);
-            b.q[h] = e * __frcp_rn(group_sum(e, 16));
-        }
-    };
-    auto stage_k = [&](auto& b, const float* slot) {        // key: softmax over the H body parts (in-lane)
-        if (!b.on) return;
-        const float* x = slot + (b.fl * H) * XS + cc;
-#pragma unroll
-        for (int h = 0; h < H; ++h) b.k[h] = x[h * XS];
-        float m = b.k[0];
-#pragma unroll
-        for (int h = 1; h < H; ++h) m = fmaxf(m, b.k[h]);
-        float sum = 0.f;
-#pragma unroll
-        for (int h = 0; h < H; ++h) { b.k[h] = fast_exp2((b.k[h] - m) * LOG2E); sum += b.k[h]; }
-        const float rs = __frcp_rn(sum);
-#pragma unroll
-        for (int h = 0; h < H; ++h) b.k[h] *= rs;
-    };
-    auto stage_v = [&](auto& b, const float* slot, int cg) {  // A = k^T v, y = q A (+ static topology + residual) -> ys
-        constexpr int NQ = sizeof(b.q) / sizeof(float);
-        if (!b.on) return;
-        const long t0 = tile_tok0 + (long)b.fl * H;
-        const float* x = slot + (b.fl * H) * XS + cc;
-        const float* bvp = g.Y + t0 * g.ldy + cg * 32 + cc;      // raw body_value: stored by this workgroup in the projection phase
-        float v[H], bv[H];
-#pragma unroll
-        for (int h = 0; h < H; ++h) bv[h] = bvp[h * g.ldy];
-#pragma unroll
-        for (int h = 0; h < H; ++h) v[h] = x[h * XS];
-        float A_[16];
-        auto contract_kv = [&](auto S) {
-            float a = 0.f;
-#pragma unroll
-            for (int h = 0; h < H; ++h) a += row_ror<decltype(S)::value>(b.k[h]) * v[h];
-            A_[decltype(S)::value] = a;
-        };
-        static_for_16(contract_kv);
-        float* out = g.ys + (t0 / H) * (long)(H * L) + cg * 32 + cc;
-        if constexpr (NQ == H) {
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                float st = 0.f;
-#pragma unroll
-                for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
-                float dy = 0.f;
-                auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(b.q[h]) * A_[decltype(S)::value]; };
-                static_for_16(contract_qa);
-                out[h * L] = st + (bv[h] + dy);
-            }
-        } else {
-#pragma unroll
-            for (int hq = 0; hq < NQ; ++hq) {
-                const int h = b.h0 + hq;               // wave-uniform
-                float st = 0.f;
-#pragma unroll
-                for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
-                float dy = 0.f;
-                auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(b.q[hq]) * A_[decltype(S)::value]; };
-                static_for_16(contract_qa);
-                float bvh = bv[0];                     // bv[h] for a runtime (wave-uniform) h without indexing the register array
-#pragma unroll
-                for (int j = 1; j < H; ++j) bvh = j == h ? bv[j] : bvh;
-                out[h * L] = st + (bvh + dy);
-            }
-        }
-    };
-    static_assert(H % 4 == 0 && NPASS <= 5, "pqbody_k: 4 full passes + one pass cut 4 ways by parts");
-    BodySet<H, H> b0;
-    BodySet<H, H / 4> b1;
+    BodyPhase<L, H> bp(g, s_x, s_w, tile_tok0, aliasing, lane, wave);
 #pragma unroll 1
     for (int cg = 0; cg < NG; ++cg) {
         const int seq = NC0 + 3 * cg;
-        float* Sq = Xs(cg & 1);
-        float* Sk = Xs((cg & 1) ^ 1);
-        set_init(b0, wave, 0);
-        set_init(b1, 4, wave * (H / 4));
+        float* Sq = bp.slot(cg & 1);
+        float* Sk = bp.slot((cg & 1) ^ 1);
+        bp.begin_group();
         qkv_chunk(seq, 4 * L + cg * 32, Sq);                      // q
         __syncthreads();
         qkv_chunk(seq + 1, 5 * L + cg * 32, Sk);                  // k
-        stage_q(b0, Sq);
-        stage_q(b1, Sq);
+        bp.after_k(Sq);
         __syncthreads();
         qkv_chunk(seq + 2, 6 * L + cg * 32, Sq);                  // v (every q read of Sq happened before the barrier above)
-        stage_k(b0, Sk);
-        stage_k(b1, Sk);
+        bp.after_v(Sk);
         __syncthreads();
-        stage_v(b0, Sq, cg);
-        stage_v(b1, Sq, cg);
+        bp.finish(Sq, cg);
         // (next group: q -> Sk, whose k reads are behind the barrier above; k -> Sq only after the next barrier, which every wave
         //  reaches after its v reads)
     }

@@ -49,3 +49,6 @@ bool mc_mlp_h_supported(int L, int hidden);
 // the K axis chain-permuted; combine + GELU + LayerNorm stay fp32
 int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
                         hipStream_t s);
+// projqkv_h + the body-topology attention over frame-aligned tiles (pqbody_k's fp16-MFMA twin; L = 128, H = 12): q/k/v stay on chip
+int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
+                       hipStream_t s);

@@ -13,6 +13,7 @@
 // fragment reads of any 16 distinct rows and the ds_write_b128 staging writes bank-conflict free.
 #include "mc_common.h"
 #include "mc_half.h"
+#include "mc_bodyphase.h"
 
 namespace {
 
@@ -596,6 +597,153 @@ __global__ __launch_bounds__(256, 2) void projqkv_h_k(RowChainArgs g, const mc_h
 #undef MC_PQH_CHUNK
 }
 
+// =================================================================================================
+// pqbody_h_k: projqkv_h_k + the body-topology attention (mc_bodyphase.h) over frame-aligned tiles, as pqbody_k (mc_chain.hip) does
+// for the fp32 path: the q/k/v chunks are walked per 32-channel group in the order q, k, v and handed to the body phase through two
+// LDS slots; q/k/v never reach HBM, ys is written from here.  Body arithmetic fp32 (identical to body_reg_k's).
+// =================================================================================================
+template <int L, int H, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g, const mc_half* __restrict__ Wph, const mc_half* __restrict__ Wpl,
+                                                     const mc_half* __restrict__ Wqh, const mc_half* __restrict__ Wql) {
+    using BP = BodyPhase<L, H>;
+    constexpr int TR = BP::TR, XS = BP::XS;
+    constexpr int P = SPLIT ? 2 : 1, NKB = L / 16, NJ = L / 8, NC0 = 4 * L / 32, NG = L / 32, NKEEP = L / 32, NSEQ = NC0 + 3 * NG;
+    constexpr int LD1 = L + 8, S1 = 32 * LD1;             // weight chunk [32 out rows][L] per plane
+    constexpr int PC = 32 * L / 8, NP = (PC + 255) / 256;  // 16-byte pieces per plane chunk
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * P * S1 + 2 * 7 * L + 2 * BP::LDS_FLOATS];
+    float* s_bias = reinterpret_cast<float*>(smem + 2 * P * S1);      // proj bias [4L] | qkv bias [3L]
+    float* s_x = s_bias + 7 * L;
+    float* s_w = s_x + 2 * 128 * XS;
+    auto Ws = [&](int b, int p) { return smem + (b * P + p) * S1; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, kq = hf * 4;
+    for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
+    for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
+    for (int i = tid; i < H * H; i += 256) s_w[i] = g.wsm[i];
+    const long tile_tok0 = g.tok0 + (long)blockIdx.x * TR;
+    const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
+    if (aliasing && tile_tok0 >= g.alias.from) return;
+    const int r = wave * 32 + (lane & 31);
+    const long tok = tile_tok0 + r;
+    const bool rok = r < TR && tok < g.N && !(aliasing && tok >= g.alias.from);
+    u32x4 rw[P][NP];
+    auto fetch = [&](int seq) {           // chunk sequence: projection rows, then per channel group q, k, v rows
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const mc_half* src;
+            if (seq < NC0) src = (p ? Wpl : Wph) + (long)seq * 32 * L;
+            else {
+                const int u = seq - NC0, cgi = u / 3, j = u - 3 * cgi;
+                src = (p ? Wql : Wqh) + (long)(j * L + cgi * 32) * L;
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC % 256 == 0 || idx < PC) rw[p][i] = *reinterpret_cast<const u32x4*>(src + (long)(idx / (L / 8)) * L + (idx % (L / 8)) * 8);
+            }
+        }
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = tid + 256 * i;
+                if (PC % 256 == 0 || idx < PC) *reinterpret_cast<u32x4*>(Ws(b, p) + (idx / (L / 8)) * LD1 + (idx % (L / 8)) * 8) = rw[p][i];
+            }
+    };
+    fetch(0);
+    f16x8 xh[NKB], xl[NKB];
+    {
+        const long tk = tok < g.N ? tok : 0;
+        const float w0 = rok ? g.comb_w[2 * tk] : 0.f, w1 = rok ? g.comb_w[2 * tk + 1] : 0.f;
+        const long ty = (g.twin_from > 0 && tk >= g.twin_from) ? tk - g.twin_from : tk;
+        const float* y0 = g.X + 2 * ty * L + hf * 8;
+        const bool k0 = w0 != 0.f, k1 = w1 != 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x4 v[2];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const f32x4 ya = *reinterpret_cast<const f32x4*>(y0 + 16 * kb + 4 * hq);
+                const f32x4 yb = *reinterpret_cast<const f32x4*>(y0 + L + 16 * kb + 4 * hq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[hq][i] = gelu_exact((k0 ? w0 * ya[i] : 0.f) + (k1 ? w1 * yb[i] : 0.f));
+            }
+            split8(v[0], v[1], xh[kb], xl[kb]);
+        }
+    }
+    commit(0);
+    fetch(1);
+    __syncthreads();
+    const int fo = (lane & 31) * LD1 + hf * 8;
+    float* orow = g.Y + tok * g.ldy + kq;
+    f32x4 bvf[NJ];
+    f16x8 bh[NKB], bl[NKB];
+    auto chunk = [&](int seq, const f16x8 (&fh)[NKB], const f16x8 (&fl)[NKB]) {
+        f32x16 a;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(Ws(seq & 1, 0) + fo + 16 * kb);
+            const f16x8 wl = SPLIT ? *reinterpret_cast<const f16x8*>(Ws(seq & 1, P - 1) + fo + 16 * kb) : wh;
+            a = mma3<SPLIT>(wh, wl, fh[kb], fl[kb], a);
+        }
+        return a;
+    };
+#define MC_PBH_CHUNK(seq, KEEP)                                                                             \
+    {                                                                                                       \
+        const f32x16 a = chunk((seq), xh, xl);                                                              \
+        commit(((seq) & 1) ^ 1);                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + (seq) * 32 + 8 * q + kq);             \
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]}; \
+            if (rok) *reinterpret_cast<f32x4*>(orow + (seq) * 32 + 8 * q) = v;                              \
+            KEEP                                                                                            \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        fetch((seq) + 2);                                                                                   \
+        __syncthreads();                                                                                    \
+    }
+#pragma unroll
+    for (int c = 0; c < NKEEP; ++c) MC_PBH_CHUNK(c, bvf[4 * c + q] = v;)
+    for (int c = NKEEP; c < NC0; ++c) MC_PBH_CHUNK(c, )
+#undef MC_PBH_CHUNK
+    frag_layernorm_h<NJ>(bvf, g.gamma, g.beta, kq);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) split8(bvf[2 * kb], bvf[2 * kb + 1], bh[kb], bl[kb]);
+    auto qkv_chunk = [&](int seq, int bias0, float* sl) {
+        const f32x16 a = chunk(seq, bh, bl);
+        if (seq + 1 < NSEQ) commit((seq & 1) ^ 1);
+        float* xr = sl + r * XS + kq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_bias + bias0 + 8 * q + kq);
+            const f32x4 v = {a[4 * q] + bb[0], a[4 * q + 1] + bb[1], a[4 * q + 2] + bb[2], a[4 * q + 3] + bb[3]};
+            *reinterpret_cast<f32x4*>(xr + 8 * q) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (seq + 2 < NSEQ) fetch(seq + 2);
+    };
+    BP bp(g, s_x, s_w, tile_tok0, aliasing, lane, wave);
+#pragma unroll 1
+    for (int cg = 0; cg < NG; ++cg) {
+        const int seq = NC0 + 3 * cg;
+        float* Sq = bp.slot(cg & 1);
+        float* Sk = bp.slot((cg & 1) ^ 1);
+        bp.begin_group();
+        qkv_chunk(seq, 4 * L + cg * 32, Sq);
+        __syncthreads();
+        qkv_chunk(seq + 1, 5 * L + cg * 32, Sk);
+        bp.after_k(Sq);
+        __syncthreads();
+        qkv_chunk(seq + 2, 6 * L + cg * 32, Sq);
+        bp.after_v(Sk);
+        __syncthreads();
+        bp.finish(Sq, cg);
+    }
+}
+
 }  // namespace
 
 int mc_launch_split_f16(const float* x, mc_half* hi, mc_half* lo, long n, hipStream_t s) {
@@ -671,6 +819,20 @@ int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_hal
     }
 #undef MC_MLPH_CASE
 #undef MC_MLPH
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
+                       hipStream_t s) {
+    MC_REQUIRE(g.L == 128 && H == 12, "fp16 pqbody: L=%d H=%d unsupported (128, 12)", g.L, H);
+    MC_REQUIRE(g.Nout == 4 * g.L && g.ldy == 4 * g.L && g.bias && g.bias2 && g.wsm && g.ys && Wph && Wqh && (!split || (Wpl && Wql)),
+               "fp16 pqbody: bad arguments");
+    MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "fp16 pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
+    if (g.N <= g.tok0) return MC_OK;
+    dim3 grid(cdiv((g.N - g.tok0) / H, 128 / H));
+    if (split) hipLaunchKernelGGL((pqbody_h_k<128, 12, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+    else hipLaunchKernelGGL((pqbody_h_k<128, 12, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -575,8 +575,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     // starts on the side stream right after the projection)
     const bool pq_fused = chain_on(c, 2) && chain_on(c, 10) && c->N > c->opt.big_tokens && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0;
     // ... and the body-topology attention too (pqbody_k: frame-aligned tiles, q/k/v never leave the chip): fp32 path, L = 128, 12 parts
-    const bool body_fused = pq_fused && chain_on(c, 15) && L == 128 && H == 12 && g.dyn_heads == 8 &&
-                            !(use_half(c) && w.h_proj.hi && w.h_qkv.hi);
+    const bool body_fused = pq_fused && chain_on(c, 15) && L == 128 && H == 12 && g.dyn_heads == 8;
     if (phase == 2) {
         // (front done elsewhere)
     } else if (chain_on(c, 2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {
@@ -591,7 +590,9 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
             p.pad_row = c->N;      // mf / qkv carry 128 padding rows (mc_ctx_create): projqkv_k's stores are unconditional
             if (body_fused) {
                 p.wsm = w.wsm; p.ys = c->ys;
-                if ((r = mc_launch_pqbody(p, H, s))) return r;
+                if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
+                    if ((r = mc_launch_pqbody_h(p, H, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
+                } else if ((r = mc_launch_pqbody(p, H, s))) return r;
             } else if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
                 if ((r = mc_launch_projqkv_h(p, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
             } else if ((r = mc_launch_projqkv(p, s))) return r;

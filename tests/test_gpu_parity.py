@@ -768,6 +768,45 @@ def test_mixed_text_audio_control_fp16_mfma_50_step_ddim(size):
     nm.close()
 
 
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+def test_fp16_fused_body_kernel_and_plane_gemm_equal_the_separate_kernels(prec):
+    """Reduced-precision contexts, round 4: pqbody_h_k (projqkv_h_k + body-topology attention over frame-aligned tiles) must write the
+    same mf / ys BITS as projqkv_h_k + body_reg_k (same MFMA order per row, same fp32 body arithmetic), and the FiLM GEMM fed from the
+    fp16 planes film_rows_k writes (gemm_hd_k, LDS-DMA) must agree with the in-kernel split of gemm_h_k to fp32 round-off of the
+    accumulation (same fp16 operand values, another k-tile grouping).  0.125b widths, B=3 x 24 frames pushed into the large-batch
+    schedule (big_tokens = 0, half_min_rows = 0)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = FULL
+    nm = NativeModel(dims, W.make_state_dict(dims, 0), cfg_scale=dims['scale'])
+    B, T = 3, 24
+    x, xf, mask = synth_inputs(dims, B, T, seed=5, lengths=[24, 20, 13])
+    DFL = 131063 | (1 << 17)
+    got = {}
+    for tag, chain in (('new', DFL), ('no_fused_body', DFL & ~(1 << 15)), ('no_planes', DFL & ~(1 << 17))):
+        ctx = nm.context(B, T, max_steps=2)
+        ctx.set_option('big_tokens', 0)
+        ctx.set_option('half_min_rows', 0)
+        ctx.set_option('chain', chain)
+        ctx.set_precision(prec)
+        ctx.set_timesteps([800, 30])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out = ctx.denoise(x.cuda(), 1).clone()
+        ctx.denoise(x.cuda(), 0, stop_after_layers=1)
+        torch.cuda.synchronize()
+        got[tag] = (out, ctx.buffer('ys').clone(), ctx.buffer('mf').clone(), ctx.buffer('h').clone())
+        assert ctx.effective_precision == prec
+        ctx.close()
+    for k, name in enumerate(('x0', 'ys layer 0', 'mf layer 0', 'h after layer 0')):
+        assert bool(torch.isfinite(got['new'][k]).all()), name
+        assert torch.equal(got['new'][k], got['no_fused_body'][k]), (name, float((got['new'][k] - got['no_fused_body'][k]).abs().max()))
+    assert torch.equal(got['new'][1], got['no_planes'][1]) and torch.equal(got['new'][2], got['no_planes'][2])
+    e = maxabs(got['new'][3], got['no_planes'][3])
+    print(f'{prec}: FiLM GEMM from fp16 planes vs in-kernel split: |dh| after layer 0 {e:.2e}, |dx0| {maxabs(got["new"][0], got["no_planes"][0]):.2e}')
+    assert e <= 2e-5
+    nm.close()
+
+
 def test_fp16_mfma_large_batch_kernels_single_step_vs_oracle(full_model):
     """The large-batch kernel selection of the reduced-precision mode (N > 65 536 tokens: proj + body LayerNorm + q/k/v in
     one chained fp16-MFMA kernel, two sample groups on two streams, twin dedupe in layer 0): one denoiser call at B=16,
