@@ -51,12 +51,16 @@ def measured_hbm_traffic():
     if not files:
         return None, None
     src = files[-1]
-    m = None
+    m, commit = None, None
     for line in open(src):
         mm = re.match(r'# per denoising step .*= ([0-9.]+) GB', line)
         if mm:
             m = mm
-    return (float(m.group(1)) if m else None), os.path.relpath(src, ROOT)
+        mc_ = re.match(r'# commit (\S+)', line)
+        if mc_:
+            commit = mc_.group(1)
+    # (the file goes stale when kernels change: its header carries the commit it was measured at, printed in the line)
+    return (float(m.group(1)) if m else None), os.path.relpath(src, ROOT) + (f' @ commit {commit}' if commit else '')
 
 DIMS = dict(input_feats=322, max_seq_len=196, L=128, H=12, NL=4, F=512, Te=2048, Dt=256, Nt=77, E=16, topk=2,
             scale=6.5)
