@@ -434,6 +434,50 @@ def main():
         configs4['note'] = ('side measurement, not `value`: median of 3 complete loops after a warm-up loop; gate / routing / normalisations / softmaxes '
                             'stay fp32 in both modes, so the fp16 MFMA ceiling bounds only the GEMM-shaped ~95 % of the FLOPs')
 
+    # ---- BASELINE configs[2] / configs[3] at their per-GPU shares (NOT `value`): the plug-and-play control branch at its real widths,
+    # complete 50-step DDIM loops (one mc_sample_loop call each), exact fp32 MFMA.
+    #   configs[2]  S2G_Beats2_no_face_loss_025b: L=128, 8 base layers + 2 control copies, audio condition of width D (the WavEncoder output,
+    #               encoded once per batch: tools/control_bench.py times it), batch 256 over 8 GPUs = 32 x 196 frames per GPU
+    #   configs[3]  M2D_finedance: L=64, F=256, 4 + 3 layers, 35-d music features, 128 sequences x 5 windows of 120 frames over 4 GPUs = 160 windows
+    control_cfgs = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        from motioncraft_amd.synthetic import control_param_shapes
+        control_cfgs = {}
+        d50c = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                                    model_var_type='fixed_large', respace='15,15,8,6,6'))
+        for key, over, copy, feats, Bc, Tc in (('configs2_s2g', dict(NL=8), 2, DIMS['L'] * DIMS['H'], 32, 196),
+                                               ('configs3_m2d', dict(L=64, F=256), 3, 35, 160, 120)):
+            dm = dict(DIMS, **over)
+            nmc = NativeModel(dm, make_state_dict(dm, 0, shapes=control_param_shapes(dm, copy, feats)), cfg_scale=dm['scale'], device=local_rank)
+            cc = nmc.context(Bc, Tc, max_steps=50)
+            cc.set_timesteps(d50c.timestep_map)
+            cc.set_condition(torch.nn.functional.layer_norm(torch.randn(Bc, dm['Nt'], dm['Dt'], device=dev, generator=gen), (dm['Dt'],)),
+                             torch.ones(Bc, Tc, device=dev))
+            cc.set_control(torch.randn(Bc, Tc, feats, device=dev, generator=gen))
+            kc = [d50c.step_coefs(j, 'ddim', dm['scale'], 0.0) for j in range(49, -1, -1)]
+            xc = torch.randn(Bc, Tc, C, device=dev, generator=gen)
+            tsc = []
+            for rep in range(3):
+                xc.normal_(generator=gen)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                cc.sample_loop(xc, list(range(49, -1, -1)), kc, noise=None, seed=NOISE_KEY, draw0=2 * 10 ** 6 + 50 * rep)
+                torch.cuda.synchronize()
+                tsc.append(time.perf_counter() - t0)
+            assert bool(torch.isfinite(xc).all())
+            tcf = min(tsc[1:])
+            Dm = dm['L'] * dm['H']
+            flc = algorithmic_flops_per_sample_step(dict(dm, NL=dm['NL'] + copy), Tc) + copy * 2 * Tc * 2 * Dm * Dm
+            achc = flc * Bc * 50 / tcf / 1e12
+            control_cfgs[key] = {'batch_per_gpu': Bc, 'frames': Tc, 'layers': f"{dm['NL']}+{copy}", 'latent_dim': dm['L'], 'loop_ms': round(tcf * 1e3, 1),
+                                 'ms_per_step': round(tcf * 20, 3), 'frames_per_s_per_gpu': round(Bc * Tc / tcf, 1),
+                                 'roofline': {'bound': 'mfma', 'achieved': round(achc, 1), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                              'frac': round(achc / PEAK_FP32_MFMA_TFLOPS, 4)}}
+            cc.close()
+            nmc.close()
+        control_cfgs['note'] = ('side measurements, not `value`: per-GPU share of BASELINE configs[2] / configs[3], complete 50-step DDIM loop (best of 2 after a '
+                                'warm-up loop), condition features resident in HBM')
+
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms, t_full or 0.0], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -464,7 +508,7 @@ def main():
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
-                       'full_loop': full_loop, 'reduced_precision_modes': reduced, 'configs0_gpu': configs0, 'configs4': configs4,
+                       'full_loop': full_loop, 'reduced_precision_modes': reduced, 'configs0_gpu': configs0, 'configs4': configs4, 'control_configs': control_cfgs,
                        'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
                        'exact_reductions': 'results equal the unreduced computation (tests/test_gpu_parity.py): CFG twins of base layer 0 '
                                            'share gate / expert / proj / qkv / body work (identical inputs); the last StylizationBlock '
