@@ -1536,6 +1536,49 @@ def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
     nm.close()
 
 
+def test_twin_pairs_split_by_capacity_in_the_large_batch_schedule():
+    """The same degenerate gate in base layer 0 of the 0.125b architecture, pushed into the LARGE-batch schedule (big_tokens = 0): two
+    sample groups on two streams, the twin layer's front as two sample sub-groups (round 4), pqbody_k.  The capacity cut separates
+    first-half tokens from their CFG twins, so the routing raises the split flag: no row may be aliased, the second CFG half runs its
+    own front (pqbody_k reading its twins' expert rows through twin_from) behind the cross-join.  Routing must equal the free-running
+    oracle exactly, the output within the per-call tolerance; beside it the same call with the round-4 schedule bits off."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    dims = FULL
+    sd = W.make_state_dict(dims, 0)
+    pre = 'temporal_decoder_blocks.0.ca_block.motion_moe.model.gates.0.cosine_projector.'
+    sd[pre + 'weight'] = torch.zeros_like(sd[pre + 'weight'])
+    sd[pre + 'bias'] = torch.randn(sd[pre + 'bias'].shape, generator=torch.Generator().manual_seed(11))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    B, T = 3, 24
+    x, xf, mask = synth_inputs(dims, B, T, seed=97, lengths=[24, 20, 9])
+    w = (1 - (1000 - 333) / 1000) * dims['scale'] + 1
+    cap = {}
+    ref = O.denoise(sd, dims, x, 333, xf, mask, cap=cap)                 # free-running oracle
+    free = cap['layer0']['routing']['free']
+    N = 2 * B * T * dims['H']
+    outs = []
+    for chain in (262135, 262135 & ~((1 << 15) | (1 << 16))):
+        ctx = nm.context(B, T, max_steps=1)
+        ctx.set_option('big_tokens', 0)
+        ctx.set_option('chain', chain)
+        ctx.enable_capture()
+        ctx.set_timesteps([333])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out2 = ctx.denoise(x.cuda(), 0)
+        got = out2[:B] * w + out2[B:] * (1 - w)
+        idx, keep = ctx.routing(0)
+        assert torch.equal(idx, torch.stack(free['indices'], 1)) and torch.equal(keep, torch.stack(free['keeps'], 1))
+        assert bool(keep[:N // 2, 0].any()) and not bool(keep[N // 2:, 0].any())     # twins split by the capacity cut
+        err = maxabs(got, ref)
+        print(f'chain {chain}: twins split in the large-batch schedule: |hip - oracle| {err:.2e}')
+        assert err <= TOL_STEP
+        outs.append(got.clone())
+        ctx.close()
+    assert torch.equal(outs[0], outs[1])
+    nm.close()
+
+
 @pytest.mark.parametrize('regime,B', [('random_scores', 3), ('exact_ties', 3), ('tiny_capacity', 3), ('reverse_ties', 3),
                                       ('random_scores', 9), ('tiny_capacity', 9), ('exact_ties', 9)])
 def test_register_routing_kernel_equals_the_streaming_form(regime, B, monkeypatch):
