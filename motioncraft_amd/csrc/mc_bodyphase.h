@@ -24,15 +24,40 @@ struct BodySet {
     bool on;       // the frame exists (inside the tile, inside the range, not aliased)
 };
 
+// Lane-to-lane reads inside one dynamic head of HD = L / 8 lanes.  HD = 16: the head is one DPP row, read by rotation (row_ror:s).
+// HD = 8: two heads share a DPP row, so the head is walked by XOR: lane i reads lane i ^ s -- s = 1..3 are quad permutations, and
+// i ^ 4 .. i ^ 7 are the same permutations of the half-mirrored value (row_half_mirror: i -> i ^ 7 inside 8 lanes), which the caller
+// forms once per register (xm).  Either way  A_[s] = sum_h read_s(k[h]) v[h]  holds A[d = src_s(lane)][lane], and q read through the
+// SAME map pairs up again in  y[h][lane] = sum_s read_s(q[h]) A_[s]: no lane needs to know d.
+template <int HD, int S>
+__device__ __forceinline__ float head_read(float x, float xm) {
+    if constexpr (HD == 16) return row_ror<S>(x);
+    else {
+        static_assert(HD == 8 && S < 8, "head_read: HD 16 or 8");
+        if constexpr (S == 0) return x;
+        else if constexpr (S == 1) return dpp_read<0xB1>(x);     // quad_perm [1,0,3,2]: i ^ 1
+        else if constexpr (S == 2) return dpp_read<0x4E>(x);     // quad_perm [2,3,0,1]: i ^ 2
+        else if constexpr (S == 3) return dpp_read<0x1B>(x);     // quad_perm [3,2,1,0]: i ^ 3
+        else if constexpr (S == 4) return dpp_read<0x1B>(xm);    // (i ^ 3) ^ 7
+        else if constexpr (S == 5) return dpp_read<0x4E>(xm);
+        else if constexpr (S == 6) return dpp_read<0xB1>(xm);
+        else return xm;                                          // i ^ 7
+    }
+}
+template <class F, int... S>
+__device__ __forceinline__ void static_for_n(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
+
 template <int L, int H>
 struct BodyPhase {
-    static_assert(L == 128, "BodyPhase: one dynamic head (16 channels) = one DPP row");
+    static constexpr int HD = L / 8;                       // channels per dynamic head (8 heads)
+    static_assert(HD == 16 || HD == 8, "BodyPhase: L = 128 (one head = one DPP row) or L = 64 (two heads per row)");
     static_assert(H % 4 == 0, "BodyPhase: the odd pass is cut 4 ways by parts");
     static constexpr int FR = 128 / H, TR = FR * H;        // frames / token rows of a tile
     static constexpr int NPASS = (FR + 1) / 2;             // wave passes (2 frames x 32 channels per pass)
     static_assert(NPASS <= 5, "BodyPhase: 4 full passes + one cut pass");
     static constexpr int XS = 36;                          // slot row stride in floats (b128 fragment writes conflict-free)
-    static constexpr int LDS_FLOATS = 2 * 128 * XS + H * H;   // two slots + softmax(body_weight)
+    static constexpr int SROWS = 128;                      // rows of a slot (120-row slots for pqbody_k<64>, 54.3 KB: no faster, M2D 18.40 either way)
+    static constexpr int LDS_FLOATS = 2 * SROWS * XS + H * H;   // two slots + softmax(body_weight)
 
     const RowChainArgs& g;
     float* s_x;            // two exchange slots
@@ -46,7 +71,7 @@ struct BodyPhase {
     __device__ __forceinline__ BodyPhase(const RowChainArgs& g_, float* s_x_, const float* s_w_, long tile_tok0_, bool aliasing_, int lane_, int wave_)
         : g(g_), s_x(s_x_), s_w(s_w_), tile_tok0(tile_tok0_), aliasing(aliasing_), lane(lane_), wave(wave_), cc(lane_ & 31) {}
 
-    __device__ __forceinline__ float* slot(int i) const { return s_x + i * 128 * XS; }
+    __device__ __forceinline__ float* slot(int i) const { return s_x + i * SROWS * XS; }
 
     template <class B>
     __device__ __forceinline__ void set_init(B& b, int pass, int h0) {
@@ -68,9 +93,9 @@ struct BodyPhase {
         for (int h = 0; h < NQ; ++h) b.q[h] = x[h * XS];
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {
-            const float m = group_max(b.q[h], 16);
+            const float m = group_max(b.q[h], HD);
             const float e = fast_exp2((b.q[h] - m) * LOG2E);
-            b.q[h] = e * __frcp_rn(group_sum(e, 16));
+            b.q[h] = e * __frcp_rn(group_sum(e, HD));
         }
     }
     template <class B>
@@ -101,14 +126,17 @@ struct BodyPhase {
         for (int h = 0; h < H; ++h) bv[h] = bvp[h * g.ldy];
 #pragma unroll
         for (int h = 0; h < H; ++h) v[h] = x[h * XS];
-        float A_[16];
+        float A_[HD];
+        float km[H];                                   // HD = 8: the half-mirrored keys (head_read)
+#pragma unroll
+        for (int h = 0; h < H; ++h) km[h] = HD == 8 ? dpp_read<0x141>(b.k[h]) : 0.f;
         auto contract_kv = [&](auto S) {
             float a = 0.f;
 #pragma unroll
-            for (int h = 0; h < H; ++h) a += row_ror<decltype(S)::value>(b.k[h]) * v[h];
+            for (int h = 0; h < H; ++h) a += head_read<HD, decltype(S)::value>(b.k[h], km[h]) * v[h];
             A_[decltype(S)::value] = a;
         };
-        static_for_16(contract_kv);
+        static_for_n(contract_kv, std::make_integer_sequence<int, HD>{});
         float* out = g.ys + (t0 / H) * (long)(H * L) + cg * 32 + cc;
         if constexpr (NQ == H) {
 #pragma unroll
@@ -117,8 +145,9 @@ struct BodyPhase {
 #pragma unroll
                 for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
                 float dy = 0.f;
-                auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(b.q[h]) * A_[decltype(S)::value]; };
-                static_for_16(contract_qa);
+                const float qm = HD == 8 ? dpp_read<0x141>(b.q[h]) : 0.f;
+                auto contract_qa = [&](auto S) { dy += head_read<HD, decltype(S)::value>(b.q[h], qm) * A_[decltype(S)::value]; };
+                static_for_n(contract_qa, std::make_integer_sequence<int, HD>{});
                 out[h * L] = st + (bv[h] + dy);
             }
         } else {
@@ -129,8 +158,9 @@ struct BodyPhase {
 #pragma unroll
                 for (int j = 0; j < H; ++j) st += s_w[h * H + j] * bv[j];
                 float dy = 0.f;
-                auto contract_qa = [&](auto S) { dy += row_ror<decltype(S)::value>(b.q[hq]) * A_[decltype(S)::value]; };
-                static_for_16(contract_qa);
+                const float qm = HD == 8 ? dpp_read<0x141>(b.q[hq]) : 0.f;
+                auto contract_qa = [&](auto S) { dy += head_read<HD, decltype(S)::value>(b.q[hq], qm) * A_[decltype(S)::value]; };
+                static_for_n(contract_qa, std::make_integer_sequence<int, HD>{});
                 float bvh = bv[0];                     // bv[h] for a runtime (wave-uniform) h without indexing the register array
 #pragma unroll
                 for (int j = 1; j < H; ++j) bvh = j == h ? bv[j] : bvh;

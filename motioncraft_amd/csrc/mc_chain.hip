@@ -744,7 +744,6 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
 // every wave rebuilds A = k^T v of the two odd frames and projects H / 4 of their query rows)
 template <int L, int H>
 __global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
-    static_assert(L == 128, "pqbody_k: the body phase maps one dynamic head (16 channels) onto one DPP row");
     constexpr int NJ = L / 8, NC0 = 4 * L / 32, NG = L / 32, NKEEP = L / 32, NSEQ = NC0 + 3 * NG;
     using BP = BodyPhase<L, H>;
     constexpr int TR = BP::TR, XS = BP::XS;         // token rows of a tile, exchange slot row stride
@@ -753,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
     auto Ws = [&](int b) { return smem + b * 32 * SP::LDS_LD; };
     float* s_bias = smem + 2 * 32 * SP::LDS_LD;      // proj bias [4L] | qkv bias [3L]
     float* s_x = s_bias + 7 * L;                     // two exchange slots [128][XS]
-    float* s_w = s_x + 2 * 128 * XS;                 // softmax(body_weight) [H][H]
+    float* s_w = s_x + 2 * BP::SROWS * XS;           // softmax(body_weight) [H][H]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
     for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
@@ -859,14 +858,15 @@ __global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
 }
 
 int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s) {
-    MC_REQUIRE(g.L == 128 && H == 12, "pqbody: L=%d H=%d unsupported (128, 12)", g.L, H);
+    MC_REQUIRE((g.L == 128 || g.L == 64) && H == 12, "pqbody: L=%d H=%d unsupported (128 / 64, 12)", g.L, H);
     MC_REQUIRE(g.Nout == 4 * g.L && g.ldy == 4 * g.L && g.W2 && g.bias2 && g.wsm && g.ys, "pqbody: bad arguments");
     MC_REQUIRE(g.pad_row >= g.N, "pqbody: pad_row (128 padding rows of Y behind the last token) not set");
     MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
     if (g.N <= g.tok0) return MC_OK;
     const long frames = (g.N - g.tok0) / H;
     dim3 grid(cdiv(frames, 128 / H));
-    hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, g);
+    if (g.L == 128) hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((pqbody_k<64, 12>), grid, dim3(256), 0, s, g);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

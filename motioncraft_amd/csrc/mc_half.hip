@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g, const mc_ha
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * P * S1 + 2 * 7 * L + 2 * BP::LDS_FLOATS];
     float* s_bias = reinterpret_cast<float*>(smem + 2 * P * S1);      // proj bias [4L] | qkv bias [3L]
     float* s_x = s_bias + 7 * L;
-    float* s_w = s_x + 2 * 128 * XS;
+    float* s_w = s_x + 2 * BP::SROWS * XS;
     auto Ws = [&](int b, int p) { return smem + (b * P + p) * S1; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, kq = hf * 4;
     for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];

@@ -1536,6 +1536,36 @@ def test_exact_score_ties_and_twin_pairs_split_by_capacity(which):
     nm.close()
 
 
+def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
+    """pqbody_k<64> (the M2D width: 8 dynamic heads of 8 channels, two heads per DPP row, the head walked by XOR reads instead of row
+    rotations) against projqkv_k<64> + body_reg_k<8>: mf the same bits, ys within fp32 round-off (the contraction over the head's 8
+    channels is summed in another order than body_reg_k's ascending-d loop).  L = 64 architecture at a small batch in the large-batch
+    schedule, ragged tiles, twin aliasing on (layer 1 snapshot) and off (stop_after_layers = 1)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = W.default_dims(L=64, F=256, max_seq_len=24)
+    nm = NativeModel(dims, W.make_state_dict(dims, 3), cfg_scale=dims['scale'])
+    B, T = 3, 24
+    x, xf, mask = synth_inputs(dims, B, T, seed=6, lengths=[24, 18, 11])
+    got = {}
+    for tag, chain in (('fused', 262135), ('separate', 262135 & ~(1 << 15))):
+        ctx = nm.context(B, T, max_steps=1)
+        ctx.set_option('big_tokens', 0)
+        ctx.set_option('chain', chain)
+        ctx.set_timesteps([700])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out = ctx.denoise(x.cuda(), 0).clone()
+        ctx.denoise(x.cuda(), 0, stop_after_layers=1)
+        torch.cuda.synchronize()
+        got[tag] = (out, ctx.buffer('ys').clone(), ctx.buffer('mf').clone())
+        ctx.close()
+    assert torch.equal(got['fused'][2], got['separate'][2])
+    e_ys, e_out = maxabs(got['fused'][1], got['separate'][1]), maxabs(got['fused'][0], got['separate'][0])
+    print(f'L = 64: |ys fused - separate| {e_ys:.2e} (|ys| max {float(got["separate"][1].abs().max()):.2f}), |x0| {e_out:.2e}')
+    assert bool(torch.isfinite(got['fused'][0]).all()) and e_ys <= 1e-5 and e_out <= 1e-4
+    nm.close()
+
+
 def test_twin_pairs_split_by_capacity_in_the_large_batch_schedule():
     """The same degenerate gate in base layer 0 of the 0.125b architecture, pushed into the LARGE-batch schedule (big_tokens = 0): two
     sample groups on two streams, the twin layer's front as two sample sub-groups (round 4), pqbody_k.  The capacity cut separates
