@@ -825,14 +825,19 @@ int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_hal
 
 int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
                        hipStream_t s) {
-    MC_REQUIRE(g.L == 128 && H == 12, "fp16 pqbody: L=%d H=%d unsupported (128, 12)", g.L, H);
+    MC_REQUIRE((g.L == 128 || g.L == 64) && H == 12, "fp16 pqbody: L=%d H=%d unsupported (128 / 64, 12)", g.L, H);
     MC_REQUIRE(g.Nout == 4 * g.L && g.ldy == 4 * g.L && g.bias && g.bias2 && g.wsm && g.ys && Wph && Wqh && (!split || (Wpl && Wql)),
                "fp16 pqbody: bad arguments");
     MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "fp16 pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv((g.N - g.tok0) / H, 128 / H));
-    if (split) hipLaunchKernelGGL((pqbody_h_k<128, 12, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
-    else hipLaunchKernelGGL((pqbody_h_k<128, 12, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+    if (g.L == 128) {
+        if (split) hipLaunchKernelGGL((pqbody_h_k<128, 12, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+        else hipLaunchKernelGGL((pqbody_h_k<128, 12, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+    } else {
+        if (split) hipLaunchKernelGGL((pqbody_h_k<64, 12, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+        else hipLaunchKernelGGL((pqbody_h_k<64, 12, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+    }
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -575,8 +575,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     // starts on the side stream right after the projection)
     const bool pq_fused = chain_on(c, 2) && chain_on(c, 10) && c->N > c->opt.big_tokens && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0;
     // ... and the body-topology attention too (pqbody_k: frame-aligned tiles, q/k/v never leave the chip): fp32 path, L = 128, 12 parts
-    const bool half_pq = use_half(c) && w.h_proj.hi && w.h_qkv.hi;
-    const bool body_fused = pq_fused && chain_on(c, 15) && H == 12 && g.dyn_heads == 8 && (L == 128 || (L == 64 && !half_pq));
+    const bool body_fused = pq_fused && chain_on(c, 15) && H == 12 && g.dyn_heads == 8 && (L == 128 || L == 64);
     if (phase == 2) {
         // (front done elsewhere)
     } else if (chain_on(c, 2) && mc_mlp_supported(L, 32) && (4 * L) % 32 == 0) {

@@ -1563,6 +1563,25 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
     e_ys, e_out = maxabs(got['fused'][1], got['separate'][1]), maxabs(got['fused'][0], got['separate'][0])
     print(f'L = 64: |ys fused - separate| {e_ys:.2e} (|ys| max {float(got["separate"][1].abs().max()):.2f}), |x0| {e_out:.2e}')
     assert bool(torch.isfinite(got['fused'][0]).all()) and e_ys <= 1e-5 and e_out <= 1e-4
+    # the fp16-MFMA twin (pqbody_h_k<64>) against projqkv_h_k<64> + body_reg_k<8> in the split mode
+    hgot = {}
+    for tag, chain in (('fused', 262135), ('separate', 262135 & ~(1 << 15))):
+        ctx = nm.context(B, T, max_steps=1)
+        ctx.set_option('big_tokens', 0)
+        ctx.set_option('half_min_rows', 0)
+        ctx.set_option('chain', chain)
+        ctx.set_precision('f16x3')
+        ctx.set_timesteps([700])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out = ctx.denoise(x.cuda(), 0).clone()
+        ctx.denoise(x.cuda(), 0, stop_after_layers=1)
+        torch.cuda.synchronize()
+        hgot[tag] = (out, ctx.buffer('ys').clone(), ctx.buffer('mf').clone())
+        ctx.close()
+    assert torch.equal(hgot['fused'][2], hgot['separate'][2])
+    e_ys, e_out = maxabs(hgot['fused'][1], hgot['separate'][1]), maxabs(hgot['fused'][0], hgot['separate'][0])
+    print(f'L = 64, f16x3: |ys fused - separate| {e_ys:.2e}, |x0| {e_out:.2e}; |x0 f16x3 - x0 f32| {maxabs(hgot["fused"][0], got["fused"][0]):.2e}')
+    assert e_ys <= 1e-5 and e_out <= 1e-4 and maxabs(hgot['fused'][0], got['fused'][0]) <= 2e-4
     nm.close()
 
 
