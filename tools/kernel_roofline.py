@@ -18,6 +18,8 @@ FLOPS = {
     ('mlp2_k<128, 0>', None): 2.0 * N * 2 * (L * 4 * L) * 2,            # top-2: two experts per token, FC1 + FC2
     ('mlp2_k<128, 1>', None): 2.0 * N * (L * F) * 2,
     ('projqkv_k<128>', None): 2.0 * N * (L * 4 * L + L * 3 * L),
+    ('pqbody_k<128, 12>', None): 2.0 * N * (L * 4 * L + L * 3 * L) + 2.0 * rows * (2 * H * H * L + 8 * 2 * H * (L // 8) ** 2 * 2),      # + static and dynamic body topology
+    ('gemm_small16_k<3, false>', None): 2.0 * (B * T) * 322 * D * 2,
     ('temporal_k<128, false>', None): 2.0 * B * H * ((Nt + T) * L * L + T * L * L) * 2,
     ('gate_k<128>', 602112): 2.0 * N * (L * 256 + 256 * E),
     ('gemm_small_k<false>', None): 2.0 * (B * T) * 322 * D * 2,
@@ -56,7 +58,7 @@ def parse_hbm(path):
 
 pmc = parse_pmc(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma_busy.txt'))
 hbm = parse_hbm(os.path.join(ROOT, 'profiles', f'{tag}_pmc_hbm_traffic.txt'))
-print(f'# tools/kernel_roofline.py {tag}: B=64 step, serial single-stream schedule (MC_CHAIN=3479 PMC pass: profiles/{tag}_pmc_mfma_busy.txt), HBM bytes per launch of the')
+print(f'# tools/kernel_roofline.py {tag}: B=64 step, serial single-stream schedule (single-stream chain mask, PMC pass: profiles/{tag}_pmc_mfma_busy.txt), HBM bytes per launch of the')
 print(f'# default two-stream schedule (half-batch launches: profiles/{tag}_pmc_hbm_traffic.txt).  GFLOP = algorithmic work of one full-batch launch as the reference')
 print('# performs it (layer 0 launches do half of it: twin dedupe); peak 157.3 TFLOP/s fp32 MFMA at 2.4 GHz, HBM 8 TB/s.')
 print(f'{"kernel":28s} {"grid":>9s} {"calls":>5s} {"us":>8s} {"GFLOP":>8s} {"TFLOP/s":>8s} {"%peak":>6s} {"MfmaUtil":>8s} {"GHz":>6s} {"MB/launch (2-stream)":>22s}')
