@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void gemm_small16_k(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[SRING * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = (g.N + NB - 1) / NB;
-    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn, grp = blockIdx.y;
+    const int bid = (g.tune & 256) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;      // (XCD-aware tile order: see gemm_small_k)
+    const int tm = bid / ntn, tn = bid % ntn, grp = blockIdx.y;
     const int row0 = tm * SM;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int dr = lane >> 3, dc = ((lane & 7) ^ dr) * 4;
@@ -854,11 +855,11 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
     const bool vec16 = vec && g.N % nb == 0;       // the float4 epilogue has no column guard
     if (nb == 48) {
-        if (vec16) hipLaunchKernelGGL((gemm_small16_k<3, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_small16_k<3, false>), grid, dim3(256), 0, stream, g);
+        if (vec16) hipLaunchKernelGGL((gemm_small16_k<3, true>), grid, dim3(256), 0, stream, gg);
+        else hipLaunchKernelGGL((gemm_small16_k<3, false>), grid, dim3(256), 0, stream, gg);
     } else if (nb == 96) {
-        if (vec16) hipLaunchKernelGGL((gemm_small16_k<6, true>), grid, dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_small16_k<6, false>), grid, dim3(256), 0, stream, g);
+        if (vec16) hipLaunchKernelGGL((gemm_small16_k<6, true>), grid, dim3(256), 0, stream, gg);
+        else hipLaunchKernelGGL((gemm_small16_k<6, false>), grid, dim3(256), 0, stream, gg);
     } else {
         if (vec) hipLaunchKernelGGL(gemm_small_k<true>, grid, dim3(256), 0, stream, gg);
         else hipLaunchKernelGGL(gemm_small_k<false>, grid, dim3(256), 0, stream, gg);
