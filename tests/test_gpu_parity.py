@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+DEFAULT_CHAIN = 262135        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
+
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
 
@@ -601,12 +603,12 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [131056, 131063])
+@pytest.mark.parametrize('chain', [262135 & ~7, 262135])
 def test_generic_fallback_path_vs_oracle(chain):
-    """chain mask with bits 0-2 cleared (131056): the generic path -- plain gemm_k launches + row kernels instead of the fused
+    """chain mask with bits 0-2 cleared: the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
     is outside the fused kernels' range, so it keeps its own parity test: small-config denoiser call + 3 DDPM steps vs the CPU
-    oracle, beside the default mask (131063) on the same inputs.  The mask is a per-context option (mc_ctx_set_option): both
+    oracle, beside the default mask on the same inputs.  The mask is a per-context option (mc_ctx_set_option): both
     contexts live in this one process."""
     from motioncraft_amd.diffusion import build_diffusion
     from motioncraft_amd.engine import NativeModel
@@ -654,7 +656,7 @@ def test_fused_proj_qkv_body_kernel_is_bit_identical_to_the_separate_kernels():
     B, T = 3, 24
     x, xf, mask = synth_inputs(dims, B, T, seed=5, lengths=[24, 20, 13])
     got = {}
-    DFL = 131063                                               # the default mask (McOptions::chain)
+    DFL = DEFAULT_CHAIN
     for tag, chain in (('fused', DFL), ('separate', DFL & ~(1 << 15)), ('fused_one_stream', DFL & ~(1 << 5)),
                        ('separate_one_stream', DFL & ~((1 << 15) | (1 << 5))), ('fused_no_twin_split', DFL & ~(1 << 16))):
         ctx = nm.context(B, T, max_steps=2)
@@ -781,7 +783,7 @@ def test_fp16_fused_body_kernel_and_plane_gemm_equal_the_separate_kernels(prec):
     nm = NativeModel(dims, W.make_state_dict(dims, 0), cfg_scale=dims['scale'])
     B, T = 3, 24
     x, xf, mask = synth_inputs(dims, B, T, seed=5, lengths=[24, 20, 13])
-    DFL = 131063 | (1 << 17)
+    DFL = DEFAULT_CHAIN
     got = {}
     for tag, chain in (('new', DFL), ('no_fused_body', DFL & ~(1 << 15)), ('no_planes', DFL & ~(1 << 17))):
         ctx = nm.context(B, T, max_steps=2)
@@ -1548,7 +1550,7 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
     B, T = 3, 24
     x, xf, mask = synth_inputs(dims, B, T, seed=6, lengths=[24, 18, 11])
     got = {}
-    for tag, chain in (('fused', 262135), ('separate', 262135 & ~(1 << 15))):
+    for tag, chain in (('fused', DEFAULT_CHAIN), ('separate', DEFAULT_CHAIN & ~(1 << 15))):
         ctx = nm.context(B, T, max_steps=1)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('chain', chain)
@@ -1565,7 +1567,7 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
     assert bool(torch.isfinite(got['fused'][0]).all()) and e_ys <= 1e-5 and e_out <= 1e-4
     # the fp16-MFMA twin (pqbody_h_k<64>) against projqkv_h_k<64> + body_reg_k<8> in the split mode
     hgot = {}
-    for tag, chain in (('fused', 262135), ('separate', 262135 & ~(1 << 15))):
+    for tag, chain in (('fused', DEFAULT_CHAIN), ('separate', DEFAULT_CHAIN & ~(1 << 15))):
         ctx = nm.context(B, T, max_steps=1)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('half_min_rows', 0)
@@ -1607,7 +1609,7 @@ def test_twin_pairs_split_by_capacity_in_the_large_batch_schedule():
     free = cap['layer0']['routing']['free']
     N = 2 * B * T * dims['H']
     outs = []
-    for chain in (262135, 262135 & ~((1 << 15) | (1 << 16))):
+    for chain in (DEFAULT_CHAIN, DEFAULT_CHAIN & ~((1 << 15) | (1 << 16))):
         ctx = nm.context(B, T, max_steps=1)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('chain', chain)
