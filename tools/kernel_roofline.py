@@ -12,13 +12,17 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 B, T, H, L, F, E, Nt, D = 64, 196, 12, 128, 512, 16, 77, 1536
 N = 2 * B * T * H                    # tokens of the CFG-doubled batch
 rows = 2 * B * T
-# algorithmic GFLOP of ONE full-batch launch (multiply-add = 2); None: not an MFMA kernel (HBM-bound)
+# algorithmic GFLOP of the AVERAGE launch of the serial schedule (multiply-add = 2); None: not an MFMA kernel (HBM-bound).  Kernels whose
+# launches differ in work but not in grid are averaged over one step (an average duration against the full-batch FLOPs
+# overstated them): the persistent gemm_wp_k runs 7 FiLM GEMMs + the pose-encoder GEMM (K = 352) per step; base layer 0 launches gate-less
+# half of the expert / proj work (CFG twin dedupe), so those kernels average 3.5 / 4 of a full launch.
+TWIN = 3.5 / 4
 FLOPS = {
-    ('gemm_wp_k', 131072): 2.0 * rows * D * D,
-    ('mlp2_k<128, 0>', None): 2.0 * N * 2 * (L * 4 * L) * 2,            # top-2: two experts per token, FC1 + FC2
+    ('gemm_wp_k', 131072): (7 * 2.0 * rows * D * D + 2.0 * (B * T) * 352 * D) / 8,
+    ('mlp2_k<128, 0>', None): TWIN * 2.0 * N * 2 * (L * 4 * L) * 2,            # top-2: two experts per token, FC1 + FC2
     ('mlp2_k<128, 1>', None): 2.0 * N * (L * F) * 2,
     ('projqkv_k<128>', None): 2.0 * N * (L * 4 * L + L * 3 * L),
-    ('pqbody_k<128, 12>', None): 2.0 * N * (L * 4 * L + L * 3 * L) + 2.0 * rows * (2 * H * H * L + 8 * 2 * H * (L // 8) ** 2 * 2),      # + static and dynamic body topology
+    ('pqbody_k<128, 12>', None): TWIN * (2.0 * N * (L * 4 * L + L * 3 * L) + 2.0 * rows * (2 * H * H * L + 8 * 2 * H * (L // 8) ** 2 * 2)),      # + static and dynamic body topology
     ('gemm_small16_k<3, false>', None): 2.0 * (B * T) * 322 * D * 2,
     ('temporal_k<128, false>', None): 2.0 * B * H * ((Nt + T) * L * L + T * L * L) * 2,
     ('gate_k<128>', 602112): 2.0 * N * (L * 256 + 256 * E),
@@ -59,8 +63,8 @@ def parse_hbm(path):
 pmc = parse_pmc(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma_busy.txt'))
 hbm = parse_hbm(os.path.join(ROOT, 'profiles', f'{tag}_pmc_hbm_traffic.txt'))
 print(f'# tools/kernel_roofline.py {tag}: B=64 step, serial single-stream schedule (single-stream chain mask, PMC pass: profiles/{tag}_pmc_mfma_busy.txt), HBM bytes per launch of the')
-print(f'# default two-stream schedule (half-batch launches: profiles/{tag}_pmc_hbm_traffic.txt).  GFLOP = algorithmic work of one full-batch launch as the reference')
-print('# performs it (layer 0 launches do half of it: twin dedupe); peak 157.3 TFLOP/s fp32 MFMA at 2.4 GHz, HBM 8 TB/s.')
+print(f'# default two-stream schedule (half-batch launches: profiles/{tag}_pmc_hbm_traffic.txt).  GFLOP = algorithmic work of the AVERAGE launch of a step as the reference')
+print('# performs it (layer-0 launches of the expert / proj kernels do half: twin dedupe; gemm_wp_k: 7 FiLM GEMMs + the encoder); peak 157.3 TFLOP/s fp32 MFMA at 2.4 GHz, HBM 8 TB/s.')
 print(f'{"kernel":28s} {"grid":>9s} {"calls":>5s} {"us":>8s} {"GFLOP":>8s} {"TFLOP/s":>8s} {"%peak":>6s} {"MfmaUtil":>8s} {"GHz":>6s} {"MB/launch (2-stream)":>22s}')
 for r in pmc:
     if r['us'] < 10 or 'rocclr' in r['name'] or r['name'].startswith('at::'):
