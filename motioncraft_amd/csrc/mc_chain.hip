@@ -240,6 +240,144 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
         }
 }
 
+// =================================================================================================
+// mlp2d_k: mlp2_k<128, MODE> with the weight chunks staged by LDS-DMA (global_load_lds_dwordx4) instead of registers + ds_write.
+// Per chunk every thread of mlp2_k issues 8 global loads, waits for them, and writes 8 x 16 bytes into LDS; here a wave issues 8 DMAs
+// and nothing else (no staging registers, no store instructions, no compiler-placed wait in the MFMA stream).  DMA writes lane-linear,
+// so the LDS images are unpadded and XOR-swizzled instead of padded:
+//   W1 chunk [32 hidden rows][128 floats]: 16-byte chunk c of row r sits at position (c & 16) | ((c & 15) ^ (r & 15))   (512-byte rows:
+//            the 16 rows of a b128 lane group hit 16 different slots of the 256-byte bank row)
+//   W2 chunk [128 out rows][32 floats]:    chunk c of row r at position c ^ ((r >> 1) & 7)   (128-byte rows: row parity picks the half of
+//            the bank row, (r >> 1) & 7 the slot -- conflict-free for the b128 lane groups {0-3, 12-15, 20-27})
+// Same MFMA order and operands as mlp2_k: the same bits.
+// =================================================================================================
+__device__ __forceinline__ void dma16c(unsigned voff, const float* sbase, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void mlp2d_k(MlpArgs g) {
+    constexpr int L = 128, NJ = L / 8, NT = L / 32, HC = 32;
+    constexpr int C1 = HC * L, C2 = L * HC, BUFSZ = C1 + C2, MAXHID = 1024;      // floats
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUFSZ + MAXHID];
+    float* s_b1 = smem + 2 * BUFSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int grp, row0, nrows;
+    if constexpr (MODE == MLP_EXPERT) {
+        const int real = *g.num_tiles;
+        const int bt = (int)blockIdx.x;
+        if (bt >= real) return;
+        const int t = xcd_remap(bt, real);
+        grp = g.tile_group[t];
+        row0 = g.tile_row0[t];
+        nrows = g.tile_nrows[t];
+    } else {
+        grp = blockIdx.y;
+        row0 = blockIdx.x * 128;
+        nrows = min(128, g.M - row0);
+    }
+    const int grp_u = __builtin_amdgcn_readfirstlane(grp);
+    const float* __restrict__ W1 = g.W1 + (long)grp_u * g.hidden * L;
+    const float* __restrict__ W2t = g.W2t + (long)grp_u * L * g.hidden;
+    const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
+    const float* __restrict__ b2 = g.b2 + (long)grp * L;
+    for (int i = tid; i < g.hidden; i += 256) s_b1[i] = b1[i];
+    // DMA byte offsets of this lane (4 pieces per matrix and wave)
+    //   W1: piece q = 2 rows: row 2 (4 wave + q) + (lane >> 5), LDS position lane & 31 <- logical chunk (p & 16) | ((p & 15) ^ (row & 15))
+    //   W2: piece q = 8 rows: row 8 (4 wave + q) + (lane >> 3), LDS position lane & 7  <- logical chunk p ^ ((row >> 1) & 7)
+    unsigned vo1[4], vo2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r1 = 2 * (4 * wave + q) + (lane >> 5), p1 = lane & 31;
+        vo1[q] = (unsigned)((r1 * L + ((p1 & 16) | ((p1 & 15) ^ (r1 & 15))) * 4) * 4);
+        const int r2 = 8 * (4 * wave + q) + (lane >> 3), p2 = lane & 7;
+        vo2[q] = (unsigned)(((long)r2 * g.hidden + (p2 ^ ((r2 >> 1) & 7)) * 4) * 4);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto issue = [&](int hc) {
+        const unsigned l1 = lds0 + (unsigned)((hc & 1) * BUFSZ * 4) + (unsigned)(4 * wave_u) * 1024;
+        const unsigned l2 = l1 + C1 * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dma16c(vo1[q], W1 + (long)hc * HC * L, l1 + q * 1024);
+            dma16c(vo2[q], W2t + hc * HC, l2 + q * 1024);
+        }
+    };
+    const int r = wave * 32 + (lane & 31);
+    const bool rok = r < nrows;
+    const int hf = lane >> 5, kq = hf * 4;
+    f32x4 xf[NJ];
+    {
+        long srow = rok ? row0 + r : row0;
+        if constexpr (MODE == MLP_EXPERT) srow = rok ? g.src_row[row0 + r] : 0;
+        const float* xp = g.X + (long)grp * g.x_gstride + srow * g.ldx + kq;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xp + 8 * j);
+    }
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[t][q] = 0.f;
+    const int nch = g.hidden / HC;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int fr = lane & 31, s1x = fr & 15, s2x = (fr >> 1) & 7;
+    for (int hc = 0; hc < nch; ++hc) {
+        if (hc + 1 < nch) issue(hc + 1);          // the other buffer: last read in iteration hc - 1, behind the barrier every wave has passed
+        const float* W1c = smem + (hc & 1) * BUFSZ + fr * L;
+        const float* W2c = smem + (hc & 1) * BUFSZ + C1;
+        // FC1 chunk: one dependent accumulator chain over the 16 k-groups (chunk_mma<NJ, 1>'s order), fragments one k-group ahead
+        f32x16 a1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+        auto w1frag = [&](int j) { return *reinterpret_cast<const f32x4*>(W1c + (((2 * j + hf) & 16) | (((2 * j + hf) & 15) ^ s1x)) * 4); };
+        f32x4 w = w1frag(0), wn;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j + 1 < NJ) wn = w1frag(j + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], xf[j][i], a1, 0, 0, 0);
+            w = wn;
+        }
+        f32x4 hfr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + hc * HC + 8 * q + kq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hfr[q][i] = gelu_exact(a1[4 * q + i] + bb[i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(W2c + (t * 32 + fr) * HC + (((2 * q + hf) ^ s2x) * 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[i], hfr[q][i], acc2[t], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of chunk hc + 1 have landed
+        __syncthreads();
+    }
+    if (!rok) return;
+    long drow = row0 + r;
+    if constexpr (MODE == MLP_EXPERT) drow = g.dst_row[row0 + r];
+    float* yrow = g.Y + (long)grp * g.y_gstride + drow * g.ldy;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = t * 32 + 8 * q + kq;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + n);
+            f32x4 v = {acc2[t][4 * q] + bb[0], acc2[t][4 * q + 1] + bb[1], acc2[t][4 * q + 2] + bb[2], acc2[t][4 * q + 3] + bb[3]};
+            *reinterpret_cast<f32x4*>(yrow + n) = v;
+        }
+}
+
 // The gate's per-token finish on fragment-distributed logits: lane l and lane l ^ 32 hold the two halves of token (l & 31)
 // (this lane: experts e(r) = (r & 3) + 8 (r >> 2) + 4 hf, r = 0..7); ss = this lane's part of |p|^2.
 // cosine logits, softmax, top-2 (lowest index on ties), renormalised gates, importance key, (choice, expert) counts in LDS.
@@ -582,6 +720,13 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
     } else {
         if (g.M <= 0) return MC_OK;
         grid = dim3(cdiv(g.M, 128), groups, g.nsplit);
+    }
+    // L = 128 without a hidden split: the LDS-DMA staged form (needs 32-bit byte offsets into one group's weights)
+    if (g.dma && g.L == 128 && g.nsplit == 1 && !g.dyn_split && (long)g.hidden * 128 * 4 < (1L << 31)) {
+        if (mode == MLP_EXPERT) hipLaunchKernelGGL((mlp2d_k<MLP_EXPERT>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((mlp2d_k<MLP_PARTS>), grid, dim3(256), 0, s, g);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
     }
 #define MC_MLP_CASE(LL)                                                                              \
     case LL:                                                                                         \

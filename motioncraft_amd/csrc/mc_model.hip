@@ -68,7 +68,8 @@ struct McOptions {
     // 15 (round 4) pqbody_k: bit 10's kernel also runs the body-topology attention (q/k/v never in HBM; L = 128, 12 parts, fp32),
     // 16 (round 4) the twin layer's gate / experts / front kernels run as two sample sub-groups on the two streams
     // 17 (round 4) reduced-precision contexts: film_rows_k writes the FiLM GEMM's A operand as fp16 planes, gemm_hd_k reads them by LDS-DMA
-    int chain = 65527 | (1 << 16) | (1 << 17);     // (all but bit 3)
+    // 18 (round 4) the fused expert / SFFN MLPs of the L = 128 models stage their weight chunks by LDS-DMA (mlp2d_k; same bits)
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18);     // (all but bit 3)
     long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
@@ -411,6 +412,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
     if (chain_on(c, 0) && mc_mlp_supported(din, hid)) {
         // fused expert FFN: hidden activations stay on chip (mc_chain.hip)
         MlpArgs m;
+        m.dma = chain_on(c, 18) ? 1 : 0;
         m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
         m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
         m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
@@ -657,6 +659,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
     int z2_parts = 1;
     if (chain_on(c, 0) && mc_mlp_supported(L, F)) {
         MlpArgs m;
+        m.dma = chain_on(c, 18) ? 1 : 0;
         m.X = hs + o; m.ldx = D; m.x_gstride = L;
         m.W1 = w.ffn_w1; m.b1 = w.ffn_b1; m.W2t = w.ffn_w2; m.b2 = w.ffn_b2;
         m.Y = c->z2 + o; m.ldy = D; m.y_gstride = L; m.M = (int)nrows; m.L = L; m.hidden = F;

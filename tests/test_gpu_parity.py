@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 262135        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
+DEFAULT_CHAIN = 524279        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
@@ -603,7 +603,7 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [262135 & ~7, 262135])
+@pytest.mark.parametrize('chain', [524279 & ~7, 524279])
 def test_generic_fallback_path_vs_oracle(chain):
     """chain mask with bits 0-2 cleared: the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
@@ -658,7 +658,8 @@ def test_fused_proj_qkv_body_kernel_is_bit_identical_to_the_separate_kernels():
     got = {}
     DFL = DEFAULT_CHAIN
     for tag, chain in (('fused', DFL), ('separate', DFL & ~(1 << 15)), ('fused_one_stream', DFL & ~(1 << 5)),
-                       ('separate_one_stream', DFL & ~((1 << 15) | (1 << 5))), ('fused_no_twin_split', DFL & ~(1 << 16))):
+                       ('separate_one_stream', DFL & ~((1 << 15) | (1 << 5))), ('fused_no_twin_split', DFL & ~(1 << 16)),
+                       ('mlp_reg_staged', DFL & ~(1 << 18))):
         ctx = nm.context(B, T, max_steps=2)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('chain', chain)
@@ -675,6 +676,7 @@ def test_fused_proj_qkv_body_kernel_is_bit_identical_to_the_separate_kernels():
     names = ('x0', 'ys layer 0', 'mf layer 0', 'ys layer 1', 'mf layer 1', 'h after 2 layers')
     for a, b, ks in (('fused', 'separate', range(6)), ('fused_one_stream', 'separate_one_stream', range(6)),
                      ('fused', 'fused_no_twin_split', range(6)),      # round 4: the twin layer's front as two sample sub-groups on two streams
+                     ('fused', 'mlp_reg_staged', range(6)),           # mlp2d_k (LDS-DMA staged weight chunks, the default) vs mlp2_k
                      ('fused', 'fused_one_stream', (1, 2))):       # (later stages: the FiLM GEMM's tile width follows the launch's row count)
         for k in ks:
             assert bool(torch.isfinite(got[a][k]).all()), (a, names[k])
