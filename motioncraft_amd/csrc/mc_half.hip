@@ -459,6 +459,148 @@ __global__ __launch_bounds__(256, 2) void mlp2_h_k(MlpArgs g, const mc_half* __r
 }
 
 // per-row LayerNorm of a fragment-distributed row (lane l and lane l ^ 32 hold the two halves; column of x[j][i] = 8 j + 4 hf + i)
+// =================================================================================================
+// mlp2hd_k: mlp2_h_k<128, MODE, SPLIT> with the weight chunks of both layers staged by LDS-DMA (the fp16 twin of mlp2d_k, mc_chain.hip):
+// no staging registers, no ds_write, no padding.  LDS images per plane:
+//   W1 chunk [32 hidden rows][128 halves] (256-byte rows): 16-byte chunk c of row r at position c ^ (r & 15)
+//   W2 chunk [128 out rows][32 halves]   (64-byte rows):  chunk c of row r at position c ^ ((r >> 2) & 3)        (gemm_wp_k's layout)
+// both conflict-free for the b128 fragment reads (mlp2_h_k's padded rows were not: 13 % of its LDS cycles were bank conflicts).
+// Same MFMA order and operands: the same bits.
+// =================================================================================================
+template <int MODE, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void mlp2hd_k(MlpArgs g, const mc_half* __restrict__ W1h, const mc_half* __restrict__ W1l,
+                                                   const mc_half* __restrict__ W2h, const mc_half* __restrict__ W2l) {
+    constexpr int L = 128, P = SPLIT ? 2 : 1, NKB = L / 16, NT = L / 32, HC = 32;
+    constexpr int C1 = HC * L, C2 = L * HC, BUF = P * (C1 + C2), MAXHID = 1024;       // halves
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BUF + 2 * MAXHID];
+    float* s_b1 = reinterpret_cast<float*>(smem + 2 * BUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int grp, row0, nrows;
+    if constexpr (MODE == MLP_EXPERT) {
+        const int real = *g.num_tiles;
+        if ((int)blockIdx.x >= real) return;
+        const int t = xcd_remap(blockIdx.x, real);
+        grp = g.tile_group[t];
+        row0 = g.tile_row0[t];
+        nrows = g.tile_nrows[t];
+    } else {
+        grp = blockIdx.y;
+        row0 = blockIdx.x * 128;
+        nrows = min(128, g.M - row0);
+    }
+    const int grp_u = __builtin_amdgcn_readfirstlane(grp);
+    const mc_half* w1p[P];
+    const mc_half* w2p[P];
+    w1p[0] = W1h + (long)grp_u * g.hidden * L;
+    w2p[0] = W2h + (long)grp_u * L * g.hidden;
+    if constexpr (SPLIT) {
+        w1p[1] = W1l + (long)grp_u * g.hidden * L;
+        w2p[1] = W2l + (long)grp_u * L * g.hidden;
+    }
+    const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
+    const float* __restrict__ b2 = g.b2 + (long)grp * L;
+    for (int i = tid; i < g.hidden; i += 256) s_b1[i] = b1[i];
+    // DMA byte offsets of this lane (2 instructions per plane, matrix and wave)
+    //   W1: instruction q = 4 rows: row 4 (2 wave + q) + (lane >> 4), position lane & 15 <- logical chunk p ^ (row & 15)
+    //   W2: instruction q = 16 rows: row 16 (2 wave + q) + (lane >> 2), position lane & 3 <- logical chunk p ^ ((row >> 2) & 3)
+    unsigned vo1[2], vo2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r1 = 4 * (2 * wave + q) + (lane >> 4), p1 = lane & 15;
+        vo1[q] = (unsigned)((r1 * L + (p1 ^ (r1 & 15)) * 8) * 2);
+        const int r2 = 16 * (2 * wave + q) + (lane >> 2), p2 = lane & 3;
+        vo2[q] = (unsigned)(((long)r2 * g.hidden + (p2 ^ ((r2 >> 2) & 3)) * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto issue = [&](int hc) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const unsigned l1 = lds0 + (unsigned)(((hc & 1) * BUF + p * C1) * 2) + (unsigned)(2 * wave_u) * 1024;
+            const unsigned l2 = lds0 + (unsigned)(((hc & 1) * BUF + P * C1 + p * C2) * 2) + (unsigned)(2 * wave_u) * 1024;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                dma16h(vo1[q], w1p[p] + (long)hc * HC * L, l1 + q * 1024);
+                dma16h(vo2[q], w2p[p] + hc * HC, l2 + q * 1024);
+            }
+        }
+    };
+    const int r = wave * 32 + (lane & 31);
+    const bool rok = r < nrows;
+    f16x8 xh[NKB], xl[NKB];
+    {
+        long srow = rok ? row0 + r : row0;
+        if constexpr (MODE == MLP_EXPERT) srow = rok ? g.src_row[row0 + r] : 0;
+        const float* xp = g.X + (long)grp * g.x_gstride + srow * g.ldx + hf * 8;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * kb), b = *reinterpret_cast<const f32x4*>(xp + 16 * kb + 4);
+            split8(a, b, xh[kb], xl[kb]);
+        }
+    }
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[t][q] = 0.f;
+    const int nch = g.hidden / HC;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int fr = lane & 31, s1x = fr & 15, s2x = (fr >> 2) & 3;
+    for (int hc = 0; hc < nch; ++hc) {
+        if (hc + 1 < nch) issue(hc + 1);
+        const _Float16* B0 = smem + (hc & 1) * BUF;
+        f32x16 a1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a1[q] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int o = fr * L + ((2 * kb + hf) ^ s1x) * 8;
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(B0 + o);
+            const f16x8 wl = SPLIT ? *reinterpret_cast<const f16x8*>(B0 + (P - 1) * C1 + o) : wh;
+            a1 = mma3<SPLIT>(wh, wl, xh[kb], xl[kb], a1);
+        }
+        f16x8 hh[2], hl[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x4 v[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * blk + qq;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b1 + hc * HC + 8 * q + 4 * hf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[qq][i] = gelu_exact(a1[4 * q + i] + bb[i]);
+            }
+            split8(v[0], v[1], hh[blk], hl[blk]);
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int o = P * C1 + (t * 32 + fr) * HC + ((2 * blk + hf) ^ s2x) * 8;
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(B0 + o);
+                const f16x8 wl = SPLIT ? *reinterpret_cast<const f16x8*>(B0 + (P - 1) * C2 + o) : wh;
+                acc2[t] = mma3<SPLIT>(wh, wl, hh[blk], hl[blk], acc2[t]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (!rok) return;
+    long drow = row0 + r;
+    if constexpr (MODE == MLP_EXPERT) drow = g.dst_row[row0 + r];
+    float* yrow = g.Y + (long)grp * g.y_gstride + drow * g.ldy;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = t * 32 + 8 * q + 4 * hf;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + n);
+            const f32x4 v = {acc2[t][4 * q] + bb[0], acc2[t][4 * q + 1] + bb[1], acc2[t][4 * q + 2] + bb[2], acc2[t][4 * q + 3] + bb[3]};
+            *reinterpret_cast<f32x4*>(yrow + n) = v;
+        }
+}
+
 template <int NJ>
 __device__ __forceinline__ void frag_layernorm_h(f32x4 (&x)[NJ], const float* __restrict__ gamma, const float* __restrict__ beta, int kq) {
     constexpr int L = 8 * NJ;
@@ -804,6 +946,14 @@ int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_hal
     } else {
         if (g.M <= 0) return MC_OK;
         grid = dim3(cdiv(g.M, 128), groups, 1);
+    }
+    if (g.dma && g.L == 128) {     // LDS-DMA staged weight chunks (chain bit 18): the same bits
+#define MC_MLPHD(MM, SS) hipLaunchKernelGGL((mlp2hd_k<MM, SS>), grid, dim3(256), 0, s, g, W1h, W1l, W2h, W2l)
+        if (mode == MLP_EXPERT) { if (split) MC_MLPHD(MLP_EXPERT, true); else MC_MLPHD(MLP_EXPERT, false); }
+        else { if (split) MC_MLPHD(MLP_PARTS, true); else MC_MLPHD(MLP_PARTS, false); }
+#undef MC_MLPHD
+        MC_LAUNCH_CHECK();
+        return MC_OK;
     }
 #define MC_MLPH(LL, MM, SS) hipLaunchKernelGGL((mlp2_h_k<LL, MM, SS>), grid, dim3(256), 0, s, g, W1h, W1l, W2h, W2l)
 #define MC_MLPH_CASE(LL)                                                       \

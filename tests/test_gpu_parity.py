@@ -787,7 +787,7 @@ def test_fp16_fused_body_kernel_and_plane_gemm_equal_the_separate_kernels(prec):
     x, xf, mask = synth_inputs(dims, B, T, seed=5, lengths=[24, 20, 13])
     DFL = DEFAULT_CHAIN
     got = {}
-    for tag, chain in (('new', DFL), ('no_fused_body', DFL & ~(1 << 15)), ('no_planes', DFL & ~(1 << 17))):
+    for tag, chain in (('new', DFL), ('no_fused_body', DFL & ~(1 << 15)), ('no_planes', DFL & ~(1 << 17)), ('mlp_reg_staged', DFL & ~(1 << 18))):
         ctx = nm.context(B, T, max_steps=2)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('half_min_rows', 0)
@@ -804,6 +804,8 @@ def test_fp16_fused_body_kernel_and_plane_gemm_equal_the_separate_kernels(prec):
     for k, name in enumerate(('x0', 'ys layer 0', 'mf layer 0', 'h after layer 0')):
         assert bool(torch.isfinite(got['new'][k]).all()), name
         assert torch.equal(got['new'][k], got['no_fused_body'][k]), (name, float((got['new'][k] - got['no_fused_body'][k]).abs().max()))
+        # mlp2hd_k (LDS-DMA staged weight chunks) vs mlp2_h_k (register staged): the same MFMA order, the same bits
+        assert torch.equal(got['new'][k], got['mlp_reg_staged'][k]), (name, float((got['new'][k] - got['mlp_reg_staged'][k]).abs().max()))
     assert torch.equal(got['new'][1], got['no_planes'][1]) and torch.equal(got['new'][2], got['no_planes'][2])
     e = maxabs(got['new'][3], got['no_planes'][3])
     print(f'{prec}: FiLM GEMM from fp16 planes vs in-kernel split: |dh| after layer 0 {e:.2e}, |dx0| {maxabs(got["new"][0], got["no_planes"][0]):.2e}')
