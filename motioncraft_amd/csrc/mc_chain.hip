@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void mlp2_k(MlpArgs g) {
 }
 
 // =================================================================================================
-// mlp2d_k: mlp2_k<128, MODE> with the weight chunks staged by LDS-DMA (global_load_lds_dwordx4) instead of registers + ds_write.
+// mlp2d_k: mlp2_k<L, MODE> (L = 128 or 64) with the weight chunks staged by LDS-DMA (global_load_lds_dwordx4) instead of registers + ds_write.
 // Per chunk every thread of mlp2_k issues 8 global loads, waits for them, and writes 8 x 16 bytes into LDS; here a wave issues 8 DMAs
 // and nothing else (no staging registers, no store instructions, no compiler-placed wait in the MFMA stream).  DMA writes lane-linear,
 // so the LDS images are unpadded and XOR-swizzled instead of padded:
@@ -257,10 +257,13 @@ __device__ __forceinline__ void dma16c(unsigned voff, const float* sbase, unsign
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 
-template <int MODE>
+template <int L, int MODE>
 __global__ __launch_bounds__(256, 2) void mlp2d_k(MlpArgs g) {
-    constexpr int L = 128, NJ = L / 8, NT = L / 32, HC = 32;
+    static_assert(L == 128 || L == 64, "mlp2d_k: L");
+    constexpr int NJ = L / 8, NT = L / 32, HC = 32;
     constexpr int C1 = HC * L, C2 = L * HC, BUFSZ = C1 + C2, MAXHID = 1024;      // floats
+    constexpr int NP = L / 32;             // 1 KB DMA pieces per matrix and wave
+    constexpr int CPR = L / 4;             // 16-byte chunks per W1 row (a DMA instruction covers 256 / CPR rows)
     __shared__ __attribute__((aligned(16))) float smem[2 * BUFSZ + MAXHID];
     float* s_b1 = smem + 2 * BUFSZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,23 +288,23 @@ __global__ __launch_bounds__(256, 2) void mlp2d_k(MlpArgs g) {
     const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
     const float* __restrict__ b2 = g.b2 + (long)grp * L;
     for (int i = tid; i < g.hidden; i += 256) s_b1[i] = b1[i];
-    // DMA byte offsets of this lane (4 pieces per matrix and wave)
-    //   W1: piece q = 2 rows: row 2 (4 wave + q) + (lane >> 5), LDS position lane & 31 <- logical chunk (p & 16) | ((p & 15) ^ (row & 15))
-    //   W2: piece q = 8 rows: row 8 (4 wave + q) + (lane >> 3), LDS position lane & 7  <- logical chunk p ^ ((row >> 1) & 7)
-    unsigned vo1[4], vo2[4];
+    // DMA byte offsets of this lane (NP pieces per matrix and wave)
+    //   W1: piece q = 64 / CPR rows: row (64 / CPR) (NP wave + q) + lane / CPR, LDS position p = lane % CPR <- logical chunk (p & 16) | ((p & 15) ^ (row & 15))
+    //   W2: piece q = 8 rows: row 8 (NP wave + q) + (lane >> 3), LDS position lane & 7  <- logical chunk p ^ ((row >> 1) & 7)
+    unsigned vo1[NP], vo2[NP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r1 = 2 * (4 * wave + q) + (lane >> 5), p1 = lane & 31;
+    for (int q = 0; q < NP; ++q) {
+        const int r1 = (64 / CPR) * (NP * wave + q) + lane / CPR, p1 = lane % CPR;
         vo1[q] = (unsigned)((r1 * L + ((p1 & 16) | ((p1 & 15) ^ (r1 & 15))) * 4) * 4);
-        const int r2 = 8 * (4 * wave + q) + (lane >> 3), p2 = lane & 7;
+        const int r2 = 8 * (NP * wave + q) + (lane >> 3), p2 = lane & 7;
         vo2[q] = (unsigned)(((long)r2 * g.hidden + (p2 ^ ((r2 >> 1) & 7)) * 4) * 4);
     }
     const unsigned lds0 = (unsigned)(size_t)smem;
     auto issue = [&](int hc) {
-        const unsigned l1 = lds0 + (unsigned)((hc & 1) * BUFSZ * 4) + (unsigned)(4 * wave_u) * 1024;
+        const unsigned l1 = lds0 + (unsigned)((hc & 1) * BUFSZ * 4) + (unsigned)(NP * wave_u) * 1024;
         const unsigned l2 = l1 + C1 * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NP; ++q) {
             dma16c(vo1[q], W1 + (long)hc * HC * L, l1 + q * 1024);
             dma16c(vo2[q], W2t + hc * HC, l2 + q * 1024);
         }
@@ -721,10 +724,15 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
         if (g.M <= 0) return MC_OK;
         grid = dim3(cdiv(g.M, 128), groups, g.nsplit);
     }
-    // L = 128 without a hidden split: the LDS-DMA staged form (needs 32-bit byte offsets into one group's weights)
-    if (g.dma && g.L == 128 && g.nsplit == 1 && !g.dyn_split && (long)g.hidden * 128 * 4 < (1L << 31)) {
-        if (mode == MLP_EXPERT) hipLaunchKernelGGL((mlp2d_k<MLP_EXPERT>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((mlp2d_k<MLP_PARTS>), grid, dim3(256), 0, s, g);
+    // L = 128 / 64 without a hidden split: the LDS-DMA staged form (needs 32-bit byte offsets into one group's weights)
+    if (g.dma && (g.L == 128 || g.L == 64) && g.nsplit == 1 && !g.dyn_split && (long)g.hidden * 128 * 4 < (1L << 31)) {
+        if (g.L == 128) {
+            if (mode == MLP_EXPERT) hipLaunchKernelGGL((mlp2d_k<128, MLP_EXPERT>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((mlp2d_k<128, MLP_PARTS>), grid, dim3(256), 0, s, g);
+        } else {
+            if (mode == MLP_EXPERT) hipLaunchKernelGGL((mlp2d_k<64, MLP_EXPERT>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((mlp2d_k<64, MLP_PARTS>), grid, dim3(256), 0, s, g);
+        }
         MC_LAUNCH_CHECK();
         return MC_OK;
     }

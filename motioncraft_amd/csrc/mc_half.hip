@@ -460,17 +460,20 @@ __global__ __launch_bounds__(256, 2) void mlp2_h_k(MlpArgs g, const mc_half* __r
 
 // per-row LayerNorm of a fragment-distributed row (lane l and lane l ^ 32 hold the two halves; column of x[j][i] = 8 j + 4 hf + i)
 // =================================================================================================
-// mlp2hd_k: mlp2_h_k<128, MODE, SPLIT> with the weight chunks of both layers staged by LDS-DMA (the fp16 twin of mlp2d_k, mc_chain.hip):
+// mlp2hd_k: mlp2_h_k<L, MODE, SPLIT> (L = 128 or 64) with the weight chunks of both layers staged by LDS-DMA (the fp16 twin of mlp2d_k, mc_chain.hip):
 // no staging registers, no ds_write, no padding.  LDS images per plane:
-//   W1 chunk [32 hidden rows][128 halves] (256-byte rows): 16-byte chunk c of row r at position c ^ (r & 15)
-//   W2 chunk [128 out rows][32 halves]   (64-byte rows):  chunk c of row r at position c ^ ((r >> 2) & 3)        (gemm_wp_k's layout)
+//   W1 chunk [32 hidden rows][L halves]: 16-byte chunk c of row r at position c ^ (r & 15) (L = 128: 256-byte rows) or c ^ ((r >> 1) & 7) (L = 64)
+//   W2 chunk [L out rows][32 halves]     (64-byte rows):  chunk c of row r at position c ^ ((r >> 2) & 3)        (gemm_wp_k's layout)
 // both conflict-free for the b128 fragment reads (mlp2_h_k's padded rows were not: 13 % of its LDS cycles were bank conflicts).
 // Same MFMA order and operands: the same bits.
 // =================================================================================================
-template <int MODE, bool SPLIT>
+template <int L, int MODE, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void mlp2hd_k(MlpArgs g, const mc_half* __restrict__ W1h, const mc_half* __restrict__ W1l,
                                                    const mc_half* __restrict__ W2h, const mc_half* __restrict__ W2l) {
-    constexpr int L = 128, P = SPLIT ? 2 : 1, NKB = L / 16, NT = L / 32, HC = 32;
+    static_assert(L == 128 || L == 64, "mlp2hd_k: L");
+    constexpr int P = SPLIT ? 2 : 1, NKB = L / 16, NT = L / 32, HC = 32;
+    constexpr int NP = L / 64;             // 1 KB DMA pieces per plane, matrix and wave
+    constexpr int CPR = L / 8;             // 16-byte chunks per W1 row: 16 (256-byte rows, swizzle r & 15) or 8 (128-byte rows, (r >> 1) & 7)
     constexpr int C1 = HC * L, C2 = L * HC, BUF = P * (C1 + C2), MAXHID = 1024;       // halves
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BUF + 2 * MAXHID];
     float* s_b1 = reinterpret_cast<float*>(smem + 2 * BUF);
@@ -501,25 +504,25 @@ __global__ __launch_bounds__(256, 2) void mlp2hd_k(MlpArgs g, const mc_half* __r
     const float* __restrict__ b1 = g.b1 + (long)grp * g.hidden;
     const float* __restrict__ b2 = g.b2 + (long)grp * L;
     for (int i = tid; i < g.hidden; i += 256) s_b1[i] = b1[i];
-    // DMA byte offsets of this lane (2 instructions per plane, matrix and wave)
-    //   W1: instruction q = 4 rows: row 4 (2 wave + q) + (lane >> 4), position lane & 15 <- logical chunk p ^ (row & 15)
-    //   W2: instruction q = 16 rows: row 16 (2 wave + q) + (lane >> 2), position lane & 3 <- logical chunk p ^ ((row >> 2) & 3)
-    unsigned vo1[2], vo2[2];
+    // DMA byte offsets of this lane (NP instructions per plane, matrix and wave)
+    //   W1: instruction q = 64 / CPR rows: row (64 / CPR) (NP wave + q) + lane / CPR, position p = lane % CPR <- logical chunk p ^ swizzle(row)
+    //   W2: instruction q = 16 rows: row 16 (NP wave + q) + (lane >> 2), position lane & 3 <- logical chunk p ^ ((row >> 2) & 3)
+    unsigned vo1[NP], vo2[NP];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r1 = 4 * (2 * wave + q) + (lane >> 4), p1 = lane & 15;
-        vo1[q] = (unsigned)((r1 * L + (p1 ^ (r1 & 15)) * 8) * 2);
-        const int r2 = 16 * (2 * wave + q) + (lane >> 2), p2 = lane & 3;
+    for (int q = 0; q < NP; ++q) {
+        const int r1 = (64 / CPR) * (NP * wave + q) + lane / CPR, p1 = lane % CPR;
+        vo1[q] = (unsigned)((r1 * L + (p1 ^ (L == 128 ? (r1 & 15) : ((r1 >> 1) & 7))) * 8) * 2);
+        const int r2 = 16 * (NP * wave + q) + (lane >> 2), p2 = lane & 3;
         vo2[q] = (unsigned)(((long)r2 * g.hidden + (p2 ^ ((r2 >> 2) & 3)) * 8) * 2);
     }
     const unsigned lds0 = (unsigned)(size_t)smem;
     auto issue = [&](int hc) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const unsigned l1 = lds0 + (unsigned)(((hc & 1) * BUF + p * C1) * 2) + (unsigned)(2 * wave_u) * 1024;
-            const unsigned l2 = lds0 + (unsigned)(((hc & 1) * BUF + P * C1 + p * C2) * 2) + (unsigned)(2 * wave_u) * 1024;
+            const unsigned l1 = lds0 + (unsigned)(((hc & 1) * BUF + p * C1) * 2) + (unsigned)(NP * wave_u) * 1024;
+            const unsigned l2 = lds0 + (unsigned)(((hc & 1) * BUF + P * C1 + p * C2) * 2) + (unsigned)(NP * wave_u) * 1024;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 dma16h(vo1[q], w1p[p] + (long)hc * HC * L, l1 + q * 1024);
                 dma16h(vo2[q], w2p[p] + hc * HC, l2 + q * 1024);
             }
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void mlp2hd_k(MlpArgs g, const mc_half* __r
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int fr = lane & 31, s1x = fr & 15, s2x = (fr >> 2) & 3;
+    const int fr = lane & 31, s1x = L == 128 ? (fr & 15) : ((fr >> 1) & 7), s2x = (fr >> 2) & 3;
     for (int hc = 0; hc < nch; ++hc) {
         if (hc + 1 < nch) issue(hc + 1);
         const _Float16* B0 = smem + (hc & 1) * BUF;
@@ -947,10 +950,15 @@ int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_hal
         if (g.M <= 0) return MC_OK;
         grid = dim3(cdiv(g.M, 128), groups, 1);
     }
-    if (g.dma && g.L == 128) {     // LDS-DMA staged weight chunks (chain bit 18): the same bits
-#define MC_MLPHD(MM, SS) hipLaunchKernelGGL((mlp2hd_k<MM, SS>), grid, dim3(256), 0, s, g, W1h, W1l, W2h, W2l)
-        if (mode == MLP_EXPERT) { if (split) MC_MLPHD(MLP_EXPERT, true); else MC_MLPHD(MLP_EXPERT, false); }
-        else { if (split) MC_MLPHD(MLP_PARTS, true); else MC_MLPHD(MLP_PARTS, false); }
+    if (g.dma && (g.L == 128 || g.L == 64)) {     // LDS-DMA staged weight chunks (chain bit 18): the same bits
+#define MC_MLPHD(LL, MM, SS) hipLaunchKernelGGL((mlp2hd_k<LL, MM, SS>), grid, dim3(256), 0, s, g, W1h, W1l, W2h, W2l)
+        if (g.L == 128) {
+            if (mode == MLP_EXPERT) { if (split) MC_MLPHD(128, MLP_EXPERT, true); else MC_MLPHD(128, MLP_EXPERT, false); }
+            else { if (split) MC_MLPHD(128, MLP_PARTS, true); else MC_MLPHD(128, MLP_PARTS, false); }
+        } else {
+            if (mode == MLP_EXPERT) { if (split) MC_MLPHD(64, MLP_EXPERT, true); else MC_MLPHD(64, MLP_EXPERT, false); }
+            else { if (split) MC_MLPHD(64, MLP_PARTS, true); else MC_MLPHD(64, MLP_PARTS, false); }
+        }
 #undef MC_MLPHD
         MC_LAUNCH_CHECK();
         return MC_OK;

@@ -1554,7 +1554,7 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
     B, T = 3, 24
     x, xf, mask = synth_inputs(dims, B, T, seed=6, lengths=[24, 18, 11])
     got = {}
-    for tag, chain in (('fused', DEFAULT_CHAIN), ('separate', DEFAULT_CHAIN & ~(1 << 15))):
+    for tag, chain in (('fused', DEFAULT_CHAIN), ('separate', DEFAULT_CHAIN & ~(1 << 15)), ('mlp_reg_staged', DEFAULT_CHAIN & ~(1 << 18))):
         ctx = nm.context(B, T, max_steps=1)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('chain', chain)
@@ -1566,12 +1566,15 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
         got[tag] = (out, ctx.buffer('ys').clone(), ctx.buffer('mf').clone())
         ctx.close()
     assert torch.equal(got['fused'][2], got['separate'][2])
+    # mlp2d_k<64> (LDS-DMA staged expert / SFFN weight chunks) vs mlp2_k<64>: the same MFMA order, the same bits everywhere
+    for k in range(3):
+        assert torch.equal(got['fused'][k], got['mlp_reg_staged'][k]), k
     e_ys, e_out = maxabs(got['fused'][1], got['separate'][1]), maxabs(got['fused'][0], got['separate'][0])
     print(f'L = 64: |ys fused - separate| {e_ys:.2e} (|ys| max {float(got["separate"][1].abs().max()):.2f}), |x0| {e_out:.2e}')
     assert bool(torch.isfinite(got['fused'][0]).all()) and e_ys <= 1e-5 and e_out <= 1e-4
     # the fp16-MFMA twin (pqbody_h_k<64>) against projqkv_h_k<64> + body_reg_k<8> in the split mode
     hgot = {}
-    for tag, chain in (('fused', DEFAULT_CHAIN), ('separate', DEFAULT_CHAIN & ~(1 << 15))):
+    for tag, chain in (('fused', DEFAULT_CHAIN), ('separate', DEFAULT_CHAIN & ~(1 << 15)), ('mlp_reg_staged', DEFAULT_CHAIN & ~(1 << 18))):
         ctx = nm.context(B, T, max_steps=1)
         ctx.set_option('big_tokens', 0)
         ctx.set_option('half_min_rows', 0)
@@ -1585,6 +1588,8 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
         hgot[tag] = (out, ctx.buffer('ys').clone(), ctx.buffer('mf').clone())
         ctx.close()
     assert torch.equal(hgot['fused'][2], hgot['separate'][2])
+    for k in range(3):          # mlp2hd_k<64> vs mlp2_h_k<64>
+        assert torch.equal(hgot['fused'][k], hgot['mlp_reg_staged'][k]), k
     e_ys, e_out = maxabs(hgot['fused'][1], hgot['separate'][1]), maxabs(hgot['fused'][0], hgot['separate'][0])
     print(f'L = 64, f16x3: |ys fused - separate| {e_ys:.2e}, |x0| {e_out:.2e}; |x0 f16x3 - x0 f32| {maxabs(hgot["fused"][0], got["fused"][0]):.2e}')
     assert e_ys <= 1e-5 and e_out <= 1e-4 and maxabs(hgot['fused'][0], got['fused'][0]) <= 2e-4
