@@ -21,6 +21,8 @@ FLOPS = {
     ('gemm_wp_k', 131072): (7 * 2.0 * rows * D * D + 2.0 * (B * T) * 352 * D) / 8,
     ('mlp2_k<128, 0>', None): TWIN * 2.0 * N * 2 * (L * 4 * L) * 2,            # top-2: two experts per token, FC1 + FC2
     ('mlp2_k<128, 1>', None): 2.0 * N * (L * F) * 2,
+    ('mlp2d_k<128, 0>', None): TWIN * 2.0 * N * 2 * (L * 4 * L) * 2,           # round 4: the same MLPs with LDS-DMA staged weight chunks
+    ('mlp2d_k<128, 1>', None): 2.0 * N * (L * F) * 2,
     ('projqkv_k<128>', None): 2.0 * N * (L * 4 * L + L * 3 * L),
     ('pqbody_k<128, 12>', None): TWIN * (2.0 * N * (L * 4 * L + L * 3 * L) + 2.0 * rows * (2 * H * H * L + 8 * 2 * H * (L // 8) ** 2 * 2)),      # + static and dynamic body topology
     ('gemm_small16_k<3, false>', None): 2.0 * (B * T) * 322 * D * 2,
