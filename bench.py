@@ -236,21 +236,26 @@ def main():
         ctx.sample_loop(x, [i], [coefs[i]], noise=None, seed=NOISE_KEY, draw0=draw[0])
         draw[0] += 1
 
+    def run_steps(first, count):
+        # `count` consecutive steps of the loop as ONE library call, as a sampling run issues them (the sampler update of a step
+        # writes the next step's padded pose-encoder operand, so single-step calls would time a pad pass no loop performs)
+        order = [(first - j) % TOTAL_DDPM_STEPS for j in range(count)]
+        ctx.sample_loop(x, order, [coefs[j] for j in order], noise=None, seed=NOISE_KEY, draw0=draw[0])
+        draw[0] += count
+        return (first - count) % TOTAL_DDPM_STEPS
+
     i = TOTAL_DDPM_STEPS - 1
-    for _ in range(a.warmup):
-        one_step(i)
-        i = i - 1 if i > 0 else TOTAL_DDPM_STEPS - 1
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    if a.warmup > 0:
+        i = run_steps(i, a.warmup)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     barrier()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        ev[k][0].record()
-        one_step(i)
-        ev[k][1].record()
-        i = i - 1 if i > 0 else TOTAL_DDPM_STEPS - 1
+    ev[0].record()
+    i = run_steps(i, a.steps)          # EXACTLY K steps
+    ev[1].record()
     barrier()
     t_loop = time.perf_counter() - t0
-    ev_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+    ev_ms = ev[0].elapsed_time(ev[1]) / a.steps
 
     # ---- the COMPLETE loop once, outside the K-step region: x_T -> x_0 over all 1000 steps, every step index used once
     # (`value` extrapolates 1000 * t_step from the K timed steps; this is the measured counterpart) ----

@@ -52,3 +52,8 @@ int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half
 // projqkv_h + the body-topology attention over frame-aligned tiles (pqbody_k's fp16-MFMA twin; L = 128, H = 12): q/k/v stay on chip
 int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const mc_half* Wpl, const mc_half* Wqh, const mc_half* Wql, bool split,
                        hipStream_t s);
+
+// temporal_k (mc_attn.hip) with both contractions on the fp16 MFMA (softmax statistics, masks and scalings fp32); L = 128 / 64,
+// whole-(sample, part) workgroups only (the column-sliced small-batch form stays on temporal_k)
+int mc_launch_temporal_h(const float* mf, const float* tf, const float* mask, float* yt, int b0, int nb, int B, int T, int Nt, int H, int L,
+                         bool split, hipStream_t s, const int* twin_flag);

@@ -889,6 +889,289 @@ __global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g, const mc_ha
     }
 }
 
+// =================================================================================================
+// temporal_h_k: temporal linear attention (temporal_k, mc_attn.hip; st_attention.py:137-170) with both contractions on the fp16
+// MFMA.  One workgroup per (sample of the CFG-doubled batch, part); wave w owns output columns [32 w, 32 w + 32).
+//   phase 1  column max / sum of K over the 77 + T tokens: fp32, as temporal_k
+//   phase 2  A2[d][l] = sum_n e[n][d] V[n][l], e = exp2(k2 - max2) UNNORMALISED (<= 1: fp16-friendly; the 1 / sum of column d is
+//            applied to the fp32 accumulator rows afterwards).  The contraction index n must be the 8 consecutive halves of a lane,
+//            so 32-row chunks of K and V are TRANSPOSED while staging: a thread owns one column and 8 consecutive rows (8 scalar
+//            loads, coalesced over the wave), converts / splits them and writes one b128 per plane into [column][32 n] tiles (64-byte
+//            rows, 16-byte chunk c of row r at position c ^ ((r >> 2) & 3): conflict-free b128 fragment reads; the lane -> column map
+//            swaps column bits 1..3 around so that the 8-lane groups of ds_write_b128 hit 8 different slots)
+//   phase 3  y[t][l] = (1 / sum_t) sum_d q'[t][d] A2[d][l], q' = exp2(q2 - max2) unnormalised; the A2 accumulator fragment is the B
+//            operand (split once into fp16 planes in registers), so the Q slab is stored with the chain permutation of its 32-chunks
+//            (mc_half.h) in [32 t][L] tiles (swizzled as mlp2hd_k's W1 chunk)
+// Softmax statistics, masks and the final scaling stay fp32.  SPLIT: three-product hi/lo form (fp32-class), else plain fp16 operands.
+// =================================================================================================
+template <int L, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__ mf, const float* __restrict__ tf,
+                                                       const float* __restrict__ mask, float* __restrict__ yt,
+                                                       int b0, int B, int T, int Nt, int H, const int* twin_flag) {
+    static_assert(L == 128 || L == 64, "temporal_h_k: L");
+    constexpr int NT = L / 32, C4 = L / 4, NSL = 256 / C4, P = SPLIT ? 2 : 1;
+    constexpr int PL = L * 32;                  // halves of one transposed plane chunk [L][32 n] (= one Q slab plane [32 t][L])
+    constexpr int NGT = L / 32;                 // 8-row groups of a chunk per staging thread (128 threads per matrix)
+    __shared__ __attribute__((aligned(16))) float sf[2 * L + 2 * NSL * L + 32];
+    __shared__ __attribute__((aligned(16))) _Float16 sh[2 * P * PL];
+    float* s_m = sf;
+    float* s_s = s_m + L;
+    float* s_pm = s_s + L;
+    float* s_ps = s_pm + NSL * L;
+    float* s_qr = s_ps + NSL * L;               // [32] 1 / sum of the query rows of the current chunk
+    _Float16* Kp = sh;                          // K planes (hi, lo), then V planes; phase 3 reuses the K planes as the Q slab
+    _Float16* Vp = sh + P * PL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = b0 + blockIdx.x / H, h = blockIdx.x % H;
+    const float cnd = b < B ? 1.f : 0.f;
+    const int bm = (twin_flag && b >= B && *twin_flag == 0) ? b - B : b;
+    const float* mrow = mask + (long)(b % B) * T;
+    const int Nseq = Nt + T;
+    const float NEG = -1000000.f;
+    const long D4 = 4 * L;
+    const int hf = lane >> 5, fr = lane & 31;
+
+    // row n of the [text | motion] sequence: pointer to its key vector (value = + L), clamped past the end
+    auto row_ptr = [&](int n, int& t) -> const float* {
+        const int nc = n < Nseq ? n : Nseq - 1;
+        const bool txt = nc < Nt;
+        t = txt ? 0 : nc - Nt;
+        const float* rt = tf + ((long)b * Nt + (txt ? nc : 0)) * 2 * L;
+        const float* rm = mf + (((long)bm * T + t) * H + h) * D4 + L;
+        return txt ? rt : rm;
+    };
+    // ---- phase 1: column max / sum (log2 domain), temporal_k's pass ----
+    {
+        const int c4 = (tid % C4) * 4, sl = tid / C4;
+        f32x4 m = {-3e38f, -3e38f, -3e38f, -3e38f}, s = {0.f, 0.f, 0.f, 0.f};
+        constexpr int BATCH = 8;
+        for (int n0 = sl; n0 < Nseq; n0 += NSL * BATCH) {
+            f32x4 kk[BATCH];
+            float mv[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                int t;
+                const float* r = row_ptr(n0 + u * NSL, t);
+                kk[u] = *reinterpret_cast<const f32x4*>(r + c4);
+                const float mm = mrow[t];
+                mv[u] = n0 + u * NSL < Nt ? cnd : mm;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const bool ok = n0 + u * NSL < Nseq;
+                const float add = (1.f - mv[u]) * NEG;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[u][j] = ok ? (kk[u][j] + add) * LOG2E : -3e38f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float nm = m[j];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) nm = fmaxf(nm, kk[u][j]);
+                float acc = s[j] * fast_exp2(m[j] - nm);
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) acc += fast_exp2(kk[u][j] - nm);
+                s[j] = acc;
+                m[j] = nm;
+            }
+        }
+        *reinterpret_cast<f32x4*>(s_pm + sl * L + c4) = m;
+        *reinterpret_cast<f32x4*>(s_ps + sl * L + c4) = s;
+    }
+    __syncthreads();
+    if (tid < L) {
+        float M = -3e38f;
+        for (int i = 0; i < NSL; ++i) M = fmaxf(M, s_pm[i * L + tid]);
+        float S = 0.f;
+        for (int i = 0; i < NSL; ++i) S += s_ps[i * L + tid] * fast_exp2(s_pm[i * L + tid] - M);
+        s_m[tid] = M;
+        s_s[tid] = 1.f / S;
+    }
+    __syncthreads();
+
+    // ---- phase 2 ----
+    // staging role of this thread: matrix (0 K, 1 V), column, first 8-row group
+    const int mat = tid >> 7, wsub = (tid >> 6) & 1;
+    const int pcol = (lane & 1) | (((lane >> 3) & 1) << 1) | (((lane >> 1) & 3) << 2) | (lane & 0x30);     // lane bits 1..3 -> column bits 2, 3, 1
+    const int col = (L == 128 ? 64 * wsub : 0) + pcol;
+    const int ng0 = L == 128 ? 0 : 2 * wsub;
+    const float colmax = s_m[col];
+    _Float16* myplane = (mat ? Vp : Kp) + col * 32;
+    const int wsw = (col >> 2) & 3;
+    float pf[NGT * 8];
+    float pmv;                      // mask value of row ch * 32 + fr (lanes fr and fr + 32 hold the same)
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NGT; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                int t;
+                const float* rp = row_ptr(ch * 32 + 8 * (ng0 + j) + r, t);
+                pf[j * 8 + r] = rp[col + (mat ? L : 0)];
+            }
+        int t;
+        const int n = ch * 32 + fr;
+        (void)row_ptr(n, t);
+        const float mm = mrow[t];
+        pmv = n < Nt ? cnd : mm;
+    };
+    auto commit = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NGT; ++j) {
+            f32x4 v[2];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = 8 * (ng0 + j) + r;                       // row of the chunk (wave-uniform)
+                const float mv = __shfl(pmv, rr, 64);
+                float x;
+                if (mat == 0) x = fast_exp2(fmaf(pf[j * 8 + r] + (1.f - mv) * NEG, LOG2E, -colmax));
+                else x = pf[j * 8 + r] * mv;
+                if (ch * 32 + rr >= Nseq) x = 0.f;
+                v[r >> 2][r & 3] = x;
+            }
+            f16x8 hi, lo;
+            split8(v[0], v[1], hi, lo);
+            const int pos = ((ng0 + j) ^ wsw) * 8;
+            *reinterpret_cast<f16x8*>(myplane + pos) = hi;
+            if constexpr (SPLIT) *reinterpret_cast<f16x8*>(myplane + PL + pos) = lo;
+        }
+    };
+    const bool mm_active = wave < NT;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const int nch = (Nseq + 31) / 32;
+    const int rsw = (fr >> 2) & 3;
+    prefetch(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        commit(ch);
+        __syncthreads();
+        if (ch + 1 < nch) prefetch(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mm_active) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int o = ((2 * ks + hf) ^ rsw) * 8;
+                const _Float16* vp = Vp + (wave * 32 + fr) * 32 + o;
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
+                const f16x8 vl = SPLIT ? *reinterpret_cast<const f16x8*>(vp + PL) : vh;
+#pragma unroll
+                for (int dt = 0; dt < NT; ++dt) {
+                    const _Float16* kp = Kp + (dt * 32 + fr) * 32 + o;
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(kp);
+                    const f16x8 kl = SPLIT ? *reinterpret_cast<const f16x8*>(kp + PL) : kh;
+                    acc[dt] = mma3<SPLIT>(kh, kl, vh, vl, acc[dt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // 1 / column sum on the accumulator rows, then the fragment becomes the B operand of phase 3 (fp16 planes in registers)
+    f16x8 a2h[NT][2], a2l[NT][2];
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x4 v[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * blk + qq;
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(s_s + dt * 32 + 8 * q + 4 * hf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[qq][i] = acc[dt][4 * q + i] * rs[i];
+            }
+            split8(v[0], v[1], a2h[dt][blk], a2l[dt][blk]);
+        }
+
+    // ---- phase 3 ----
+    const int ntc = (T + 31) / 32;
+    constexpr int SEG = L / 8;
+    const int qrow = tid >> 3, qsub = tid & 7;
+    const int qsw = L == 128 ? (qrow & 15) : ((qrow >> 1) & 7);
+    float qv[SEG];
+    auto prefetch_q = [&](int tc) {
+        const int t = tc * 32 + qrow;
+        if (t < T) {
+            const float* r = mf + (((long)bm * T + t) * H + h) * D4 + 3 * L + qsub * SEG;
+#pragma unroll
+            for (int j = 0; j < SEG; j += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(r + j);
+                qv[j] = x[0]; qv[j + 1] = x[1]; qv[j + 2] = x[2]; qv[j + 3] = x[3];
+            }
+        }
+    };
+    const int fsw = L == 128 ? (fr & 15) : ((fr >> 1) & 7);
+    prefetch_q(0);
+    for (int tc = 0; tc < ntc; ++tc) {
+        {
+            const int t = tc * 32 + qrow;
+            float mx = -3e38f;
+            if (t < T) {
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) mx = fmaxf(mx, qv[j]);
+            }
+            mx = group_max(mx, 8);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) {
+                qv[j] = t < T ? fast_exp2((qv[j] - mx) * LOG2E) : 0.f;
+                s += qv[j];
+            }
+            s = group_sum(s, 8);
+            if (qsub == 0) s_qr[qrow] = t < T ? 1.f / s : 0.f;
+            // quads of 4 consecutive d -> k-slot positions of the chain permutation
+#pragma unroll
+            for (int jq = 0; jq < SEG / 4; ++jq) {
+                const int d0 = SEG * qsub + 4 * jq, s0 = d0 & 31;
+                const int p0 = 16 * (s0 >> 4) + 8 * ((s0 >> 2) & 1) + 4 * ((s0 >> 3) & 1);
+                const int hpos = (d0 & ~31) + p0;                        // half index inside the row
+                const int a = qrow * L + (((hpos >> 3) ^ qsw) << 3) + (hpos & 4);
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = pinned(qv[4 * jq + i]);
+                    const _Float16 hx = (_Float16)x;
+                    hi[i] = hx;
+                    lo[i] = (_Float16)(x - pinned((float)hx));
+                }
+                *reinterpret_cast<f16x4*>(Kp + a) = hi;
+                if constexpr (SPLIT) *reinterpret_cast<f16x4*>(Kp + PL + a) = lo;
+            }
+        }
+        __syncthreads();
+        if (tc + 1 < ntc) prefetch_q(tc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mm_active) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const _Float16* qp = Kp + fr * L + (((2 * (2 * dt + blk) + hf) ^ fsw) << 3);
+                    const f16x8 qh = *reinterpret_cast<const f16x8*>(qp);
+                    const f16x8 ql = SPLIT ? *reinterpret_cast<const f16x8*>(qp + PL) : qh;
+                    o = mma3<SPLIT>(qh, ql, a2h[dt][blk], a2l[dt][blk], o);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(s_qr + 8 * q + 4 * hf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = tc * 32 + 8 * q + 4 * hf + i;
+                    if (t < T) yt[((long)b * T + t) * (H * L) + h * L + wave * 32 + fr] = o[4 * q + i] * rs[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int mc_launch_split_f16(const float* x, mc_half* hi, mc_half* lo, long n, hipStream_t s) {
@@ -1015,6 +1298,22 @@ int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half
         default: mc_set_error("fp16 projqkv: L=%d unsupported", g.L); return MC_ERR_ARG;
     }
 #undef MC_PQH
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_temporal_h(const float* mf, const float* tf, const float* mask, float* yt, int b0, int nb, int B, int T, int Nt, int H, int L,
+                         bool split, hipStream_t s, const int* twin_flag) {
+    MC_REQUIRE(L == 128 || L == 64, "fp16 temporal attention: latent_dim=%d unsupported (128, 64)", L);
+    if (nb <= 0) return MC_OK;
+    dim3 grid(nb * H), blk(256);
+    if (L == 128) {
+        if (split) hipLaunchKernelGGL((temporal_h_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        else hipLaunchKernelGGL((temporal_h_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    } else {
+        if (split) hipLaunchKernelGGL((temporal_h_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        else hipLaunchKernelGGL((temporal_h_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    }
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -46,10 +46,13 @@ struct SamplerCoefs {
 // table != nullptr (graph replay): the step's coefficients are table[*step_ptr]; only text_coef / none_coef of `c` are used
 // rng (with noise == nullptr): the noise is drawn inside the kernel, Philox4x32-10 keyed by the seed, counter (element / 4, draw index)
 struct RngArgs { uint32_t seed_lo = 0, seed_hi = 0, draw_lo = 0, draw_hi = 0; };
+// pad (mc_sample_loop): x_prev is also written as rows of Cp floats into xpad (the next step's pose-encoder GEMM operand; the pad
+// columns are not touched)
+struct PadOut { float* xpad = nullptr; int C = 0, Cp = 0; };
 int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none,
                              const float* noise, float* x_prev, float* x0_out, long n,
                              SamplerCoefs c, hipStream_t s, const SamplerCoefs* table = nullptr, const int* step_ptr = nullptr,
-                             const RngArgs* rng = nullptr);
+                             const RngArgs* rng = nullptr, const PadOut* pad = nullptr);
 // out[n] = the normals / bits[n] = the raw 32-bit words of draw `rng` (either may be null)
 int mc_launch_philox_fill(float* out, uint32_t* bits, long n, RngArgs rng, hipStream_t s);
 // out = table[*step].text_coef * x + table[*step].none_coef * y   (CFG combine of the two halves under graph replay)

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void sampler_update_k(const float* x_t, const 
                                                         const float* __restrict__ o_none, const float* __restrict__ noise,
                                                         float* x_prev, float* __restrict__ x0_out, long n,
                                                         SamplerCoefs c, const SamplerCoefs* __restrict__ table,
-                                                        const int* __restrict__ step_ptr, RngArgs rng) {
+                                                        const int* __restrict__ step_ptr, RngArgs rng, PadOut po) {
     if (table) {          // graph replay: this step's schedule coefficients from the device table
         const float tc = c.text_coef, nc = c.none_coef;
         c = table[*step_ptr];
@@ -271,14 +271,25 @@ __global__ __launch_bounds__(256) void sampler_update_k(const float* x_t, const 
             }
             *reinterpret_cast<f32x4*>(x_prev + i) = out;
             if (x0_out) *reinterpret_cast<f32x4*>(x0_out + i) = x0v;
+            if (po.xpad) {        // the next step's pose-encoder operand: the same rows at the padded stride (pad columns stay zero)
+                long row = i / po.C;
+                int col = (int)(i - row * po.C);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    po.xpad[row * po.Cp + col] = out[j];
+                    if (++col == po.C) { col = 0; ++row; }
+                }
+            }
         } else {
             f32x4 nz = {0.f, 0.f, 0.f, 0.f};
             if constexpr (RNG) nz = philox_normal4(gi, rng);
             for (int j = 0; j < 4 && i + j < n; ++j) {
                 const float x0 = cfg_elem(o_text[i + j], o_none[i + j], c);
                 const float z = RNG ? nz[j] : noise[i + j];
-                x_prev[i + j] = sampler_elem(x_t[i + j], x0, z, c, d);
+                const float o = sampler_elem(x_t[i + j], x0, z, c, d);
+                x_prev[i + j] = o;
                 if (x0_out) x0_out[i + j] = x0;
+                if (po.xpad) po.xpad[(i + j) / po.C * po.Cp + (i + j) % po.C] = o;
             }
         }
     }
@@ -489,7 +500,7 @@ int mc_launch_softmax_rows_small(const float* W, float* out, int rows, int cols,
 }
 
 int mc_launch_sampler_update(const float* x_t, const float* out_text, const float* out_none, const float* noise, float* x_prev, float* x0_out, long n,
-                             SamplerCoefs c, hipStream_t s, const SamplerCoefs* table, const int* step_ptr, const RngArgs* rng) {
+                             SamplerCoefs c, hipStream_t s, const SamplerCoefs* table, const int* step_ptr, const RngArgs* rng, const PadOut* pad) {
     MC_REQUIRE(noise || rng, "sampler update: neither a noise tensor nor a Philox draw given");
     // float4 path when every stream is 16-byte aligned (torch / workspace allocations are; out2 + B*T*C or noise + k*n need not be:
     // C = 263 / 251 / 322 with an odd B*T) -- otherwise the element-wise form of the same kernel (same groups, same Philox counters)
@@ -499,7 +510,9 @@ int mc_launch_sampler_update(const float* x_t, const float* out_text, const floa
     if (blocks < 1) blocks = 1;
     const bool dev_rng = rng && !noise;
     const RngArgs ra = dev_rng ? *rng : RngArgs();
-#define MC_SU(R, V) hipLaunchKernelGGL((sampler_update_k<R, V>), dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev, x0_out, n, c, table, step_ptr, ra)
+    const PadOut po = pad ? *pad : PadOut();
+    MC_REQUIRE(!po.xpad || (po.C > 0 && po.Cp >= po.C), "sampler update: bad padded-copy shape");
+#define MC_SU(R, V) hipLaunchKernelGGL((sampler_update_k<R, V>), dim3(blocks), dim3(256), 0, s, x_t, out_text, out_none, noise, x_prev, x0_out, n, c, table, step_ptr, ra, po)
     if (dev_rng) { if (vec) MC_SU(true, true); else MC_SU(true, false); }
     else { if (vec) MC_SU(false, true); else MC_SU(false, false); }
 #undef MC_SU

@@ -68,8 +68,10 @@ struct McOptions {
     // 15 (round 4) pqbody_k: bit 10's kernel also runs the body-topology attention (q/k/v never in HBM; L = 128, 12 parts, fp32),
     // 16 (round 4) the twin layer's gate / experts / front kernels run as two sample sub-groups on the two streams
     // 17 (round 4) reduced-precision contexts: film_rows_k writes the FiLM GEMM's A operand as fp16 planes, gemm_hd_k reads them by LDS-DMA
-    // 18 (round 4) the fused expert / SFFN MLPs of the L = 128 models stage their weight chunks by LDS-DMA (mlp2d_k; same bits)
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18);     // (all but bit 3)
+    // 18 (round 4) the fused expert / SFFN MLPs (fp32 and fp16, L = 128 / 64) stage their weight chunks by LDS-DMA (mlp2d_k / mlp2hd_k; same bits)
+    // 19 (round 4) mc_sample_loop: the sampler update also writes x_{t-1} at the padded stride of the next step's pose-encoder GEMM
+    // 20 (round 4) reduced-precision contexts: temporal linear attention on the fp16 MFMA (temporal_h_k)
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20);     // (all but bit 3)
     long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
@@ -128,6 +130,7 @@ struct mc_ctx {
     // side stream: the temporal branch of STMA needs only the motion-MoE output, so it runs beside
     // (LN + qkv -> body attention) of the same layer (fork after the MoE projection, join before proj_out)
     hipStream_t side = nullptr;
+    bool xpad_ready = false;           // mc_sample_loop: xpad already holds this step's padded x_t (written by the previous sampler update)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // large batches: the batch is cut into `nparts` groups of whole samples, group k > 0 runs on parts[k-1]
     bool no_alias = false;          // introspection runs (stop_after_layers < num_layers): every intermediate row is materialised
@@ -638,8 +641,13 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
                             frame_alias, row0))) return r;
     if (sb != s) MC_HIP(hipEventRecord(c->ev_join, sb));
     if (phase == 1) return MC_OK;
-    if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), (int)(nrows / c->T), c->B, c->T,
-                                g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split))) return r;
+    const int tnb = (int)(nrows / c->T);
+    if (use_half(c) && chain_on(c, 20) && (L == 128 || L == 64) && (long)tnb * H > c->opt.temporal_split) {
+        // reduced-precision mode: both contractions on the fp16 MFMA (whole-(sample, part) workgroups; the sliced small-batch form stays fp32)
+        if ((r = mc_launch_temporal_h(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), tnb, c->B, c->T, g.max_text_len, H, L,
+                                      c->prec == MC_PREC_F16X3, stt, twin_flag))) return r;
+    } else if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), tnb, c->B, c->T,
+                                       g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split))) return r;
     if (stt != s) MC_HIP(hipEventRecord(c->ev_join, stt));
     if (st != s) MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
     return MC_OK;
@@ -1291,8 +1299,10 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
     // PoseEncoder as one dense [C -> D] GEMM with the scattered weight, + sequence_embedding[:T],
     // written to both CFG halves (stmogen.py:336-353; diffusion_transformer.py:215-218; stmogen.py:740)
     {
+        const bool padded = c->xpad_ready && !seed;        // mc_sample_loop: the previous step's sampler update wrote the rows already
+        c->xpad_ready = false;
         if (seed) { if ((r = mc_launch_pad_rows_seeded(const_cast<float*>(x_t), c->xpad, BT, C, c->m->Cp, *seed, s))) return r; }
-        else if ((r = mc_launch_pad_rows(x_t, c->xpad, BT, C, c->m->Cp, s))) return r;
+        else if (!padded && (r = mc_launch_pad_rows(x_t, c->xpad, BT, C, c->m->Cp, s))) return r;
         GemmArgs e;
         gemm_opts(c, e);
         e.A = c->xpad; e.lda = c->m->Cp;
@@ -1447,15 +1457,25 @@ int mc_sample_loop(mc_ctx* c, float* x, const int32_t* step_indices, const mc_st
     MC_REQUIRE(c && x && step_indices && coefs, "null argument");
     MC_REQUIRE(num_steps >= 0, "num_steps < 0");
     const long n = (long)c->B * c->T * c->m->cfg.input_feats;
+    // the sampler update of step k also writes x_{t-1} at the padded row stride the pose-encoder GEMM of step k + 1 stages from
+    // (chain bit 19: no pad_rows_k launch between the steps; the first step of a loop pads, which also zeroes the pad columns)
+    PadOut po;
+    po.xpad = c->xpad; po.C = c->m->cfg.input_feats; po.Cp = c->m->Cp;
+    const bool fold_pad = chain_on(c, 19) && c->xpad;
+    c->xpad_ready = false;
     for (int k = 0; k < num_steps; ++k) {
         const float *x0a = nullptr, *x0b = nullptr;
         int r = denoise_combined(c, x, step_indices[k], &coefs[k], stream, &x0a, &x0b);
-        if (r != MC_OK) return r;
+        if (r != MC_OK) { c->xpad_ready = false; return r; }
         const RngArgs rng = rng_args(seed, noise_draw0 + (uint64_t)k);
+        const bool more = fold_pad && k + 1 < num_steps;
         r = mc_launch_sampler_update(x, x0a, x0b ? x0b : x0a, noise ? noise + (long)k * n : nullptr, x, k + 1 == num_steps ? x0_last : nullptr, n,
-                                     combined_coefs(&coefs[k], x0b != nullptr), (hipStream_t)stream, nullptr, nullptr, noise ? nullptr : &rng);
-        if (r != MC_OK) return r;
+                                     combined_coefs(&coefs[k], x0b != nullptr), (hipStream_t)stream, nullptr, nullptr, noise ? nullptr : &rng,
+                                     more ? &po : nullptr);
+        if (r != MC_OK) { c->xpad_ready = false; return r; }
+        c->xpad_ready = more;
     }
+    c->xpad_ready = false;
     return MC_OK;
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 524279        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
+DEFAULT_CHAIN = 2097143        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
@@ -603,7 +603,7 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [524279 & ~7, 524279])
+@pytest.mark.parametrize('chain', [2097143 & ~7, 2097143])
 def test_generic_fallback_path_vs_oracle(chain):
     """chain mask with bits 0-2 cleared: the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
@@ -810,6 +810,43 @@ def test_fp16_fused_body_kernel_and_plane_gemm_equal_the_separate_kernels(prec):
     e = maxabs(got['new'][3], got['no_planes'][3])
     print(f'{prec}: FiLM GEMM from fp16 planes vs in-kernel split: |dh| after layer 0 {e:.2e}, |dx0| {maxabs(got["new"][0], got["no_planes"][0]):.2e}')
     assert e <= 2e-5
+    nm.close()
+
+
+@pytest.mark.parametrize('latent', [128, 64])
+def test_fp16_temporal_attention_kernel_vs_the_fp32_kernel(latent):
+    """temporal_h_k (round 4: the temporal linear attention's two contractions on the fp16 MFMA, K / V chunks transposed while staging,
+    unnormalised exponentials with the 1 / sum applied in fp32) against temporal_k on the SAME mf / text rows of a reduced-precision
+    context: y_t of base layer 0 with chain bit 20 on and off (every kernel before it is the same, so mf is bit-equal).  Ragged
+    lengths (masked frames), the unconditional half (masked text rows), L = 128 and L = 64.  f16x3 must be fp32-class, plain f16
+    within one fp16 rounding per operand."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = FULL if latent == 128 else W.default_dims(L=64, F=256, max_seq_len=24)
+    nm = NativeModel(dims, W.make_state_dict(dims, 2), cfg_scale=dims['scale'])
+    B, T = 3, 24
+    x, xf, mask = synth_inputs(dims, B, T, seed=8, lengths=[24, 19, 9])
+    for prec, tol in (('f16x3', 2e-5), ('f16', 4e-3)):
+        got = {}
+        for tag, chain in (('h', DEFAULT_CHAIN), ('f32', DEFAULT_CHAIN & ~(1 << 20))):
+            ctx = nm.context(B, T, max_steps=1)
+            ctx.set_option('big_tokens', 0)
+            ctx.set_option('half_min_rows', 0)
+            ctx.set_option('temporal_split', 0)
+            ctx.set_option('chain', chain)
+            ctx.set_precision(prec)
+            ctx.set_timesteps([650])
+            ctx.set_condition(xf.cuda(), mask.cuda())
+            out = ctx.denoise(x.cuda(), 0).clone()
+            ctx.denoise(x.cuda(), 0, stop_after_layers=1)
+            torch.cuda.synchronize()
+            got[tag] = (out, ctx.buffer('yt').clone(), ctx.buffer('mf').clone())
+            ctx.close()
+        assert torch.equal(got['h'][2], got['f32'][2])
+        scale = float(got['f32'][1].abs().max())
+        e = maxabs(got['h'][1], got['f32'][1])
+        print(f'L = {latent} {prec}: |y_t fp16-MFMA - fp32-MFMA| {e:.2e} (|y_t| max {scale:.2f}), |x0| {maxabs(got["h"][0], got["f32"][0]):.2e}')
+        assert bool(torch.isfinite(got['h'][1]).all()) and e <= tol * max(scale, 1.0)
     nm.close()
 
 

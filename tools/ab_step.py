@@ -48,8 +48,9 @@ coefs = [diff.step_coefs(992 + j, 'ddpm', 6.5) for j in range(8)]
 
 
 def run(j, n):
-    for s in range(n):
-        ctxs[j].sample_loop(xs[j], [s % 8], [coefs[s % 8]], noise=None, seed=7, draw0=s)
+    # ONE mc_sample_loop call over n steps (what a real loop is: the sampler update of a step can prepare the next step's operands)
+    order = [s % 8 for s in range(n)]
+    ctxs[j].sample_loop(xs[j], order, [coefs[s] for s in order], noise=None, seed=7, draw0=0)
 
 
 for j in range(len(ctxs)):
