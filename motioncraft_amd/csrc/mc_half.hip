@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
     {
         const int c4 = (tid % C4) * 4, sl = tid / C4;
         f32x4 m = {-3e38f, -3e38f, -3e38f, -3e38f}, s = {0.f, 0.f, 0.f, 0.f};
-        constexpr int BATCH = 8;
+        constexpr int BATCH = 12;      // (3 round trips for the 273 rows of the 196-frame configs; no accumulators live yet)
         for (int n0 = sl; n0 < Nseq; n0 += NSL * BATCH) {
             f32x4 kk[BATCH];
             float mv[BATCH];
@@ -999,9 +999,11 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
     const float colmax = s_m[col];
     _Float16* myplane = (mat ? Vp : Kp) + col * 32;
     const int wsw = (col >> 2) & 3;
-    float pf[NGT * 8];
-    float pmv;                      // mask value of row ch * 32 + fr (lanes fr and fr + 32 hold the same)
-    auto prefetch = [&](int ch) {
+    // split mode: two register sets -- chunk ch + 1 is requested BEFORE chunk ch is converted, so its round trip to L2 / HBM overlaps the
+    // conversion, the barrier and the MFMAs of chunk ch (the workgroup count per CU is set by the split planes' registers anyway)
+    float pfA[NGT * 8], pfB[NGT * 8];
+    float pmvA, pmvB;               // mask value of row ch * 32 + fr (lanes fr and fr + 32 hold the same)
+    auto prefetch = [&](int ch, float (&pf)[NGT * 8], float& pmv) {
 #pragma unroll
         for (int j = 0; j < NGT; ++j)
 #pragma unroll
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
         const float mm = mrow[t];
         pmv = n < Nt ? cnd : mm;
     };
-    auto commit = [&](int ch) {
+    auto commit = [&](int ch, const float (&pf)[NGT * 8], const float pmv) {
 #pragma unroll
         for (int j = 0; j < NGT; ++j) {
             f32x4 v[2];
@@ -1045,12 +1047,7 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const int nch = (Nseq + 31) / 32;
     const int rsw = (fr >> 2) & 3;
-    prefetch(0);
-    for (int ch = 0; ch < nch; ++ch) {
-        commit(ch);
-        __syncthreads();
-        if (ch + 1 < nch) prefetch(ch + 1);
-        __builtin_amdgcn_sched_barrier(0);
+    auto chunk_mma = [&]() {
         if (mm_active) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1067,7 +1064,35 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
                 }
             }
         }
-        __syncthreads();
+    };
+    prefetch(0, pfA, pmvA);
+    if constexpr (SPLIT) {
+        for (int ch = 0; ch < nch; ch += 2) {
+            if (ch + 1 < nch) prefetch(ch + 1, pfB, pmvB);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(ch, pfA, pmvA);
+            __syncthreads();
+            chunk_mma();
+            __syncthreads();
+            if (ch + 1 < nch) {
+                if (ch + 2 < nch) prefetch(ch + 2, pfA, pmvA);
+                __builtin_amdgcn_sched_barrier(0);
+                commit(ch + 1, pfB, pmvB);
+                __syncthreads();
+                chunk_mma();
+                __syncthreads();
+            }
+        }
+    } else {
+        // plain fp16: one register set (128 VGPRs: four workgroups per CU hide the round trips better than the second set does at two)
+        for (int ch = 0; ch < nch; ++ch) {
+            commit(ch, pfA, pmvA);
+            __syncthreads();
+            if (ch + 1 < nch) prefetch(ch + 1, pfA, pmvA);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk_mma();
+            __syncthreads();
+        }
     }
     // 1 / column sum on the accumulator rows, then the fragment becomes the B operand of phase 3 (fp16 planes in registers)
     f16x8 a2h[NT][2], a2l[NT][2];
