@@ -28,7 +28,7 @@ x = torch.randn(B, T, 322, generator=g).cuda()
 xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],)).cuda()
 ctx = nm.context(B, T, max_steps=50)
 PREC = os.environ.get('MC_PREC', 'f32')          # f32 | f16 | f16x3 (mc_ctx_set_precision; BASELINE configs[4] is the mixed control config in fp16)
-for kv in filter(None, os.environ.get('MC_OPTS', '').split(',')):      # per-context options (mc_ctx_set_option), e.g. MC_OPTS=chain=262135
+for kv in filter(None, os.environ.get('MC_OPTS', '').split(',')):      # per-context options (mc_ctx_set_option), e.g. MC_OPTS=chain=1048567 (no temporal_h_k)
     k_, v_ = kv.split('=')
     ctx.set_option(k_.strip(), int(v_))
 ctx.set_precision(PREC)
