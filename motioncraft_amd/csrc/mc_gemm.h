@@ -49,3 +49,24 @@ int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipSt
 // small-M plain GEMM (64 x 64 tiles, one MFMA tile per wave): C = A W^T + bias (+ add) + R, K % 32 == 0; any N (guarded scalar
 // epilogue when rows are not 16-byte aligned); `groups` as in mc_launch_gemm (the *_gstride fields)
 int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups = 1);
+
+// The folded decoder tail of the large-batch schedule in one pass (gemm_tail_k): x0 = (wc H[r] + wu H[r + half]) W[0]^T +
+// (wc Af[r] + wu Af[r + half]) W[1]^T + bias[0] + bias[1]; the CFG combination is formed while the A slab is staged.
+struct TailArgs {
+    const float* H = nullptr;       // residual stream [2 M][lda]: conditional rows, then (at + half elements) the unconditional ones
+    const float* Af = nullptr;      // FiLM activations of the last StylizationBlock, same layout
+    long half = 0, lda = 0;
+    const float* W = nullptr;       // [2][N][ldw]: pose decoder, pose decoder x last FiLM Linear
+    long ldw = 0, w_gstride = 0;
+    const float* bias = nullptr;    // [2][N] at stride b_gstride
+    long b_gstride = 0;
+    float* C = nullptr;             // [M][ldc]
+    long ldc = 0;
+    int M = 0, N = 0, K = 0;        // K per group
+    float wc = 1.f, wu = 0.f;       // CFG weights ...
+    const float* coef_table = nullptr;   // ... or (graph replay) read from coef_table[*step_ptr * coef_stride + {0, 1}]
+    const int* step_ptr = nullptr;
+    long coef_stride = 0;
+    int tune = -1;
+};
+int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream);

@@ -806,6 +806,139 @@ __global__ __launch_bounds__(256) void gemm_small16_k(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// gemm_tail_k: the folded decoder tail of the large-batch schedule as ONE pass (round 4; stmogen.py:505-544, 757-760):
+//     x0[r] = (w_c h[r] + w_u h[r + half]) W0^T + (w_c a[r] + w_u a[r + half]) W1^T + b0 + b1
+// gemm_small16_k's tile (64 x 16 NBLK, v_mfma_f32_16x16x4_f32, W slabs by LDS-DMA into the same ring) with
+//   * the CFG combination formed while the A slab is staged (two global loads + 2 VALU ops per element through registers, written
+//     into the image the DMA would have produced): no axpby_pair_k pass, h_c / a_c never exist in HBM
+//   * both K groups walked by one accumulator (k-tiles of h, then of a): one output, no partial sums for the sampler kernel
+// Order of a wave's vector-memory ops per iteration: [A loads of tile kt + 3] [W DMAs of stage kt + 3]; at the top of iteration kt
+// everything up to the A loads of tile kt + 1 must have landed (in-order vmcnt): s_waitcnt vmcnt(W(kt+1) A(kt+2) W(kt+2) = 2 nw + 4).
+// ---------------------------------------------------------------------------------------
+// 16-byte global load the compiler does not track: its own s_waitcnt placement counts only the loads it knows, not the LDS-DMAs
+// issued between them, and would drain the whole queue (vmcnt(0)) in front of the first use.  The caller waits by count.
+__device__ __forceinline__ void gload16(f32x4& v, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(256) void gemm_tail_k(TailArgs g) {
+    constexpr int NB = 16 * NBLK, NWP = NB / 8;
+    constexpr int STAGE = (SM + NB) * BK;
+    __shared__ __attribute__((aligned(16))) float smem[SRING * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = (g.N + NB - 1) / NB;
+    const int bid = (g.tune & 256) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * SM;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float wc = g.wc, wu = g.wu;
+    if (g.coef_table) { wc = g.coef_table[(long)*g.step_ptr * g.coef_stride]; wu = g.coef_table[(long)*g.step_ptr * g.coef_stride + 1]; }
+    // A slab slots of this thread: (row, 16-byte position) = ((tid + 256 j) >> 3, (tid + 256 j) & 7); position p of row r holds chunk p ^ (r & 7)
+    long aoff[2];
+    int alds[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + 256 * j, row = i >> 3, pos = i & 7;
+        aoff[j] = (long)min(row0 + row, g.M - 1) * g.lda + ((pos ^ (row & 7)) << 2);
+        alds[j] = row * BK + (pos << 2);
+    }
+    const int dr = lane >> 3, dc = ((lane & 7) ^ dr) * 4;
+    constexpr int MAXW = (NWP + 3) / 4;
+    unsigned vow[MAXW];
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q) vow[q] = (unsigned)(((long)min(tn * NB + 8 * (wave + 4 * q) + dr, g.N - 1) * g.ldw + dc) * 4);
+    const int nw = (NWP - wave_u + 3) / 4;                    // W pieces of this wave (uniform)
+    const unsigned lds_base = (unsigned)(size_t)smem;
+    const int nk = g.K / BK, NK = 2 * nk;
+    auto a_load = [&](int kt, f32x4 (&c)[2], f32x4 (&u)[2]) {
+        const float* A = (kt < nk ? g.H : g.Af) + (long)(kt < nk ? kt : kt - nk) * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gload16(c[j], A + aoff[j]);
+            gload16(u[j], A + g.half + aoff[j]);
+        }
+    };
+    auto a_store = [&](int kt, const f32x4 (&c)[2], const f32x4 (&u)[2]) {
+        float* St = smem + (kt & (SRING - 1)) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = wc * c[j][i] + wu * u[j][i];
+            *reinterpret_cast<f32x4*>(St + alds[j]) = v;
+        }
+    };
+    auto w_issue = [&](int kt) {
+        const float* Wb = g.W + (kt < nk ? 0 : g.w_gstride) + (long)(kt < nk ? kt : kt - nk) * BK;
+        const unsigned l = lds_base + (unsigned)(kt & (SRING - 1)) * (STAGE * 4) + SM * BK * 4;
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+            if (q < nw) dma16(vow[q], Wb, l + (unsigned)(8 * (wave_u + 4 * q)) * BK * 4);
+    };
+    f32x4 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, kg = lane >> 4;
+    const int sw = frow & 7;
+    // three A register sets in rotation (tile k lives in set k % 3): a tile is requested three iterations before it is written into its
+    // LDS stage (one iteration of 24 MFMAs is ~0.3 us, a round trip to L2 / HBM several times that)
+    f32x4 c0[2], u0[2], c1[2], u1[2], c2[2], u2[2];
+    a_load(0, c0, u0);
+    w_issue(0);
+    if (NK > 1) { a_load(1, c1, u1); w_issue(1); }
+    if (NK > 2) { a_load(2, c2, u2); w_issue(2); }
+    // A(0) has landed once at most W0 A1 W1 A2 W2 are outstanding (NK >= 3 for every model width; otherwise wait for everything)
+    if (NK > 2) { if (nw == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    a_store(0, c0, u0);
+    // one iteration: stage kt is consumed; A(kt + 1) (set `st`) goes into its LDS stage; A(kt + 3) is requested into the set tile kt used
+    auto step = [&](int kt, f32x4 (&cs)[2], f32x4 (&us)[2], f32x4 (&cl)[2], f32x4 (&ul)[2]) {
+        // everything up to A(kt + 1) has landed once only W(kt+1) A(kt+2) W(kt+2) are outstanding
+        if (kt + 2 < NK) { if (nw == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < NK) a_store(kt + 1, cs, us);
+        if (kt + 3 < NK) { a_load(kt + 3, cl, ul); w_issue(kt + 3); }
+        const float* St = smem + (kt & (SRING - 1)) * STAGE;
+        const float* At = St + (16 * wave + frow) * BK;
+        const float* Bt = St + SM * BK + frow * BK;
+        f32x4 fa[2], fb[NBLK][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pos = ((4 * j + kg) ^ sw) * 4;
+            fa[j] = *reinterpret_cast<const f32x4*>(At + pos);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) fb[b][j] = *reinterpret_cast<const f32x4*>(Bt + b * 16 * BK + pos);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[b][j][i], fa[j][i], acc[b], 0, 0, 0);
+    };
+    for (int kt = 0; kt < NK; kt += 3) {
+        step(kt, c1, u1, c0, u0);
+        if (kt + 1 < NK) step(kt + 1, c2, u2, c1, u1);
+        if (kt + 2 < NK) step(kt + 2, c0, u0, c2, u2);
+    }
+    const int m = row0 + 16 * wave + frow;
+    if (m >= g.M) return;
+    float* crow = g.C + (long)m * g.ldc;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int n = tn * NB + 16 * b + 4 * kg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (n + i >= g.N) continue;
+            crow[n + i] = acc[b][i] + (g.bias[n + i] + g.bias[g.b_gstride + n + i]);
+        }
+    }
+}
+
 }  // namespace
 
 static int tune_bits() {
@@ -903,6 +1036,20 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
         case GM_ENC: hipLaunchKernelGGL(gemm_k<GM_ENC>, grid, dim3(256), 0, stream, g); break;
         default: mc_set_error("bad gemm mode %d", mode); return MC_ERR_ARG;
     }
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream) {
+    MC_REQUIRE(g.H && g.Af && g.W && g.bias && g.C, "gemm_tail: null operand");
+    MC_REQUIRE(g.K % BK == 0 && g.K >= BK && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.half % 4 == 0 && g.w_gstride % 4 == 0,
+               "gemm_tail: unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    if (g.M <= 0 || g.N <= 0) return MC_OK;
+    MC_REQUIRE((long)g.N * g.ldw * 4 < (1L << 32), "gemm_tail: weight beyond 4 GB");
+    TailArgs gg = g;
+    if (gg.tune < 0) gg.tune = tune_bits();
+    dim3 grid(cdiv(g.M, SM) * cdiv(g.N, 48));
+    hipLaunchKernelGGL((gemm_tail_k<3>), grid, dim3(256), 0, stream, gg);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

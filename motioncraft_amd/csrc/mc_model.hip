@@ -71,7 +71,8 @@ struct McOptions {
     // 18 (round 4) the fused expert / SFFN MLPs (fp32 and fp16, L = 128 / 64) stage their weight chunks by LDS-DMA (mlp2d_k / mlp2hd_k; same bits)
     // 19 (round 4) mc_sample_loop: the sampler update also writes x_{t-1} at the padded stride of the next step's pose-encoder GEMM
     // 20 (round 4) reduced-precision contexts: temporal linear attention on the fp16 MFMA (temporal_h_k)
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20);     // (all but bit 3)
+    // 21 (round 4) large batches: the folded decoder tail with the CFG combination in its A staging, one pass over both K groups (gemm_tail_k)
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21);     // (all but bit 3)
     long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
@@ -1387,6 +1388,24 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
         if (c->graph_mode) return mc_launch_cfg_combine_tab(x, y, c->gcoefs, c->gstep, out, BT * D, s);
         return mc_launch_axpby(x, y, k->text_coef, k->none_coef, out, BT * D, s);
     };
+    if (defer && c->dec_cat_w && chain_on(c, 11) && chain_on(c, 21) && BT > c->opt.small_gemm_rows && D % 32 == 0) {
+        // large batches: CFG combination, both K groups and the biases in ONE GEMM pass (gemm_tail_k): no axpby_pair_k, no partial outputs
+        TailArgs t;
+        t.H = c->h; t.Af = c->a; t.half = BT * D; t.lda = D;
+        t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D; t.bias = c->dec_cat_b; t.b_gstride = C;
+        t.C = c->out2; t.ldc = C; t.M = (int)BT; t.N = C; t.K = D;
+        t.wc = k->text_coef; t.wu = k->none_coef;
+        if (c->graph_mode) {
+            static_assert(sizeof(SamplerCoefs) % sizeof(float) == 0 && offsetof(SamplerCoefs, none_coef) == offsetof(SamplerCoefs, text_coef) + sizeof(float), "SamplerCoefs layout");
+            t.coef_table = reinterpret_cast<const float*>(c->gcoefs) + offsetof(SamplerCoefs, text_coef) / sizeof(float);
+            t.coef_stride = sizeof(SamplerCoefs) / sizeof(float);
+            t.step_ptr = c->gstep;
+        }
+        t.tune = options_of(c).gemm_tune;
+        if ((r = mc_launch_gemm_tail(t, s))) return r;
+        *x0a = c->out2;
+        return MC_OK;
+    }
     if (defer && c->dec_cat_w && chain_on(c, 11)) {
         // h_c and a_c in one launch
         if ((r = mc_launch_axpby_pair(c->h, c->h + BT * D, c->z2, c->a, c->a + BT * D, c->z2 + BT * D, k->text_coef, k->none_coef,

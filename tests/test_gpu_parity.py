@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 2097143        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
+DEFAULT_CHAIN = 4194295        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
@@ -603,7 +603,7 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [2097143 & ~7, 2097143])
+@pytest.mark.parametrize('chain', [4194295 & ~7, 4194295])
 def test_generic_fallback_path_vs_oracle(chain):
     """chain mask with bits 0-2 cleared: the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
@@ -935,6 +935,53 @@ def test_hipgraph_replay_of_the_sampler_step_is_bit_identical(prec):
         assert bool(torch.isfinite(outs['eager']).all())
         assert torch.equal(outs['eager'], outs['graph']), (prec, dims['L'], maxabs(outs['eager'], outs['graph']))
         nm.close()
+
+
+def test_one_pass_decoder_tail_equals_combine_plus_grouped_gemm():
+    """gemm_tail_k (round 4, chain bit 21: the folded decoder tail of the large-batch schedule with the CFG combination formed in its A
+    staging and both K groups in one accumulator) against axpby_pair_k + the grouped gemm_small16_k + the sum in the sampler kernel:
+    x0 and x_(t-1) of two DDIM steps within fp32 round-off of the other accumulation order (the operands are the same values).  0.125b
+    widths at B=3 x 24 frames (72 rows: a ragged second row tile; N = 322: a ragged seventh column tile), pushed onto the kernel with
+    small_gemm_rows = 0.  Under hipGraph replay the CFG weights come from the device table: replay must equal eager bit for bit."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = FULL
+    nm = NativeModel(dims, W.make_state_dict(dims, 4), cfg_scale=dims['scale'])
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large',
+                             respace='2'))
+    S = d.num_timesteps
+    B, T = 3, 24
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=9, lengths=[24, 17, 12])
+    coefs = [d.step_coefs(i, 'ddim', dims['scale']) for i in range(S)]
+    noise = torch.randn(B, T, dims['input_feats'], generator=torch.Generator().manual_seed(3)).cuda()
+    got = {}
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for arm, chain in (('one_pass', DEFAULT_CHAIN), ('grouped', DEFAULT_CHAIN & ~(1 << 21)), ('one_pass_graph', DEFAULT_CHAIN)):
+            ctx = nm.context(B, T, max_steps=S)
+            ctx.set_option('small_gemm_rows', 0)
+            ctx.set_option('chain', chain)
+            ctx.set_timesteps(d.timestep_map)
+            ctx.set_condition(xf.cuda(), mask.cuda())
+            x = x_T.cuda().clone()
+            x0 = torch.empty_like(x)
+            if arm.endswith('graph'):
+                ctx.graph_capture(x, noise, coefs)
+                x.copy_(x_T)
+                for i in range(S - 1, -1, -1):
+                    ctx.graph_step(i)
+            else:
+                for i in range(S - 1, -1, -1):
+                    ctx.sample_step(x, i, coefs[i], noise, x_prev=x, x0=x0)
+            stream.synchronize()
+            got[arm] = (x.clone(), x0.clone())
+            ctx.close()
+    e_x, e_x0 = maxabs(got['one_pass'][0], got['grouped'][0]), maxabs(got['one_pass'][1], got['grouped'][1])
+    print(f'one-pass tail vs combine + grouped GEMM: |dx_prev| {e_x:.2e}, |dx0| {e_x0:.2e} (|x0| max {float(got["grouped"][1].abs().max()):.2f})')
+    assert bool(torch.isfinite(got["one_pass"][0]).all()) and e_x <= 6e-5 and e_x0 <= 6e-5
+    assert torch.equal(got['one_pass'][0], got['one_pass_graph'][0])
+    nm.close()
 
 
 def test_wrap_fp16_model_and_graph_replay_through_the_reference_api(small_model):
