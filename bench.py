@@ -8,7 +8,8 @@ batch=64 per GPU).
 
 A "step" is one pass of the hot path over one batch: denoiser (CFG-doubled) + CFG combine +
 p_sample update, including the per-step noise draw (on the device, inside the sampler-update
-kernel: mc_sample_loop).  K steps are timed between barriers + device syncs; MAX over ranks.  `value` = whole-job frames/s of the COMPLETE 1000-step loop:
+kernel: mc_sample_loop).  EXACTLY K consecutive steps of the loop, issued as one mc_sample_loop call (as a sampling run issues
+them), are timed between barriers + device syncs; MAX over ranks.  `value` = whole-job frames/s of the COMPLETE 1000-step loop:
 
     value = N * B * T / (t_setup + 1000 * t_step + t_gather)
 
