@@ -46,17 +46,18 @@ __device__ __forceinline__ float gelu_exact(float x) {
     // nn.GELU() default / F.gelu: x * Phi(x), Phi(x) = 0.5 (1 + erf(x / sqrt 2)).
     // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level; the resulting
     // GELU has max abs error 4.7e-7 over [-8, 8], the same as evaluating libm erff in fp32: 4.5e-7)
-    // in ~17 VALU instructions instead of the ~45 of the device erff.  For x < 0, Phi = 0.5 p e is
-    // formed directly instead of 1 - (1 - p e) (no cancellation).
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));   // v_rcp_f32, 1 ulp (__frcp_rn expands to the IEEE division sequence)
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float h = 0.5f * p * t * fast_exp2(az * az * -LOG2E);
-    return x * (z >= 0.f ? 1.0f - h : h);
+    // in 12 VALU + 2 transcendental instructions instead of the ~45 of the device erff (the fused MLPs pay for these lane-cycles:
+    // fp32 VALU work shares the datapath with the fp32 MFMA).  With z = x / sqrt 2, t = 1 / (1 + p |z|),
+    // h = 0.5 poly(t) t exp(-z^2):  gelu = x (1 - h) for x >= 0 and x h for x < 0, i.e. max(x, 0) - |x| h in both cases (no
+    // cancellation for x < 0).  The 1 / sqrt 2 and the 0.5 are folded into the constants.
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));   // v_rcp_f32, 1 ulp
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float h = p * t * fast_exp2(x * x * (-0.5f * LOG2E));
+    return fmaf(-ax, h, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
