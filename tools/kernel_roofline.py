@@ -26,6 +26,7 @@ FLOPS = {
     ('projqkv_k<128>', None): 2.0 * N * (L * 4 * L + L * 3 * L),
     ('pqbody_k<128, 12>', None): TWIN * (2.0 * N * (L * 4 * L + L * 3 * L) + 2.0 * rows * (2 * H * H * L + 8 * 2 * H * (L // 8) ** 2 * 2)),      # + static and dynamic body topology
     ('gemm_small16_k<3, false>', None): 2.0 * (B * T) * 322 * D * 2,
+    ('gemm_tail_k<3>', None): 2.0 * (B * T) * 322 * D * 2,                      # round 4: the folded decoder tail in one pass
     ('temporal_k<128, false>', None): 2.0 * B * H * ((Nt + T) * L * L + T * L * L) * 2,
     ('gate_k<128>', 602112): 2.0 * N * (L * 256 + 256 * E),
     ('gemm_small_k<false>', None): 2.0 * (B * T) * 322 * D * 2,
