@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
         float s = 0.f;
 #pragma unroll
         for (int h = 0; h < H; ++h) { k[h] = fast_exp2((k[h] - m) * LOG2E); s += k[h]; }
-        const float rs = __builtin_amdgcn_rcpf(s);
+        const float rs = __frcp_rn(s);
 #pragma unroll
         for (int h = 0; h < H; ++h) k[h] *= rs;
     }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
     for (int h = 0; h < H; ++h) {
         const float m = group_max(q[h], HD);
         const float e = fast_exp2((q[h] - m) * LOG2E);
-        q[h] = e * __builtin_amdgcn_rcpf(group_sum(e, HD));
+        q[h] = e * __frcp_rn(group_sum(e, HD));
     }
     float* out = ys + frame * (H * L) + c;
     if constexpr (HD == 16) {

@@ -95,7 +95,7 @@ struct BodyPhase {
         for (int h = 0; h < NQ; ++h) {
             const float m = group_max(b.q[h], HD);
             const float e = fast_exp2((b.q[h] - m) * LOG2E);
-            b.q[h] = e * __builtin_amdgcn_rcpf(group_sum(e, HD));
+            b.q[h] = e * __frcp_rn(group_sum(e, HD));
         }
     }
     template <class B>
@@ -110,7 +110,7 @@ struct BodyPhase {
         float sum = 0.f;
 #pragma unroll
         for (int h = 0; h < H; ++h) { b.k[h] = fast_exp2((b.k[h] - m) * LOG2E); sum += b.k[h]; }
-        const float rs = __builtin_amdgcn_rcpf(sum);
+        const float rs = __frcp_rn(sum);
 #pragma unroll
         for (int h = 0; h < H; ++h) b.k[h] *= rs;
     }
