@@ -126,28 +126,36 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
 // columns are cut into 32-wide slices on blockIdx.y; inside a workgroup wave w then owns ONE 32 x 32 tile of A2 (d tile w
 // of the slice's columns) instead of all L/32 d tiles of its own columns, and the partial products of the second
 // contraction (one d tile per wave) are summed through LDS.  4x the workgroups, a quarter of the MFMA chain per wave.
-template <int L, bool LSPLIT>
+// PAIR (L = 64 models, even H; round 4): one workgroup owns TWO adjacent parts (h, h + 1) of a sample.  At L = 64 a part has two 32-wide
+// d tiles, i.e. two MFMA waves, and half of every workgroup only staged and waited at the chunk barriers (temporal_k<64> ran at 33 % of
+// the MFMA rate).  The pair's K / V / Q rows are staged as one 128-column slab (part p in columns [64 p, 64 p + 64)); waves 2 p, 2 p + 1 own
+// part p's two output column tiles.  Same per-part arithmetic, half the workgroups, every wave on the MFMA.
+template <int L, bool LSPLIT, bool PAIR = false>
 __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                      const float* __restrict__ mask, float* __restrict__ yt,
                                                      int b0, int B, int T, int Nt, int H, const int* twin_flag) {
-    constexpr int NT = L / 32;           // 32-wide d tiles (= active waves)
-    constexpr int LP = L + 4;
-    constexpr int C4 = L / 4;            // float4 columns per row
+    static_assert(!PAIR || (L == 64 && !LSPLIT), "temporal_k: PAIR is the L = 64 whole-part form");
+    constexpr int LW = PAIR ? 2 * L : L; // columns of the staged slabs
+    constexpr int NT = L / 32;           // 32-wide d tiles of a part (= MFMA waves per part)
+    constexpr int LP = LW + 4;
+    constexpr int C4 = LW / 4;           // float4 columns per row
     constexpr int NSL = 256 / C4;        // row slices in the stats pass
     constexpr int NACC = LSPLIT ? 1 : NT;
-    __shared__ __attribute__((aligned(16))) float sm[2 * L + 2 * NSL * L + 2 * 32 * LP + (LSPLIT ? NT * 32 * 33 : 0)];
+    __shared__ __attribute__((aligned(16))) float sm[2 * LW + 2 * NSL * LW + 2 * 32 * LP + (LSPLIT ? NT * 32 * 33 : 0)];
     float* s_m = sm;
-    float* s_s = s_m + L;
-    float* s_pm = s_s + L;               // [NSL][L]
-    float* s_ps = s_pm + NSL * L;        // [NSL][L]
-    float* Ks = s_ps + NSL * L;          // [32][LP]
+    float* s_s = s_m + LW;
+    float* s_pm = s_s + LW;              // [NSL][LW]
+    float* s_ps = s_pm + NSL * LW;       // [NSL][LW]
+    float* Ks = s_ps + NSL * LW;         // [32][LP]
     float* Vs = Ks + 32 * LP;            // [32][LP]
     float* Qs = Ks;                      // [32][LP]  phase 3 reuses the K slab (43 KB total -> 3 workgroups per CU)
     float* Ps = Vs + 32 * LP;            // LSPLIT: [NT][32][33] partial y_t tiles of the waves
     const int ls = LSPLIT ? (int)blockIdx.y : 0;      // output column slice (LSPLIT)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = b0 + blockIdx.x / H, h = blockIdx.x % H;
+    const int HB = PAIR ? H / 2 : H;                 // workgroups per sample
+    const int b = b0 + blockIdx.x / HB, h = PAIR ? 2 * (blockIdx.x % HB) : blockIdx.x % HB;
+    const int wp = PAIR ? wave >> 1 : 0, wl = PAIR ? wave & 1 : wave;      // MFMA role of this wave: part of the pair, 32-wide output column tile
     const float cnd = b < B ? 1.f : 0.f;             // text-conditioned half first (stmogen.py:736-739)
     // CFG twin aliasing (base layer 0): the motion rows of sample b >= B were not produced, they equal sample b - B's
     const int bm = (twin_flag && b >= B && *twin_flag == 0) ? b - B : b;
@@ -164,8 +172,9 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
         const int nc = n < Nseq ? n : Nseq - 1;
         const bool txt = nc < Nt;
         t = txt ? 0 : nc - Nt;
-        const float* rt = tf + ((long)b * Nt + (txt ? nc : 0)) * 2 * L + c4;            // [key | value]
-        const float* rm = mf + (((long)bm * T + t) * H + h) * D4 + L + c4;              // [.. | key | value | ..]
+        const int pp = PAIR ? c4 / L : 0, cc = PAIR ? c4 % L : c4;                     // part of the pair, column inside the part
+        const float* rt = tf + ((long)b * Nt + (txt ? nc : 0)) * 2 * L + cc;            // [key | value] (the text rows serve every part)
+        const float* rm = mf + (((long)bm * T + t) * H + h + pp) * D4 + L + cc;         // [.. | key | value | ..]
         return txt ? rt : rm;
     };
     auto issue_kv = [&](int n, int c4, f32x4& kk, f32x4& vv, float& mv) {
@@ -216,22 +225,22 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
                 m[j] = nm;
             }
         }
-        *reinterpret_cast<f32x4*>(s_pm + sl * L + c4) = m;
-        *reinterpret_cast<f32x4*>(s_ps + sl * L + c4) = s;
+        *reinterpret_cast<f32x4*>(s_pm + sl * LW + c4) = m;
+        *reinterpret_cast<f32x4*>(s_ps + sl * LW + c4) = s;
     }
     __syncthreads();
-    if (tid < L) {
+    if (tid < LW) {
         float M = -3e38f;
-        for (int i = 0; i < NSL; ++i) M = fmaxf(M, s_pm[i * L + tid]);
+        for (int i = 0; i < NSL; ++i) M = fmaxf(M, s_pm[i * LW + tid]);
         float S = 0.f;
-        for (int i = 0; i < NSL; ++i) S += s_ps[i * L + tid] * fast_exp2(s_pm[i * L + tid] - M);
+        for (int i = 0; i < NSL; ++i) S += s_ps[i * LW + tid] * fast_exp2(s_pm[i * LW + tid] - M);
         s_m[tid] = M;                 // column max in the log2 domain
         s_s[tid] = 1.f / S;           // reciprocal of the column sum
     }
     __syncthreads();
 
     // ---- phase 2: A2[d][l] = sum_n softmaxK[n][d] V[n][l]  (st_attention.py:167) ----
-    const bool mm_active = wave < NT;
+    const bool mm_active = PAIR || wave < NT;
     f32x16 acc[NACC];
 #pragma unroll
     for (int dt = 0; dt < NACC; ++dt)
@@ -280,10 +289,10 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
                     const float a = Ks[n * LP + wave * 32 + (lane & 31)];
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[0], 0, 0, 0);
                 } else {
-                    const float bb = Vs[n * LP + wave * 32 + (lane & 31)];
+                    const float bb = Vs[n * LP + wp * L + wl * 32 + (lane & 31)];
 #pragma unroll
                     for (int dt = 0; dt < NT; ++dt) {
-                        const float a = Ks[n * LP + dt * 32 + (lane & 31)];
+                        const float a = Ks[n * LP + wp * L + dt * 32 + (lane & 31)];
                         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[dt], 0, 0, 0);
                     }
                 }
@@ -296,13 +305,15 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
     // lane (l = 32*wave + (lane&31), half hf) holds A2[d][l] for d = 32 dt + 8 q + 4 hf + i in acc[dt][4q+i]:
     // exactly the B operand of k-group (dt, q); the A operand Q[t][same d] is one b128 read.
     const int ntc = (T + 31) / 32;
-    constexpr int SEG = L / 8;                       // 8 threads per query row
+    constexpr int SEG = LW / 8;                      // 8 threads per query row (PAIR: 4 per part)
+    constexpr int QG = PAIR ? 4 : 8;                 // threads that share one softmax row
     const int qrow = tid >> 3, qsub = tid & 7;
+    const int qpart = PAIR ? qsub >> 2 : 0, qcol = PAIR ? (qsub & 3) * SEG : qsub * SEG;
     float qv[SEG];
     auto prefetch_q = [&](int tc) {
         const int t = tc * 32 + qrow;
         if (t < T) {
-            const float* r = mf + (((long)bm * T + t) * H + h) * D4 + 3 * L + qsub * SEG;
+            const float* r = mf + (((long)bm * T + t) * H + h + qpart) * D4 + 3 * L + qcol;
 #pragma unroll
             for (int j = 0; j < SEG; j += 4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(r + j);
@@ -322,13 +333,13 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
 #pragma unroll
                 for (int j = 0; j < SEG; ++j) mx = fmaxf(mx, qv[j]);
             }
-            mx = group_max(mx, 8);
+            mx = group_max(mx, QG);
             float s = 0.f;
             if (t < T) {
 #pragma unroll
                 for (int j = 0; j < SEG; ++j) { qv[j] = fast_exp2((qv[j] - mx) * LOG2E); s += qv[j]; }
             }
-            s = 1.f / group_sum(s, 8);
+            s = 1.f / group_sum(s, QG);
 #pragma unroll
             for (int j = 0; j < SEG; j += 4) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
-            const float* qp = Qs + (lane & 31) * LP + 4 * hf;
+            const float* qp = Qs + (lane & 31) * LP + wp * L + 4 * hf;
             if constexpr (LSPLIT) {          // this wave's d tile only: a partial sum over d
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int t = tc * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
-                    if (t < T) yt[((long)b * T + t) * (H * L) + h * L + wave * 32 + (lane & 31)] = o[reg];
+                    if (t < T) yt[((long)b * T + t) * (H * L) + (h + wp) * L + wl * 32 + (lane & 31)] = o[reg];
                 }
             }
         }
@@ -405,7 +416,7 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 }
 
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag, long lsplit_max) {
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag, long lsplit_max, bool pair) {
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
     // small batches: a few dozen (sample, part) workgroups, each bound by its waves' serial MFMA chain -> cut the L output
@@ -420,7 +431,10 @@ int mc_launch_temporal(const float* mf, const float* tf, const float* mask, floa
         return MC_OK;
     }
     if (L == 128) hipLaunchKernelGGL((temporal_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-    else if (L == 64) hipLaunchKernelGGL((temporal_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    else if (L == 64 && pair && H % 2 == 0) {       // two parts per workgroup: every wave on the MFMA
+        grid.x = nb * (H / 2);
+        hipLaunchKernelGGL((temporal_k<64, false, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    } else if (L == 64) hipLaunchKernelGGL((temporal_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
     else if (L == 32) hipLaunchKernelGGL((temporal_k<32, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
     else { mc_set_error("temporal: latent_dim=%d unsupported (32, 64, 128)", L); return MC_ERR_ARG; }
     MC_LAUNCH_CHECK();

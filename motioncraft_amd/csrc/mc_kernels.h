@@ -147,4 +147,5 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 // samples [b0, b0 + nb) of the CFG-doubled batch (B = samples per CFG half)
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
                        int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag = nullptr,
-                       long lsplit_max = 96);    // up to this many (sample, part) workgroups the output columns are sliced over blockIdx.y
+                       long lsplit_max = 96,     // up to this many (sample, part) workgroups the output columns are sliced over blockIdx.y
+                       bool pair = false);       // L = 64, even H, beyond lsplit_max: two adjacent parts per workgroup

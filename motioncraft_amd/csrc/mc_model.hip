@@ -71,8 +71,9 @@ struct McOptions {
     // 18 (round 4) the fused expert / SFFN MLPs (fp32 and fp16, L = 128 / 64) stage their weight chunks by LDS-DMA (mlp2d_k / mlp2hd_k; same bits)
     // 19 (round 4) mc_sample_loop: the sampler update also writes x_{t-1} at the padded stride of the next step's pose-encoder GEMM
     // 20 (round 4) reduced-precision contexts: temporal linear attention on the fp16 MFMA (temporal_h_k)
+    // 22 (round 4) L = 64 models: temporal_k takes two adjacent parts per workgroup (all four waves on the MFMA)
     // 21 (round 4) large batches: the folded decoder tail with the CFG combination in its A staging, one pass over both K groups (gemm_tail_k)
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21);     // (all but bit 3)
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22);     // (all but bit 3)
     long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
@@ -648,7 +649,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         if ((r = mc_launch_temporal_h(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), tnb, c->B, c->T, g.max_text_len, H, L,
                                       c->prec == MC_PREC_F16X3, stt, twin_flag))) return r;
     } else if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), tnb, c->B, c->T,
-                                       g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split))) return r;
+                                       g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split, chain_on(c, 22)))) return r;
     if (stt != s) MC_HIP(hipEventRecord(c->ev_join, stt));
     if (st != s) MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
     return MC_OK;

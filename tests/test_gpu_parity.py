@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 4194295        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
+DEFAULT_CHAIN = 8388599        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
@@ -603,7 +603,7 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [4194295 & ~7, 4194295])
+@pytest.mark.parametrize('chain', [8388599 & ~7, 8388599])
 def test_generic_fallback_path_vs_oracle(chain):
     """chain mask with bits 0-2 cleared: the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
@@ -1677,6 +1677,37 @@ def test_fused_proj_qkv_body_kernel_at_latent_64_vs_the_separate_kernels():
     e_ys, e_out = maxabs(hgot['fused'][1], hgot['separate'][1]), maxabs(hgot['fused'][0], hgot['separate'][0])
     print(f'L = 64, f16x3: |ys fused - separate| {e_ys:.2e}, |x0| {e_out:.2e}; |x0 f16x3 - x0 f32| {maxabs(hgot["fused"][0], got["fused"][0]):.2e}')
     assert e_ys <= 1e-5 and e_out <= 1e-4 and maxabs(hgot['fused'][0], got['fused'][0]) <= 2e-4
+    nm.close()
+
+
+def test_temporal_attention_two_parts_per_workgroup_at_latent_64():
+    """temporal_k<64, PAIR> (round 4, chain bit 22: one workgroup owns two adjacent body parts of a sample, so that all four waves carry
+    MFMA tiles at L = 64) against the one-part form on the same mf / text rows: y_t of base layer 0 within fp32 round-off (the column
+    statistics are combined over 8 instead of 16 row slices), ragged lengths, the masked-text half included; x0 of the step as well."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = W.default_dims(L=64, F=256, max_seq_len=24)
+    nm = NativeModel(dims, W.make_state_dict(dims, 5), cfg_scale=dims['scale'])
+    B, T = 3, 24
+    x, xf, mask = synth_inputs(dims, B, T, seed=10, lengths=[24, 15, 7])
+    got = {}
+    for tag, chain in (('pair', DEFAULT_CHAIN), ('single', DEFAULT_CHAIN & ~(1 << 22))):
+        ctx = nm.context(B, T, max_steps=1)
+        ctx.set_option('big_tokens', 0)
+        ctx.set_option('temporal_split', 0)
+        ctx.set_option('chain', chain)
+        ctx.set_timesteps([620])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out = ctx.denoise(x.cuda(), 0).clone()
+        ctx.denoise(x.cuda(), 0, stop_after_layers=1)
+        torch.cuda.synchronize()
+        got[tag] = (out, ctx.buffer('yt').clone(), ctx.buffer('mf').clone())
+        ctx.close()
+    assert torch.equal(got['pair'][2], got['single'][2])
+    scale = float(got['single'][1].abs().max())
+    e, e0 = maxabs(got['pair'][1], got['single'][1]), maxabs(got['pair'][0], got['single'][0])
+    print(f'L = 64 temporal attention, two parts per workgroup: |dy_t| {e:.2e} (|y_t| max {scale:.2f}), |dx0| {e0:.2e}')
+    assert bool(torch.isfinite(got['pair'][1]).all()) and e <= 2e-6 * max(scale, 1.0) and e0 <= 1e-4
     nm.close()
 
 
