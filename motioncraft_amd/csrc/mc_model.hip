@@ -74,7 +74,9 @@ struct McOptions {
     // 22 (round 4) L = 64 models: temporal_k takes two adjacent parts per workgroup (all four waves on the MFMA)
     // 21 (round 4) large batches: the folded decoder tail with the CFG combination in its A staging, one pass over both K groups (gemm_tail_k)
     int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22);     // (all but bit 3)
-    long small_gemm_rows = 6400;       // plain GEMMs of up to this many rows take the small-M kernels
+    long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
+                                       // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
+                                       // S2G at 32 per GPU 27.65 -> 27.14; at 4704 rows (B=24) the small kernels still do, 7.85 vs 7.91)
     long split_rows_expert = 2048, split_rows_sffn = 8192;      // residual rows up to which the fused MLPs split their hidden dimension
     long temporal_split = 96;          // (sample, part) workgroups up to which temporal_k slices its output columns
     long big_tokens = 65536;           // above this many motion tokens: the large-batch schedule (two sample groups on two streams, projqkv / pqbody)
