@@ -170,7 +170,7 @@ int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy);
  * meaning only seed the defaults of contexts created afterwards; two contexts of one process may differ.  Keys:
  *   "chain" (bit mask), "big_tokens", "split_groups", "small_gemm_rows", "split_rows_expert",
  *   "split_rows_sffn", "split_expert", "split_sffn", "temporal_split", "rowchain_split", "gemm_tune", "small_tile_n",
- *   "gemm_wp_grid", "half_min_rows", "gate_small", "route_reg", "route_small", "route_coop".
+ *   "gemm_wp_grid", "half_min_rows", "gate_small", "route_reg", "route_small", "route_coop", "route_per".
  * Results never depend on them beyond fp32 summation order where DESIGN.md says so.  Unknown key -> MC_ERR_ARG.
  * Not while a captured graph exists (mc_ctx_graph_release first). */
 int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value);

@@ -116,6 +116,7 @@ struct RouteBufs {
     int max_tiles;
     uint32_t tie_xor = 0xFFFFFFFFu;   // order of equal-importance tokens at the capacity cut: ~0 = lower index first (stable), 0 = higher first
     bool coop = true;                 // larger batches: the cooperative one-launch routing kernel (false: the 12-launch sequence; env MC_ROUTE_COOP=0, tests)
+    int coop_per = 0;                 // route_coop_k: (token, choice) pairs per thread, 10 or 16 (0: 10 up to 256 workgroups, 16 beyond; option "route_per")
     long small_pairs = -1;            // >= 0: overrides MC_ROUTE_SMALL for this context (tests force the large-batch paths on small configs)
     bool reg_kernel = true;           // small batches: the register-resident one-workgroup routing kernel (false: the L2-streaming form at every size; env MC_ROUTE_REG=0, tests)
 };

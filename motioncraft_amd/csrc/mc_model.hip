@@ -1159,6 +1159,7 @@ int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value) {
     else if (k == "split_expert") c->split_expert = (int)value;
     else if (k == "split_sffn") c->split_sffn = (int)value;
     else if (k == "route_reg") c->rb.reg_kernel = value != 0;
+    else if (k == "route_per") { MC_REQUIRE(value == 0 || value == 10 || value == 16, "route_per: 0 (default), 10 or 16"); c->rb.coop_per = (int)value; }
     else if (k == "route_small") { MC_REQUIRE(value <= 131072, "route_small: the one-workgroup kernels hold at most 131072 pairs"); c->rb.small_pairs = value; }
     else if (k == "route_coop") {
         // off: give the reservation back; on: only if the grid can be reserved now

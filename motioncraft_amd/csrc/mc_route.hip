@@ -388,13 +388,13 @@ __device__ __forceinline__ bool grid_sync(int* bar, int nwg, int* s_last, int* s
 constexpr int COOP_PER = 10;
 constexpr long COOP_MAX_WG = 512;      // grid limit of route_coop_k: 1.31 M (token, choice) pairs (B <= 139 at 196 frames; M2D 160 windows x 120 frames = 921 600);
                                        // round 3: was 256 -- beyond it the 12-launch sequence ran (M2D: 196 us per routing instead of ~50)
+template <int PER>      // (token, choice) pairs per thread, register resident: 10, or 16 for fewer workgroups at the same pair count
 __global__ __launch_bounds__(256) void route_coop_k(const int* __restrict__ idx, const float* __restrict__ gate,
                                                     const uint32_t* __restrict__ key, long N, long Nsrc, long gsplit, int E,
                                                     int capacity, int cnt_mul, float* __restrict__ comb_w, int* state,
                                                     int* __restrict__ src_row, int* __restrict__ dst_row,
                                                     int* __restrict__ tile_group, int* __restrict__ tile_row0,
                                                     int* __restrict__ tile_nrows, int max_tiles, uint32_t tie_xor, int skip_mid) {
-    constexpr int PER = COOP_PER;
     __shared__ int h[MAXP * 256];
     __shared__ int s_act[MAXP];
     __shared__ unsigned long long s_pre[MAXP];
@@ -968,7 +968,7 @@ int mc_route_coop_slots(int dev) {
     if (v > 0) return v;
     int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, route_coop_k, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, route_coop_k<COOP_PER>, 256, 0) != hipSuccess ||
         hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     if (per_cu > 8) per_cu = 8;                    // (hardware admits at most 8 256-thread blocks per CU: MI355X_MICROARCH.md, residency)
     v = per_cu * prop.multiProcessorCount;
@@ -1023,10 +1023,16 @@ int mc_launch_route(long N, long Nsrc, long gsplit, int E, int capacity, RouteBu
         return MC_OK;
     }
     if (rb.coop && 2 * N <= COOP_MAX_WG * 256 * COOP_PER) {
-        const int nwg = cdiv(2 * N, 256L * COOP_PER);
-        hipLaunchKernelGGL(route_coop_k, dim3(nwg), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity, (int)(N / Nsrc),
-                           rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows, rb.max_tiles, rb.tie_xor,
-                           N <= 65536 ? 1 : 0);
+        // pairs per thread: 10 while that is at most one workgroup per CU (<= 256; B=64 at 196 frames: 236 workgroups, 45 us either way --
+        // the ~6 grid barriers set the time), 16 beyond (M2D at 160 windows per GPU: 360 -> 225 workgroups, 88 -> 80 us per routing)
+        const int per = rb.coop_per == 10 || rb.coop_per == 16 ? rb.coop_per : (cdiv(2 * N, 256L * COOP_PER) > 256 ? 16 : 10);
+        const int nwg = cdiv(2 * N, 256L * per);              // (<= the PER = 10 count the context reserved)
+#define MC_ROUTE_COOP(P)                                                                                                             \
+    hipLaunchKernelGGL(route_coop_k<P>, dim3(nwg), dim3(256), 0, s, rb.idx, rb.gate, rb.key, N, Nsrc, gsplit, E, capacity, (int)(N / Nsrc), \
+                       rb.comb_w, rb.state, rb.src_row, rb.dst_row, rb.tile_group, rb.tile_row0, rb.tile_nrows, rb.max_tiles, rb.tie_xor,  \
+                       N <= 65536 ? 1 : 0)
+        if (per == 16) MC_ROUTE_COOP(16); else MC_ROUTE_COOP(10);
+#undef MC_ROUTE_COOP
         MC_LAUNCH_CHECK();
         return MC_OK;
     }
