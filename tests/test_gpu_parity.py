@@ -937,22 +937,27 @@ def test_hipgraph_replay_of_the_sampler_step_is_bit_identical(prec):
         nm.close()
 
 
-def test_one_pass_decoder_tail_equals_combine_plus_grouped_gemm():
+@pytest.mark.parametrize('arch', ['motionx_322', 'humanml3d_263'])
+def test_one_pass_decoder_tail_equals_combine_plus_grouped_gemm(arch):
     """gemm_tail_k (round 4, chain bit 21: the folded decoder tail of the large-batch schedule with the CFG combination formed in its A
     staging and both K groups in one accumulator) against axpby_pair_k + the grouped gemm_small16_k + the sum in the sampler kernel:
     x0 and x_(t-1) of two DDIM steps within fp32 round-off of the other accumulation order (the operands are the same values).  0.125b
     widths at B=3 x 24 frames (72 rows: a ragged second row tile; N = 322: a ragged seventh column tile), pushed onto the kernel with
-    small_gemm_rows = 0.  Under hipGraph replay the CFG weights come from the device table: replay must equal eager bit for bit."""
+    small_gemm_rows = 0.  Under hipGraph replay the CFG weights come from the device table: replay must equal eager bit for bit.
+    Second architecture: HumanML3D widths (263 features in 6 column tiles, 8 parts x 64, D = 512) at 25 frames -- 75 rows and
+    B*T*C % 4 != 0, so the sampler update runs its element-wise form; there the two steps are also walked as ONE mc_sample_loop call
+    (the sampler update of step 1 writes step 0's padded pose-encoder operand, 263 -> 288 columns) and must equal the per-step walk
+    bit for bit."""
     from motioncraft_amd.diffusion import build_diffusion
     from motioncraft_amd.engine import NativeModel
     from oracle import weights as W
-    dims = FULL
+    dims = FULL if arch == 'motionx_322' else HML_FULL
     nm = NativeModel(dims, W.make_state_dict(dims, 4), cfg_scale=dims['scale'])
     d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large',
                              respace='2'))
     S = d.num_timesteps
-    B, T = 3, 24
-    x_T, xf, mask = synth_inputs(dims, B, T, seed=9, lengths=[24, 17, 12])
+    B, T = (3, 24) if arch == 'motionx_322' else (3, 25)
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=9, lengths=[T, 17, 12])
     coefs = [d.step_coefs(i, 'ddim', dims['scale']) for i in range(S)]
     noise = torch.randn(B, T, dims['input_feats'], generator=torch.Generator().manual_seed(3)).cuda()
     got = {}
@@ -981,6 +986,17 @@ def test_one_pass_decoder_tail_equals_combine_plus_grouped_gemm():
     print(f'one-pass tail vs combine + grouped GEMM: |dx_prev| {e_x:.2e}, |dx0| {e_x0:.2e} (|x0| max {float(got["grouped"][1].abs().max()):.2f})')
     assert bool(torch.isfinite(got["one_pass"][0]).all()) and e_x <= 6e-5 and e_x0 <= 6e-5
     assert torch.equal(got['one_pass'][0], got['one_pass_graph'][0])
+    if arch != 'motionx_322':
+        ctx = nm.context(B, T, max_steps=S)
+        ctx.set_option('small_gemm_rows', 0)
+        ctx.set_timesteps(d.timestep_map)
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        x = x_T.cuda().clone()
+        order = list(range(S - 1, -1, -1))
+        ctx.sample_loop(x, order, [coefs[i] for i in order], noise=torch.stack([noise] * S))
+        torch.cuda.synchronize()
+        assert torch.equal(x, got['one_pass'][0]), maxabs(x, got['one_pass'][0])
+        ctx.close()
     nm.close()
 
 
