@@ -78,6 +78,51 @@ def algorithmic_flops_per_sample_step(d, T):
     return 2 * d['NL'] * layer + T * 2 * 644 * L + 2 * T * 2 * 644 * L
 
 
+def executed_flops_per_sample_step(d, T):
+    """FLOPs the kernels actually LAUNCH per sample and step (useful MFMA work, tile padding not counted), against the reference's count
+    above: base layer 0 runs gate / experts / proj / q,k,v / body topology for ONE CFG half (twin dedupe), the last StylizationBlock
+    Linear + pose decoder run once on the CFG-combined rows as one [322, 2D] product (folded tail), the pose encoder / decoder are dense
+    [D, 324] / [322, D] products of the packed weights instead of the reference's per-part ones (more FLOPs, one GEMM)."""
+    L, H, F, Nt, E = d['L'], d['H'], d['F'], d['Nt'], d['E']
+    D = L * H
+    TH = T * H
+    front = (TH * (2 * L * 256 + 2 * 256 * E) + TH * d['topk'] * 16 * L * L + TH * 8 * L * L + T * 2 * H * H * L
+             + TH * 6 * L * L + T * 8 * (2 * 12 * (L // 8) ** 2) * 2)                 # gate, experts, proj, static topology, q/k/v, dynamic topology
+    temporal = H * (2 * (Nt + T) * L * L + 2 * T * L * L)
+    film = T * 2 * D * D
+    sffn = TH * 4 * L * F
+    total = T * 2 * 324 * D                                  # pose encoder, written to both halves by one GEMM
+    for i in range(d['NL']):
+        total += (1 if i == 0 else 2) * front + 2 * (temporal + film + sffn)
+        total += 0 if i == d['NL'] - 1 else 2 * film          # the SFFN's FiLM Linear; the last one is folded into the tail
+    return total + T * 2 * 322 * 2 * D                        # folded tail on the combined rows
+
+
+def lone_dominant_kernel():
+    """The dominant kernel's LONE-launch figure (serial single-stream schedule, so a launch's duration is the kernel's own): read from the
+    newest tracked profiles/rNN_kernel_roofline.txt (tools/kernel_roofline.py over the rocprofv3 --pmc pass; its header carries the
+    commit).  HIP events around in-step launches of the two-stream schedule measure the overlap, not the kernel."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_roofline.txt')))
+    if not files:
+        return None
+    src, commit, row = files[-1], None, None
+    for line in open(src):
+        mc_ = re.match(r'# commit (\S+)', line)
+        if mc_:
+            commit = mc_.group(1)
+        if row is None and line.startswith('gemm_wp_k'):
+            row = line.split()
+    if not row:
+        return None
+    return {'kernel': 'gemm_wp_k (fp32 MFMA 32x32x2, wave-private LDS-DMA ring): FiLM out_layers GEMMs h += a W^T + b (stylization_block.py:39) + pose encoder',
+            'avg_us': float(row[3]), 'gflop_per_launch': float(row[4]), 'achieved': float(row[5]), 'frac': round(float(row[6]) / 100, 4),
+            'mfma_util_pct': float(row[7]), 'clock_ghz': float(row[8]),
+            'source': os.path.relpath(src, ROOT) + (f' @ commit {commit}' if commit else ''),
+            'how': 'lone whole-batch launches of the serial schedule, rocprofv3 --kernel-trace --pmc pass (duration and counters of the same dispatches)'}
+
+
 def synth_condition(B, seed):
     g = torch.Generator().manual_seed(seed)
     xf = torch.nn.functional.layer_norm(torch.randn(B, DIMS['Nt'], DIMS['Dt'], generator=g), (DIMS['Dt'],))
@@ -279,26 +324,9 @@ def main():
     t_gather = time.perf_counter() - t0
     assert out.shape[0] == GB and bool(torch.isfinite(out).all())
 
-    # ---- dominant kernel, measured IN the step: HIP events around every FiLM out_layers GEMM launch (h += a W^T + b,
-    # stylization_block.py:39) on the stream it is launched on, over 8 steps after the timed region (mc_ctx_profile; the
-    # rocprofv3 --kernel-trace --stats table of this command is profiles/r03_kernel_stats_b64.txt) ----
-    dom = None
-    if rank == 0 and not a.no_extras:
-        D = DIMS['L'] * DIMS['H']
-        ctx.profile(True)
-        for j in range(8):
-            one_step(500 + j)
-        torch.cuda.synchronize()
-        us, cnt, gf = ctx.profile_read()
-        ctx.profile(False)
-        if cnt:
-            tf = gf / us * 1e3          # GFLOP / us = PFLOP/s
-            dom = {'kernel': 'gemm_wp_k (fp32 MFMA, wave-private LDS-DMA pipeline): the FiLM out_layers GEMMs h += a W^T + b as the step '
-                             f'launches them (one launch per sample group: {int(round(gf * 1e9 / (2 * D * D)))} rows x {D} x {D}, bias + residual)',
-                   'launches_timed': cnt, 'avg_us': round(us, 1), 'gflop_per_launch': round(gf, 2), 'achieved': round(tf, 2),
-                   'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                   'how': 'HIP events on the launch stream around each in-step launch (the two sample groups overlap on two streams, so a '
-                          "launch's interval includes the other group's kernels sharing the CUs)"}
+    # ---- dominant kernel: the lone-launch figure of the newest tracked rocprofv3 table (profiles/rNN_kernel_roofline.txt); in-step HIP events
+    # would time the overlap of the two sample groups, not the kernel ----
+    dom = lone_dominant_kernel() if rank == 0 else None
 
     # ---- side measurement (NOT `value`): two independent batches of B in flight on this GPU, one HIP stream and one
     # context each -- what a test loop over many batches of 64 can do; each batch keeps its own MoE capacity domain ----
@@ -428,6 +456,16 @@ def main():
                     gs.synchronize()
                     ts4.append(time.perf_counter() - t0)
                 assert bool(torch.isfinite(x4).all()), 'configs[4] loop produced non-finite poses'
+                # what the replays compute is checked where it is measured: one more replayed step against an EAGER mc_sample_step from the
+                # same x_t (same large-batch two-stream schedule) must give the same bits (tests/test_gpu_parity.py::
+                # test_configs4_as_benched_large_batch_graph_replay_and_lockstep holds the same shape against the oracle)
+                x4.normal_(generator=gen)
+                xs4 = x4.clone()
+                c4.graph_step(7)
+                gs.synchronize()
+                xe4 = c4.sample_step(xs4, 7, k50[7], n4)
+                gs.synchronize()
+                assert torch.equal(x4, xe4), 'configs[4]: hipGraph replay differs from the eager step'
                 t4 = sorted(ts4[1:])[1]
                 ach4 = fl4 * B4 * 50 / t4 / 1e12
                 configs4[prec] = {'loop_ms': round(t4 * 1e3, 2), 'ms_per_step': round(t4 * 20, 3), 'frames_per_s': round(B4 * T / t4, 1),
@@ -437,6 +475,9 @@ def main():
                 c4.graph_release()
                 c4.close()
         nm4.close()
+        configs4['replay_equals_eager_step'] = True      # asserted above, per mode
+        configs4['plain_f16_caveat'] = ('`f16` (one fp16 rounding per operand) is OUTSIDE the north-star 1e-3 tolerance on the x0 prediction (8e-3 at the '
+                                        'CFG weights of t = 640; include/motioncraft_amd.h) and meets it per sampler step only; `f16x3` meets every fp32 bound')
         configs4['note'] = ('side measurement, not `value`: median of 3 complete loops after a warm-up loop; gate / routing / normalisations / softmaxes '
                             'stay fp32 in both modes, so the fp16 MFMA ceiling bounds only the GEMM-shaped ~95 % of the FLOPs')
 
@@ -521,7 +562,12 @@ def main():
                                            'Linear + affine pose decoder run once on the CFG-combined rows; FLOPs in `roofline` are '
                                            'counted as the reference performs them (DESIGN.md section 4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic_gb if (B, T) == (64, 196) else None,
+                         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'executed_frac': round(executed_flops_per_sample_step(DIMS, T) * B / (ev_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'executed_gflop_per_sample_step': round(executed_flops_per_sample_step(DIMS, T) / 1e9, 3),
+                         'frac_note': '`frac` counts FLOPs as the reference performs them (SURVEY.md section 8d); `executed_frac` counts what the kernels '
+                                      'launch after the exact reductions (CFG twin dedupe of base layer 0, folded decoder tail)',
+                         'traffic': traffic_gb if (B, T) == (64, 196) else None,
                          'algorithmic_bytes': round(alg_gb, 3),
                          'algorithmic_bytes_unit': 'GB per step (SURVEY.md section 8d): fp32 weights streamed once (0.512) + the residual stream h '
                                                    '[2B,T,D] once per fused kernel, 6 per layer + the sampler update 5 B T 322 floats',

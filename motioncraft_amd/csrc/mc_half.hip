@@ -1294,6 +1294,7 @@ int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const m
     MC_REQUIRE((g.L == 128 || g.L == 64) && H == 12, "fp16 pqbody: L=%d H=%d unsupported (128 / 64, 12)", g.L, H);
     MC_REQUIRE(g.Nout == 4 * g.L && g.ldy == 4 * g.L && g.bias && g.bias2 && g.wsm && g.ys && Wph && Wqh && (!split || (Wpl && Wql)),
                "fp16 pqbody: bad arguments");
+    MC_REQUIRE(g.pad_row >= g.N, "fp16 pqbody: pad_row (128 padding rows of Y behind the last token) not set");
     MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "fp16 pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv((g.N - g.tok0) / H, 128 / H));

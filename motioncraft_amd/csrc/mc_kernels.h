@@ -59,6 +59,7 @@ int mc_launch_philox_fill(float* out, uint32_t* bits, long n, RngArgs rng, hipSt
 int mc_launch_cfg_combine_tab(const float* x, const float* y, const SamplerCoefs* table, const int* step_ptr, float* out, long n,
                               hipStream_t s);
 int mc_launch_set_int(int* dst, int value, hipStream_t s);
+int mc_launch_spin(long ticks, hipStream_t s);      // tests: hold stream s for `ticks` of the 100 MHz wall clock
 
 // RePaint / outpainting (gaussian_diffusion.py:492-501, 855-877)
 struct InpaintArgs {

@@ -444,6 +444,11 @@ __global__ __launch_bounds__(256) void axpby_pair_k(AxpbySet s0, AxpbySet s1, fl
 }
 
 __global__ void set_int_k(int* dst, int value) { *dst = value; }
+// tests only: hold a stream for `ticks` of the 100 MHz s_memtime counter (one lane; mc_ctx_set_option("dbg_delay_us"))
+__global__ void spin_k(long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 
 }  // namespace
 
@@ -549,6 +554,11 @@ int mc_launch_axpby_pair(const float* x0, const float* y0, float* out0, const fl
     return MC_OK;
 }
 
+int mc_launch_spin(long ticks, hipStream_t s) {
+    hipLaunchKernelGGL(spin_k, dim3(1), dim3(1), 0, s, ticks);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
 int mc_launch_set_int(int* dst, int value, hipStream_t s) {
     hipLaunchKernelGGL(set_int_k, dim3(1), dim3(1), 0, s, dst, value);
     MC_LAUNCH_CHECK();

@@ -117,6 +117,11 @@ struct mc_ctx {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     float *h, *z, *proj, *hbuf, *y2, *mf, *qkv, *ys, *yt, *a, *z2, *fh, *out2, *xpad;
+    // reduced-precision contexts: the fp32 rows of the DEFERRED last FiLM block (defer_last_gemm) get their own array -- `a` holds the
+    // fp16 hi | lo planes of BOTH sample groups there, and fp32 rows written into it by one group's stream would land on the plane rows
+    // the other group's gemm_hd_k may still be reading; null in fp32 contexts (then `a` itself holds fp32 rows only)
+    float* a_tail = nullptr;
+    long dbg_delay_us = 0;       // tests (option "dbg_delay_us"): hold the SECOND sample group's stream this long in front of every layer tail, so the groups run far out of phase
     size_t hbuf_cap = 0;        // floats allocated behind hbuf
     size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
     bool cnt_clean = false;     // the routing state's (choice, expert) counts are known to be zero on the stream (route_small_k cleans up after itself)
@@ -509,6 +514,9 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     return mc_launch_gemm(GM_COMB, p, 1, 0, s);
 }
 
+// the array the deferred last FiLM block's fp32 rows live in (read back by denoise_combined)
+static float* deferred_a(const mc_ctx* c) { return c->a_tail ? c->a_tail : c->a; }
+
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
@@ -522,9 +530,11 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     // reduced-precision contexts: `a` is consumed by the fp16-MFMA GEMM only -> written as fp16 planes (hi [rows][D] | lo) into the same
     // buffer: the rows of this range start at halves offset o, the lo plane sits rows * D halves behind the hi plane
     const bool half_gemm = !prologue_only && hw && hw->hi && use_half(c);
-    const bool planes = half_gemm && chain_on(c, 17) && D % 64 == 0;
+    // (the plane path's launcher needs N % 128 == 0, K % 64 == 0 and 32-bit byte offsets into a plane: anything else stays on dense_h)
+    const bool planes = half_gemm && chain_on(c, 17) && D % 128 == 0 && c->rows * D * 2 < (1L << 31);      // (one answer per context: plane rows and fp32 rows never share `a`)
     const long pstride = c->rows * D;
-    float* a_out = planes ? reinterpret_cast<float*>(reinterpret_cast<mc_half*>(c->a) + o) : c->a + o;
+    float* a_rows = prologue_only ? deferred_a(c) : c->a;
+    float* a_out = planes ? reinterpret_cast<float*>(reinterpret_cast<mc_half*>(c->a) + o) : a_rows + o;
     if ((r = mc_launch_film_rows(y1_parts > 1 ? y1 : y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, a_out, nrows, D, s, y1_alias, row0, sref,
                                  y1_parts, nrows * D, planes ? (c->prec == MC_PREC_F16X3 ? 2 : 1) : 0, pstride))) return r;
     if (prologue_only) return MC_OK;
@@ -848,8 +858,10 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
                 for (int j = 1; j < c->nparts; ++j) MC_HIP(hipStreamWaitEvent(c->parts[j - 1], c->ev_join, 0));
             }
         }
-        for (int k = 0; k < c->nparts; ++k)
+        for (int k = 0; k < c->nparts; ++k) {
+            if (k == 1 && c->dbg_delay_us > 0 && (r = mc_launch_spin(c->dbg_delay_us * 100, part_stream(c, k, s)))) return r;
             if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+        }
         if (split == 1 && (r = parts_join(c, s))) return r;
         return MC_OK;
     }
@@ -857,6 +869,20 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     const bool side_temporal = c->side && (chain_on(c, 3) || c->N <= c->opt.big_tokens);
     if ((r = layer_rows(c, i, hs, step, twin, 0, 2 * half, s, side_temporal ? c->side : s))) return r;
     return layer_rows_tail(c, i, hs, step, twin, 0, 2 * half, s);
+}
+
+// The largest grid any routing call of this context can launch cooperatively (mc_ctx_create and mc_ctx_set_option("route_coop") share
+// it): the motion MoE routes N tokens, the text MoE (mc_ctx_set_condition) Ntxt -- either may be the one inside route_coop_k's size
+// range; sizes in the one-workgroup regime or beyond the kernel's range need nothing.  Counted at 10 pairs per thread, the larger of
+// the two grids the launch may pick.
+int coop_grid_needed(const mc_ctx* c) {
+    const long small = c->rb.small_pairs >= 0 ? c->rb.small_pairs : -1;
+    int nwg = 0;
+    for (long n : {c->N, c->Ntxt}) {
+        const bool one_wg = small >= 0 ? 2 * n <= small : mc_route_is_small(n);
+        if (!one_wg && mc_route_coop_wgs(n) > nwg) nwg = mc_route_coop_wgs(n);
+    }
+    return nwg;
 }
 
 }  // namespace
@@ -1031,12 +1057,7 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     // the one-workgroup regime or beyond the kernel's range) or no room -> coop off for the context, so no unreserved grid can launch.
     MC_HIP(hipGetDevice(&c->device));
     if (c->rb.coop) {
-        const long small = c->rb.small_pairs >= 0 ? c->rb.small_pairs : -1;
-        int nwg = 0;
-        for (long n : {c->N, c->Ntxt}) {
-            const bool one_wg = small >= 0 ? 2 * n <= small : mc_route_is_small(n);
-            if (!one_wg && mc_route_coop_wgs(n) > nwg) nwg = mc_route_coop_wgs(n);
-        }
+        const int nwg = coop_grid_needed(c);
         if (nwg > 0 && mc_route_coop_reserve(c->device, nwg)) c->coop_reserved = nwg;
         else c->rb.coop = false;
     }
@@ -1131,6 +1152,7 @@ int mc_ctx_set_precision(mc_ctx* c, int32_t precision) {
     if (precision != MC_PREC_F32) {
         int r = bind_half_weights(c);
         if (r != MC_OK) return r;
+        if (!c->a_tail && (r = ws_alloc(c, &c->a_tail, (size_t)c->rows * c->m->cfg.latent_dim * c->m->cfg.num_parts)) != MC_OK) return r;
     }
     c->prec = precision;
     return MC_OK;
@@ -1155,6 +1177,7 @@ int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value) {
     else if (k == "small_tile_n") o.small_tile_n = (int)value;
     else if (k == "gemm_wp_grid") o.gemm_wp_grid = (int)value;
     else if (k == "half_min_rows") c->half_min_rows = value;
+    else if (k == "dbg_delay_us") { MC_REQUIRE(value >= 0 && value <= 100000, "dbg_delay_us: 0 .. 100000"); c->dbg_delay_us = value; }
     else if (k == "gate_small") c->gate_small_tokens = value;
     else if (k == "split_expert") c->split_expert = (int)value;
     else if (k == "split_sffn") c->split_sffn = (int)value;
@@ -1167,12 +1190,10 @@ int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value) {
             if (c->coop_reserved) { mc_route_coop_release(c->device, c->coop_reserved); c->coop_reserved = 0; }
             c->rb.coop = false;
         } else if (!c->rb.coop) {
-            int nwg = 0;
-            for (long n : {c->N, c->Ntxt})
-                if (mc_route_coop_wgs(n) > nwg) nwg = mc_route_coop_wgs(n);
-            MC_REQUIRE(nwg > 0 && mc_route_coop_reserve(c->device, nwg), "route_coop: the cooperative routing grid cannot be reserved on this device");
+            const int nwg = coop_grid_needed(c);       // 0: no routing call of this context is in route_coop_k's size range (nothing to switch on)
+            MC_REQUIRE(nwg == 0 || mc_route_coop_reserve(c->device, nwg), "route_coop: the cooperative routing grid cannot be reserved on this device");
             c->coop_reserved = nwg;
-            c->rb.coop = true;
+            c->rb.coop = nwg > 0;
         }
     } else if (k == "split_groups") {
         MC_REQUIRE(value >= 2 && value <= 4 && value <= 2 * c->B, "split_groups: 2..4 groups of whole samples (batch %d)", c->B);
@@ -1395,7 +1416,7 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
     if (defer && c->dec_cat_w && chain_on(c, 11) && chain_on(c, 21) && BT > c->opt.small_gemm_rows && D % 32 == 0) {
         // large batches: CFG combination, both K groups and the biases in ONE GEMM pass (gemm_tail_k): no axpby_pair_k, no partial outputs
         TailArgs t;
-        t.H = c->h; t.Af = c->a; t.half = BT * D; t.lda = D;
+        t.H = c->h; t.Af = deferred_a(c); t.half = BT * D; t.lda = D;
         t.W = c->dec_cat_w; t.ldw = D; t.w_gstride = (long)C * D; t.bias = c->dec_cat_b; t.b_gstride = C;
         t.C = c->out2; t.ldc = C; t.M = (int)BT; t.N = C; t.K = D;
         t.wc = k->text_coef; t.wu = k->none_coef;
@@ -1412,7 +1433,7 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
     }
     if (defer && c->dec_cat_w && chain_on(c, 11)) {
         // h_c and a_c in one launch
-        if ((r = mc_launch_axpby_pair(c->h, c->h + BT * D, c->z2, c->a, c->a + BT * D, c->z2 + BT * D, k->text_coef, k->none_coef,
+        if ((r = mc_launch_axpby_pair(c->h, c->h + BT * D, c->z2, deferred_a(c), deferred_a(c) + BT * D, c->z2 + BT * D, k->text_coef, k->none_coef,
                                       c->graph_mode ? c->gcoefs : nullptr, c->graph_mode ? c->gstep : nullptr, BT * D, s))) return r;
     } else if ((r = combine(c->h, c->h + BT * D, c->z2))) return r;     // h_c
     if (defer) {
@@ -1432,14 +1453,15 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
             *x0b = c->out2 + BT * C;
             return MC_OK;
         }
-        if ((r = combine(c->a, c->a + BT * D, c->a))) return r;      // a_c
+        float* const ad = deferred_a(c);
+        if ((r = combine(ad, ad + BT * D, ad))) return r;      // a_c
         if (c->dec_wf) {
             if ((r = dense(c, c->z2, D, c->dec_w, D, c->dec_bf, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
-            if ((r = dense(c, c->a, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
+            if ((r = dense(c, ad, D, c->dec_wf, D, nullptr, c->out2, C, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
             *x0a = c->out2;
             return MC_OK;
         }
-        if ((r = dense(c, c->a, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
+        if ((r = dense(c, ad, D, w.ffn_out_w, D, w.ffn_out_b, c->z2, D, c->z2, D, BT, D, D, ACT_NONE, s))) return r;  // h_c += a_c W^T + b
     }
     if ((r = dense(c, c->z2, D, c->dec_w, D, c->dec_b, nullptr, 0, c->out2, C, BT, C, D, ACT_NONE, s))) return r;
     *x0a = c->out2;
@@ -1640,7 +1662,12 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
     else if (n == "y2") { p = c->y2; cnt = c->N * 2 * L; }
     else if (n == "ys") { p = c->ys; cnt = c->rows * D; }
     else if (n == "yt") { p = c->yt; cnt = c->rows * D; }
-    else if (n == "a") { p = c->a; cnt = c->rows * D; }
+    else if (n == "a") {
+        // reduced-precision contexts keep fp16 hi | lo PLANES in `a` (film_block): not the fp32 [rows][D] rows this call promises
+        MC_REQUIRE(!(use_half(c) && chain_on(c, 17) && D % 128 == 0), "buffer 'a' holds fp16 planes in a reduced-precision context (clear chain bit 17 to read fp32 rows)");
+        p = c->a; cnt = c->rows * D;
+    }
+    else if (n == "a_tail") { p = deferred_a(c); cnt = c->rows * D; }
     else if (n == "z2") { p = c->z2; cnt = c->rows * D; }
     else if (n == "out2") { p = c->out2; cnt = c->rows * g.input_feats; }
     else if (n == "emb") { p = c->emb; cnt = (int64_t)c->S * g.time_embed_dim; }

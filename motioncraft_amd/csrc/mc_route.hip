@@ -966,10 +966,13 @@ int mc_route_coop_slots(int dev) {
     if (dev < 0 || dev >= 64) return 0;
     int v = cached[dev].load();
     if (v > 0) return v;
-    int per_cu = 0;
+    int per_cu = 0, per_cu16 = 0;
     hipDeviceProp_t prop;
+    // the launch picks route_coop_k<10> or <16> (another register footprint): admit against the smaller of the two occupancies
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, route_coop_k<COOP_PER>, 256, 0) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, route_coop_k<16>, 256, 0) != hipSuccess ||
         hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (per_cu16 < per_cu) per_cu = per_cu16;
     if (per_cu > 8) per_cu = 8;                    // (hardware admits at most 8 256-thread blocks per CU: MI355X_MICROARCH.md, residency)
     v = per_cu * prop.multiProcessorCount;
     if (const char* e = getenv("MC_ROUTE_COOP_SLOTS")) v = atoi(e) > 0 ? atoi(e) : v;      // (tests: a small capacity exercises the fallback)

@@ -407,7 +407,9 @@ def test_baseline_batch_64_single_step_vs_oracle(full_model, B):
         keep_diff = int(((fkeep != forced[i][1]) & (fidx == forced[i][0])).sum())
         dropped = int((~fkeep).sum())
         print(f'layer {i}: dropped {dropped}, expert-id flips {idx_diff}, keep flips {keep_diff} of {npairs} pairs')
-        assert idx_diff <= 8 and keep_diff <= 8            # observed 0-4 of 602 112 pairs per layer
+        # expert-id flips: the free-running ORACLE disagrees with itself by up to 7 per layer at this size (profiles/r04_oracle_self_divergence.txt);
+        # keep flips: it never does (0 in every variant), and one moves its token by O(1): held to the observed level (0-1 per 7 routings)
+        assert idx_diff <= 8 and keep_diff <= 2, (i, idx_diff, keep_diff)
     ctx.close()
 
 
@@ -483,7 +485,8 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model, prec
             for l in range(FULL['NL']):
                 a, b, dropped = _routing_flips(cap[f'layer{l}']['routing']['free'], forced[l])
                 flips_idx, flips_keep = flips_idx + a, flips_keep + b
-                assert a <= 8 and b <= 8, (i, l, a, b)               # observed 0-4 of 602 112 pairs
+                print(f'  step {i} layer {l}: expert-id flips {a}, keep flips {b}, dropped {dropped} of {npairs} pairs')
+                assert a <= 8 and b <= 2, (i, l, a, b)               # (see test_baseline_batch_64_single_step_vs_oracle)
             assert abs(float(x_c.std()) - float(ref.std())) <= 1e-3 and abs(float(x_c.mean()) - float(ref.mean())) <= 1e-3
             assert e <= TOL_FINAL, (i, e)
         else:
@@ -499,6 +502,49 @@ def test_baseline_b64_ddpm_lockstep_and_complete_1000_step_loop(full_model, prec
           f'final x std {float(x.std()):.3f}')
     assert bool(torch.isfinite(x).all())
     ctx.close()
+
+
+def test_baseline_b64_free_running_envelope_vs_free_running_oracle(full_model):
+    """BASELINE.json configs[1], the other half of the parity argument (north star: "<= 1e-3 abs on the final pose on
+    identical noise seeds"): NOTHING is teacher-forced here.  B=64 x 196 frames, the first 16 steps of the 1000-step DDPM loop
+    (gaussian_diffusion.py:698-797), the same x_T / condition / per-step noise on both sides: the HIP path free-running (one
+    mc_sample_loop call) against `oracle.sample_loop` free-running, each taking its OWN routing decisions.  The inputs are those of
+    tools/oracle_self_divergence.py, so the figure stands beside the oracle-vs-ITSELF envelope of profiles/r04_oracle_self_divergence.txt
+    (the same torch-CPU code at another thread count / another summation order of the gate matmul: 1.7e-4 .. 3.9e-4 over these 16
+    steps): an implementation is inside the reference's own reproducibility when it stays inside that band."""
+    from oracle import stmogen_oracle as O
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = full_model
+    B, T, S, NSTEP = 64, 196, 1000, 16
+    g = torch.Generator().manual_seed(0)
+    x_T = torch.randn(B, T, 322, generator=g)
+    xf = torch.nn.functional.layer_norm(torch.randn(B, FULL['Nt'], FULL['Dt'], generator=g), (FULL['Dt'],))
+    mask = torch.ones(B, T)
+    noise = [torch.randn(B, T, 322, generator=g) for _ in range(NSTEP)]
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=S, model_mean_type='start_x', model_var_type='fixed_large'))
+    ctx = nm.context(B, T, max_steps=S)
+    ctx.set_timesteps(d.timestep_map)
+    ctx.set_condition(xf.cuda(), mask.cuda())
+    order = list(range(S - 1, S - 1 - NSTEP, -1))
+    coefs = [d.step_coefs(i, 'ddpm', FULL['scale']) for i in order]
+    nz = torch.stack(noise).cuda()
+    hip = []
+    x = x_T.cuda()
+    for n in range(NSTEP):            # (one loop call per step only to keep every intermediate x_t; same kernels as one call over all 16)
+        ctx.sample_loop(x, order[n:n + 1], coefs[n:n + 1], noise=nz[n:n + 1])
+        hip.append(x.cpu())
+    ctx.close()
+    torch.set_num_threads(min(32, os.cpu_count()))
+    t0 = time.time()
+    traj = []
+    ref = O.sample_loop(sd, FULL, O.Schedule(S, None), 'ddpm', x_T, xf, mask, step_noise=lambda i: noise[S - 1 - i], num_steps=NSTEP,
+                        trajectory=traj)
+    per_step = [maxabs(hip[n], traj[n][1]) for n in range(NSTEP)]
+    print(f'B=64 free-running HIP vs free-running oracle, {NSTEP} DDPM steps (oracle {time.time() - t0:.0f} s): max|x_hip - x_oracle| per step '
+          + ' '.join(f'{e:.1e}' for e in per_step) + f'; final {per_step[-1]:.2e} (oracle vs itself: 1.7e-4 .. 3.9e-4, profiles/r04_oracle_self_divergence.txt)')
+    assert bool(torch.isfinite(hip[-1]).all())
+    assert max(per_step) <= TOL_FINAL, per_step
+    assert maxabs(hip[-1], ref) <= TOL_FINAL
 
 
 @pytest.mark.parametrize('case', ['s2g_b32', 'm2d_160_windows'])
@@ -539,7 +585,8 @@ def test_baseline_control_configs_at_their_per_gpu_batches_vs_oracle(case):
     for slot in range(NL + copy):
         a, b, dropped = _routing_flips(cap['routing'][slot]['free'], forced[slot])
         tot_i, tot_k = tot_i + a, tot_k + b
-        assert a <= 8 and b <= 8, (slot, a, b)
+        print(f'  {case} slot {slot}: expert-id flips {a}, keep flips {b}, dropped {dropped}')
+        assert a <= 8 and b <= 2, (slot, a, b)
     print(f'{case}: B={B} T={T} NL={NL}+{copy}: |hip - oracle (teacher-forced)| {err:.2e}; expert-id flips {tot_i}, keep flips '
           f'{tot_k} over {NL + copy} routings of {2 * 2 * B * T * dims["H"]} pairs')
     assert err <= TOL_FINAL
@@ -884,6 +931,91 @@ def test_fp16_mfma_large_batch_kernels_single_step_vs_oracle(full_model):
         print(f'B=16 single step, precision {prec}: |hip - fp32 oracle (teacher-forced)| x0 {err:.2e}, x_(t-1) {err_prev:.2e}')
         assert err <= tol and err_prev <= TOL_FINAL, (prec, err, err_prev)
         ctx.close()
+
+
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+def test_configs4_as_benched_large_batch_graph_replay_and_lockstep(prec):
+    """BASELINE.json configs[4] AT THE SHAPE bench.py REPORTS (`config.configs4`): 0.125b + 2 control copies, batch 32 x 196 frames
+    (150 528 tokens > big_tokens: the large-batch TWO-STREAM schedule -- fork / join inside the capture, cooperative routing,
+    per-group after_proj, fp16 planes into gemm_hd_k, gemm_tail_k with the CFG weights from the device table), width-D audio
+    condition through ControlT2MHalf (controlnet.py:340-424), fp16 MFMA (tools/test.py:95-97), hipGraph replay.  Three arms over
+    the first steps of the 50-step DDIM schedule, same inputs and noise:
+      (a) eager mc_sample_step with the routing capture on: every step in lockstep with the fp32 CPU oracle on a 4-sample
+          sub-batch, teacher-forced to the HIP path's routing, from the HIP path's own x_t: x_{t-1} within 1e-3;
+      (b) mc_ctx_graph_capture + graph_step replays: the SAME BITS as (a);
+      (c) eager again with the second sample group's stream held back 2 ms in front of every layer tail (the two groups far out of
+          phase: ADVICE r04 -- the deferred last FiLM block's fp32 rows and the other group's fp16 planes must not share `a`):
+          the SAME BITS as (a)."""
+    from motioncraft_amd.diffusion import build_diffusion
+    from motioncraft_amd.engine import NativeModel
+    from oracle import stmogen_oracle as O, weights as W
+    dims, copy, B, T, NSTEP = FULL, 2, 32, 196, 3
+    feats = dims['L'] * dims['H']
+    NL, H = dims['NL'], dims['H']
+    sd = W.make_state_dict(dims, 0, shapes=W.control_param_shapes(dims, copy, feats))
+    nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
+    g = torch.Generator().manual_seed(401)
+    lengths = [int(v) for v in torch.randint(T // 2, T + 1, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(dims, B, T, seed=402, lengths=lengths)
+    c = torch.randn(B, T, feats, generator=g)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
+                             model_var_type='fixed_large', respace='15,15,8,6,6'))
+    sched = O.Schedule(1000, '15,15,8,6,6')
+    S = d.num_timesteps
+    coefs = [d.step_coefs(i, 'ddim', dims['scale']) for i in range(S)]
+    noises = [n.cuda() for n in step_noise_from_seed(403, tuple(x_T.shape), NSTEP)]
+    torch.set_num_threads(min(32, os.cpu_count()))
+    sub = torch.arange(0, B, B // 4)
+    tf_full = O.precompute_text_control(sd, xf, dims, copy)
+    tf_sub = {k: t.view(2, B, *t.shape[1:])[:, sub].reshape(2 * len(sub), *t.shape[1:]) for k, t in tf_full.items()}
+    outs, worst = {}, 0.0
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for arm in ('eager', 'graph', 'delayed'):
+            ctx = nm.context(B, T, max_steps=S)
+            ctx.set_precision(prec)
+            if arm == 'eager':
+                ctx.enable_capture()
+            if arm == 'delayed':
+                ctx.set_option('dbg_delay_us', 2000)
+            ctx.set_timesteps(d.timestep_map)
+            ctx.set_condition(xf.cuda(), mask.cuda())
+            ctx.set_control(c.cuda())
+            assert ctx.effective_precision == prec
+            x, noise = x_T.cuda(), torch.empty(B, T, dims['input_feats'], device='cuda')
+            if arm == 'graph':
+                ctx.graph_capture(x, noise, coefs)
+                x.copy_(x_T)
+            traj = []
+            for n, i in enumerate(range(S - 1, S - 1 - NSTEP, -1)):
+                noise.copy_(noises[n])
+                if arm == 'graph':
+                    ctx.graph_step(i)
+                else:
+                    x_in = x.cpu() if arm == 'eager' else None
+                    ctx.sample_step(x, i, coefs[i], noise, x_prev=x)
+                stream.synchronize()
+                traj.append(x.cpu())
+                if arm == 'eager':
+                    forced = {slot: ctx.routing(slot) for slot in range(NL + copy)}
+                    fsub = {slot: tuple(v.view(2, B, T * H, 2)[:, sub].reshape(-1, 2) for v in f) for slot, f in forced.items()}
+                    x0 = O.denoise_control(sd, dims, x_in[sub], sched.timestep_map[i], xf[sub], mask[sub], c[sub], copy,
+                                           forced_routing=fsub, text_feats=tf_sub)
+                    ref = O.ddim_step(sched, i, x_in[sub], x0, noises[n].cpu()[sub])
+                    e = maxabs(traj[-1][sub], ref)
+                    worst = max(worst, e)
+                    assert e <= TOL_FINAL, (prec, i, e)
+            outs[arm] = traj
+            if arm == 'graph':
+                ctx.graph_release()
+            ctx.close()
+    print(f'configs[4] as benched (B={B} x {T}, 4+{copy} layers, {prec}): {NSTEP} DDIM steps, lockstep |hip - fp32 oracle| worst {worst:.2e} '
+          f'on {len(sub)} samples; graph replay and the delayed-stream run bit-identical to eager')
+    for k in range(NSTEP):
+        assert bool(torch.isfinite(outs['eager'][k]).all())
+        assert torch.equal(outs['eager'][k], outs['graph'][k]), (prec, 'graph', k, maxabs(outs['eager'][k], outs['graph'][k]))
+        assert torch.equal(outs['eager'][k], outs['delayed'][k]), (prec, 'delayed', k, maxabs(outs['eager'][k], outs['delayed'][k]))
+    nm.close()
 
 
 @pytest.mark.parametrize('prec', ['f32', 'f16x3'])
@@ -1508,6 +1640,83 @@ def test_long_sequence_windows_repaint_vs_oracle(small_model):
         assert err <= TOL_FINAL
     assert maxabs(T_(rec), torch.cat(ref_parts)) <= TOL_FINAL
     assert np.abs(wins[1][0] - wins[0][-6]).max() <= 1e-6          # frame 0 of a later window IS the previous frame -6
+    arch.model.release()
+
+
+def test_batched_long_sequence_windows_vs_oracle_on_the_same_batches(small_model):
+    """longform.sample_long_batched (BASELINE configs[3]; reference loop tools/m2d_test.py:139-232 at B = 1): S sequences x W windows
+    folded into the batch.  The MoE capacity couples the windows of one model call, so the criterion is NOT "equals the window sampled
+    alone" but "equals the ORACLE on the same batch" -- plain mode: ONE call over all S*W windows against O.sample_loop on that batch;
+    RePaint mode: window i of all S sequences per call, chained through the previous outputs, against O.sample_loop_repaint with the
+    same window plumbing.  Stitching is checked against stitch_windows of the oracle's windows."""
+    import types
+    import motioncraft_amd as mc
+    from motioncraft_amd import longform
+    from oracle import stmogen_oracle as O
+    sd, _ = small_model
+    opt = types.SimpleNamespace(same_overlap_noisy=False, no_repaint=False, addBlend=True, overlap_len=6, no_resample=True,
+                                jump_length=3, jump_n_sample=5, timestep_respacing='ddim50')
+    cfg = mc.Config.fromfile(os.path.join(HERE, 'configs', 'stmogen_small.py'))
+    cfg.model['opt'] = opt
+    arch = mc.build_architecture(cfg.model)
+    arch.load_state_dict({'model.' + k: v for k, v in sd.items()})
+    S, total, L, pre = 3, 42, 24, 6
+    n_win, stride = longform.window_starts(total, L, pre)
+    assert (n_win, stride) == (2, 18)
+    g = torch.Generator().manual_seed(321)
+    xf = torch.nn.functional.layer_norm(torch.randn(S, SMALL['Nt'], SMALL['Dt'], generator=g), (SMALL['Dt'],))
+    first_gt = torch.randn(S, 6, 322, generator=g)
+    sched = O.Schedule(1000, '15,15,8,6,6')
+    torch.set_num_threads(min(32, os.cpu_count()))
+    # ---- plain mode: one batch of S * W = 6 windows, pairs in (sequence, window) order ----
+    x_T = torch.randn(S * n_win, L, 322, generator=g)
+    noises = step_noise_from_seed(77, (S * n_win, L, 322), 50)
+    seen = []
+
+    def inf_plain(pairs):
+        seen.append(list(pairs))
+        return dict(noise=x_T, step_noise=[noises[49 - i] for i in range(50)])       # step_noise[i] = the draw of schedule index i
+    recs, wins = longform.sample_long_batched(arch, total, L, pre, text=['a'] * S, repaint=False, condition_kwargs=dict(xf_out=xf.cuda()),
+                                              inference_kwargs=inf_plain, max_batch=160, shard=False)
+    assert seen == [[(s, w) for s in range(S) for w in range(n_win)]]
+    rows = torch.tensor([s for s, _ in seen[0]])
+    ref = O.sample_loop(sd, SMALL, sched, 'ddim', x_T, xf[rows], torch.ones(S * n_win, L), step_noise=lambda i: noises[49 - i])
+    e = max(maxabs(T_(wins[p]), ref[j]) for j, p in enumerate(seen[0]))
+    print(f'batched windows, plain mode: {S} sequences x {n_win} windows in one call: |hip - oracle| {e:.2e}')
+    assert e <= TOL_FINAL
+    for s in range(S):
+        want = longform.stitch_windows([ref[s * n_win + w].numpy() for w in range(n_win)], pre, False)
+        assert recs[s].shape == (stride + L, 322) and float(np.abs(recs[s] - want).max()) <= TOL_FINAL
+    # ---- RePaint mode: window i of all S sequences per call ----
+    x_Ts = [torch.randn(S, L, 322, generator=g) for _ in range(n_win)]
+
+    def draws(seed):
+        gen = torch.Generator().manual_seed(seed)
+        return (torch.randn(S, L, 322, generator=gen) for _ in range(10 ** 6))
+    seen.clear()
+
+    def inf_rep(pairs):
+        seen.append(list(pairs))
+        w = pairs[0][1]
+        return dict(noise=x_Ts[w], step_noise=draws(60 + w))
+    recs, wins = longform.sample_long_batched(arch, total, L, pre, text=['a'] * S, repaint=True, overlap_len=6, first_gt=first_gt,
+                                              condition_kwargs=dict(xf_out=xf.cuda()), inference_kwargs=inf_rep, max_batch=160, shard=False)
+    assert seen == [[(s, w) for s in range(S)] for w in range(n_win)]
+    keep = torch.zeros(S, L, 322, dtype=torch.bool)
+    keep[:, :6] = True
+    prev, ref_w = None, []
+    for w in range(n_win):
+        gt = torch.zeros(S, L, 322)
+        gt[:, :6] = first_gt if w == 0 else prev[:, -6:]
+        prev = O.sample_loop_repaint(sd, SMALL, sched, x_Ts[w], xf, torch.ones(S, L), keep, gt, draws(60 + w), 6, 50, no_resample=True)
+        ref_w.append(prev)
+        e = max(maxabs(T_(wins[(s, w)]), prev[s]) for s in range(S))
+        print(f'batched windows, RePaint mode, window {w} of {S} sequences: |hip - oracle| {e:.2e}')
+        assert e <= TOL_FINAL
+    for s in range(S):
+        want = longform.stitch_windows([ref_w[w][s].numpy() for w in range(n_win)], pre, True)
+        assert float(np.abs(recs[s] - want).max()) <= TOL_FINAL
+        assert np.abs(wins[(s, 1)][0] - wins[(s, 0)][-6]).max() <= 1e-6
     arch.model.release()
 
 

@@ -25,9 +25,12 @@ db=$(run ${tag}_stats --kernel-trace -d $out/prof_${tag}_stats -o s -- $BENCH --
 db=$(MC_CHAIN=$SERIAL run ${tag}_serial --kernel-trace -d $out/prof_${tag}_serial -o s -- $BENCH --steps 12 --warmup 3)
 { echo "# MC_CHAIN=$SERIAL bench.py --steps 12 --warmup 3 (B=64): single-stream schedule (whole-batch launches, no overlap) -- the clean per-kernel durations"; python tools/rocpd_stats.py $db 24; } > $out/${tag}_kernel_stats_b64_serial.txt
 db=$(MC_CHAIN=$SERIAL run ${tag}_mfma --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $out/prof_${tag}_mfma -o s -- $BENCH --steps 3 --warmup 1)
-{ echo "# MC_CHAIN=$SERIAL (single-stream schedule) rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"; echo "#   -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-full-loop   (B=64, T=196); summary by tools/rocpd_pmc.py"; echo "# MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024 SIMDs), cycles = GRBM_GUI_ACTIVE / 8 XCDs; per-dispatch averages"; python tools/rocpd_pmc.py $db; } > $out/${tag}_pmc_mfma_busy.txt
+{ echo "# commit $COMMIT"; echo "# MC_CHAIN=$SERIAL (single-stream schedule) rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"; echo "#   -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-full-loop   (B=64, T=196); summary by tools/rocpd_pmc.py"; echo "# MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024 SIMDs), cycles = GRBM_GUI_ACTIVE / 8 XCDs; per-dispatch averages"; python tools/rocpd_pmc.py $db; } > $out/${tag}_pmc_mfma_busy.txt
 dbf=$(run ${tag}_fetch --kernel-trace --pmc FETCH_SIZE -d $out/prof_${tag}_fetch -o s -- $BENCH --steps 4 --warmup 1)
 dbw=$(run ${tag}_write --kernel-trace --pmc WRITE_SIZE -d $out/prof_${tag}_write -o s -- $BENCH --steps 4 --warmup 1)
 { echo "# commit $COMMIT"; echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (separate passes) over"; echo "#   python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --no-full-loop   (B=64, T=196; 5 steps + setup per pass); table by tools/hbm_traffic.py"; echo "# units: KiB per dispatch (average).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B requests of wide coalesced reads as 64 B -> fetch_x2 doubles it (calibrated on sampler_update_k in round 1); WRITE_SIZE exact."; python tools/hbm_traffic.py $dbf $dbw 5; } > $out/${tag}_pmc_hbm_traffic.txt
+# per-kernel roofline table from the two PMC summaries (bench.py reads its gemm_wp_k row as `roofline.dominant_kernel`)
+cp $out/${tag}_pmc_mfma_busy.txt $out/${tag}_pmc_hbm_traffic.txt $root/profiles/ 2>/dev/null
+python tools/kernel_roofline.py $tag > $out/${tag}_kernel_roofline.txt
 tail -3 $out/${tag}_pmc_hbm_traffic.txt
 head -12 $out/${tag}_kernel_stats_b64_serial.txt

@@ -63,6 +63,10 @@ def parse_hbm(path):
     return out
 
 
+for line in open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma_busy.txt')):
+    if line.startswith('# commit'):
+        print(line.rstrip())
+        break
 pmc = parse_pmc(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma_busy.txt'))
 hbm = parse_hbm(os.path.join(ROOT, 'profiles', f'{tag}_pmc_hbm_traffic.txt'))
 print(f'# tools/kernel_roofline.py {tag}: B=64 step, serial single-stream schedule (single-stream chain mask, PMC pass: profiles/{tag}_pmc_mfma_busy.txt), HBM bytes per launch of the')
