@@ -237,6 +237,14 @@ int mc_op_gemm(const float* a_dev, const float* w_dev, const float* bias_dev, co
 /* C = A W^T + bias + res on the fp16 MFMA (split != 0: hi/lo three-product form); N % 128 == 0, K % 32 == 0; synchronises */
 int mc_op_gemm_f16(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* c_dev,
                    int32_t M, int32_t N, int32_t K, int32_t split, void* stream);
+/* the folded decoder tail as one op (stmogen.py:505-544 + 757-760 after the CFG combination, motioncraft_amd/csrc/mc_gemm.hip):
+ *   C[r] = (wc h[r] + wu h[r + M]) W[0]^T + (wc a[r] + wu a[r + M]) W[1]^T + bias[0] + bias[1]
+ * h, a [2 M][K] (conditional rows, then the unconditional ones), W [2][N][K], bias [2][N], C [M][N]; c2_dev: scratch [M][N] (the
+ * block-range form writes one partial product per K group, added here by a second launch and by the sampler-update kernel in the step;
+ * may be NULL for variant 1); variant 0 = the default kernel choice, 1 = the column-tile form (gemm_tail_k), 2 = the block-range form
+ * (gemm_tail2_k; N <= 336) */
+int mc_op_gemm_tail(const float* h_dev, const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, float* c2_dev,
+                    int32_t M, int32_t N, int32_t K, float wc, float wu, int32_t variant, void* stream);
 int mc_op_ln_rows(const float* x_dev, int64_t ldx, const float* gamma_dev, const float* beta_dev,
                   const float* add_dev, int32_t add_mod, float* y_dev, int64_t rows, int32_t L, void* stream);
 int mc_op_sampler_update(const float* x_t_dev, const float* out_text_dev, const float* out_none_dev,

@@ -61,6 +61,7 @@ struct TailArgs {
     const float* bias = nullptr;    // [2][N] at stride b_gstride
     long b_gstride = 0;
     float* C = nullptr;             // [M][ldc]
+    float* C2 = nullptr;            // [M][ldc], optional: second partial product (gemm_tail2_k writes one per K group: x0 = C + C2; null: the one-output kernel)
     long ldc = 0;
     int M = 0, N = 0, K = 0;        // K per group
     float wc = 1.f, wu = 0.f;       // CFG weights ...
@@ -70,3 +71,4 @@ struct TailArgs {
     int tune = -1;
 };
 int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream);
+bool mc_gemm_tail_two_outputs(const TailArgs& g);      // true: this launch writes the two partial products C and C2 (x0 = C + C2), else C alone

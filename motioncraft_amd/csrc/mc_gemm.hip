@@ -939,13 +939,208 @@ __global__ __launch_bounds__(256) void gemm_tail_k(TailArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// gemm_tail2_k (round 5): the same folded decoder tail, A read ONCE.  gemm_tail_k cuts N = 322 into seven 48-wide column tiles and every
+// one of them re-reads (and re-combines) the A rows: 548 MB fetched per launch against the 308 MB of h and a (both CFG halves) + 4 MB of
+// W, 0.48 of the MFMA peak.  Here the launch is a flat list of 16 x 16 output blocks in row-tile-major order (784 row tiles x 21 column
+// blocks at B = 64) cut into one CONTIGUOUS range per workgroup, one workgroup per CU (the stream-K idea applied to blocks: 12544 rows
+// are 49 per CU, so whole row tiles per workgroup can only reach 77 % of the CUs' MFMA time; ranges of 64 / 65 blocks reach 98 %).
+// A workgroup stages the <= 5 row tiles its range touches (CFG combination formed in registers on the way, as in gemm_tail_k) and ALL
+// column blocks of W per k-tile, so A is fetched once per workgroup and W streams from L2.  The two K groups (h x W0, a x W1) are TWO
+// workgroups over the same range (two per CU, 78 KB of LDS each: they drift freely and cover each other's barrier / issue phases; a first
+// version with both groups as wave quads of one 512-thread workgroup met at one barrier per k-tile and ran at half this speed); each
+// writes its partial product (C, C2), which the sampler-update kernel adds -- the x0a + x0b form it already had for the grouped tail.
+// Inside a workgroup the range is cut into four contiguous pieces of <= NBW + 1 blocks, one per wave; every block reads its own A fragment
+// (a scalar offset picks the row tile: no per-block register select; 34 ds_read_b128 per 64 MFMAs = a quarter of the LDS read rate).
+// k-tiles of 16 columns; LDS stage of a quad = [80 A rows | 336 W rows][16 floats], 16-byte chunk c of row r at position c ^ F[(r >> 2) & 3],
+// F = {0, 2, 3, 1}: conflict-free for the 16 x 16 fragment read (lane = row l & 15, chunk l >> 4) in ds_read_b128's lane groups.
+// Ring of 3 stages = 78 KB.  Per iteration kt a wave issues [A loads of tile kt + 3][W DMAs of tile kt + 2]; at its top
+// A(kt + 1) and W(kt) must have landed: everything but the previous iteration's na + nwp operations (in-order vmcnt).
+// ---------------------------------------------------------------------------------------
+constexpr int T2_BK = 16, T2_MAXCB = 21, T2_MAXRT = 5, T2_RING = 3;
+constexpr int T2_STAGE = 16 * (T2_MAXRT + T2_MAXCB) * T2_BK;            // floats per stage (26 KB)
+constexpr int T2_WROW0 = 16 * T2_MAXRT;                                 // first W row of a stage
+
+__device__ __forceinline__ int t2_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }      // F = {0, 2, 3, 1}, two bits each: 0b01111000 >> {0, 2, 4, 6}
+
+__device__ __forceinline__ void t2_wait(int n) {      // s_waitcnt vmcnt(n), n uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+}
+
+template <int NBW>        // blocks per wave handled by the static part (a wave's piece has <= NBW + 1 blocks)
+__global__ __launch_bounds__(256, 2) void gemm_tail2_k(TailArgs g, int ncb, long nblocks) {
+    static_assert(NBW % 4 == 0 && NBW >= 4 && NBW <= 16, "NBW");
+    constexpr int PH = 4;                                                // blocks per fragment phase (8 spills address registers at NBW = 16, and spill reloads share the vmcnt queue)
+    __shared__ __attribute__((aligned(16))) float smem[T2_RING * T2_STAGE];      // 78 KB: two workgroups per CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int qw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float wc = g.wc, wu = g.wu;
+    if (g.coef_table) { wc = g.coef_table[(long)*g.step_ptr * g.coef_stride]; wu = g.coef_table[(long)*g.step_ptr * g.coef_stride + 1]; }
+    // workgroup -> (block range, K group); consecutive ranges (neighbouring rows) share an XCD's L2
+    const int G = gridDim.x >> 1, rid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int wg = rid >> 1, grp = rid & 1;
+    const long gb0 = nblocks * wg / G, gb1 = nblocks * (wg + 1) / G;
+    const int n = (int)(gb1 - gb0);
+    if (n <= 0) return;
+    const int rt_first = (int)(gb0 / ncb), nrt = (int)((gb1 - 1) / ncb) - rt_first + 1;      // <= T2_MAXRT (launcher)
+    // this wave's piece
+    const int wb0 = qw * n / 4, wb1 = (qw + 1) * n / 4, nb = wb1 - wb0;                        // <= NBW + 1 (launcher)
+    const int frow = lane & 15, kg = lane >> 4;
+    const int lfrag = frow * T2_BK + ((kg ^ t2_swz(frow)) << 2);                               // lane part of a fragment address (floats)
+    const int g0 = (int)(gb0 - (long)rt_first * ncb) + wb0;                                    // first block of the piece, relative to the range's first row tile
+    int aoff[NBW + 1], boff[NBW + 1];                                                          // per block: its A row tile / W column block inside a stage
+    {
+        // (one division per wave, then a walk: blocks past the piece repeat its last one -- computed, never stored)
+        int rt = g0 / ncb, cb = g0 - rt * ncb;
+#pragma unroll
+        for (int b = 0; b <= NBW; ++b) {
+            aoff[b] = rt * 16 * T2_BK;
+            boff[b] = (T2_WROW0 + 16 * cb) * T2_BK;
+            if (b + 1 < nb) { if (++cb == ncb) { cb = 0; ++rt; } }
+        }
+    }
+    // ---- A staging: 16-byte slot s = (row s >> 2, position s & 3), s = tid (+ 256 for the fifth row tile) ----
+    const float* Asrc = grp ? g.Af : g.H;
+    long a_go[2];
+    int a_lds[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int s = tid + 256 * j, row = s >> 2, pos = s & 3;
+        long grow = (long)rt_first * 16 + row;
+        if (grow > g.M - 1) grow = g.M - 1;
+        a_go[j] = grow * g.lda + ((pos ^ t2_swz(row)) << 2);
+        a_lds[j] = row * T2_BK + (pos << 2);
+    }
+    const int nslot = (qw < nrt ? 1 : 0) + ((4 + qw) < nrt ? 1 : 0);                           // slots of this wave's threads (uniform): 64 slots per row tile
+    const int na = 2 * nslot;
+    // ---- W DMA: piece p = rows [16 p, 16 p + 16) of the group's weight, pieces qw, qw + 4, ... of this wave ----
+    constexpr int MAXP = (T2_MAXCB + 3) / 4;
+    unsigned vow[MAXP];
+    {
+        const int dr = lane >> 2, pos = lane & 3;
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+            int wr = 16 * (qw + 4 * q) + dr;
+            if (wr > g.N - 1) wr = g.N - 1;
+            vow[q] = (unsigned)(((long)wr * g.ldw + ((pos ^ t2_swz(dr)) << 2)) * 4);
+        }
+    }
+    const int nwp = qw < ncb ? (ncb - qw + 3) / 4 : 0;
+    const float* Wsrc = g.W + (grp ? g.w_gstride : 0);
+    const unsigned lds_q = (unsigned)(size_t)smem;
+    const int nk = g.K / T2_BK;
+    auto a_load = [&](int kt, f32x4 (&c)[2], f32x4 (&u)[2]) {
+        const float* A = Asrc + (long)kt * T2_BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < nslot) { gload16(c[j], A + a_go[j]); gload16(u[j], A + g.half + a_go[j]); }
+    };
+    auto a_store = [&](int kt, const f32x4 (&c)[2], const f32x4 (&u)[2]) {
+        float* St = smem + (kt % T2_RING) * T2_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < nslot) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = wc * c[j][i] + wu * u[j][i];
+                *reinterpret_cast<f32x4*>(St + a_lds[j]) = v;
+            }
+    };
+    auto w_issue = [&](int kt) {
+        const float* Wb = Wsrc + (long)kt * T2_BK;
+        const unsigned l = lds_q + (unsigned)((kt % T2_RING) * T2_STAGE + T2_WROW0 * T2_BK) * 4;
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q)
+            if (q < nwp) dma16(vow[q], Wb, l + (unsigned)(16 * (qw + 4 * q)) * T2_BK * 4);
+    };
+    f32x4 acc[NBW + 1];
+#pragma unroll
+    for (int b = 0; b <= NBW; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // two A register sets in rotation: tile k lives in set k & 1, requested three iterations before it is consumed
+    f32x4 c0[2], u0[2], c1[2], u1[2];
+    a_load(0, c0, u0);
+    t2_wait(0);
+    asm volatile("" : "+v"(c0[0]), "+v"(c0[1]), "+v"(u0[0]), "+v"(u0[1]));
+    a_store(0, c0, u0);
+    a_load(1, c1, u1);
+    w_issue(0);
+    if (nk > 2) a_load(2, c0, u0);
+    if (nk > 1) w_issue(1);
+    // queue now: A(1) W(0) A(2) W(1)
+    auto step = [&](int kt, f32x4 (&cs)[2], f32x4 (&us)[2]) {
+        // A(kt + 1) and W(kt) have landed once only the previous iteration's issues -- A(kt + 2), W(kt + 1) -- are outstanding
+        t2_wait((kt + 2 < nk ? na : 0) + (kt + 1 < nk ? nwp : 0));
+        asm volatile("" : "+v"(cs[0]), "+v"(cs[1]), "+v"(us[0]), "+v"(us[1]));              // (the set is consumed only behind the wait)
+        if (kt + 1 < nk) a_store(kt + 1, cs, us);
+        __syncthreads();
+        if (kt + 3 < nk) a_load(kt + 3, cs, us);                                              // (set (kt + 1) & 1 is free again)
+        if (kt + 2 < nk) w_issue(kt + 2);
+        const float* St = smem + (kt % T2_RING) * T2_STAGE + lfrag;
+#pragma unroll
+        for (int p0 = 0; p0 < NBW; p0 += PH) {
+            f32x4 fa[PH], fb[PH];
+#pragma unroll
+            for (int b = 0; b < PH; ++b) {
+                fa[b] = *reinterpret_cast<const f32x4*>(St + aoff[p0 + b]);
+                fb[b] = *reinterpret_cast<const f32x4*>(St + boff[p0 + b]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < PH; ++b)
+                    acc[p0 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[b][i], fa[b][i], acc[p0 + b], 0, 0, 0);
+        }
+        if (nb > NBW) {          // the piece's extra block (uniform branch)
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(St + aoff[NBW]);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(St + boff[NBW]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[NBW] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[i], acc[NBW], 0, 0, 0);
+        }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, c1, u1);
+        if (kt + 1 < nk) step(kt + 1, c0, u0);
+    }
+    // ---- this K group's partial product: group 0 -> C (+ both biases), group 1 -> C2; the sampler kernel adds the two ----
+    float* Cout = grp ? g.C2 : g.C;
+    {
+        int rt = g0 / ncb, cb = g0 - rt * ncb;
+#pragma unroll
+        for (int b = 0; b <= NBW; ++b) {
+            if (b < nb) {
+                const long m = ((long)rt_first + rt) * 16 + frow;
+                const int n0 = cb * 16 + 4 * kg;
+                if (m < g.M) {
+                    float* crow = Cout + m * g.ldc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (n0 + i < g.N) crow[n0 + i] = grp ? acc[b][i] : acc[b][i] + (g.bias[n0 + i] + g.bias[g.b_gstride + n0 + i]);
+                }
+                if (++cb == ncb) { cb = 0; ++rt; }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int tune_bits() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MC_GEMM_TUNE");
-        v = e ? atoi(e) : 49 + 256 + 512;
+        v = e ? atoi(e) : 49 + 256 + 512 + 1024;
     }
     return v;
 }
@@ -1040,6 +1235,34 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
     return MC_OK;
 }
 
+static int device_cus() {
+    static int v = 0;
+    if (v <= 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+        if (v <= 0) v = 256;
+    }
+    return v;
+}
+
+// grid of the block-range form for this launch, or 0: the column-tile kernel runs (tune bit 10 off, no second output, N > 336, ranges too long)
+static int tail2_grid(const TailArgs& g, int tune, int* per_wave_out) {
+    const int ncb = cdiv(g.N, 16);
+    const long nblocks = (long)cdiv(g.M, 16) * ncb;
+    if (!(tune & 1024) || !g.C2 || ncb > T2_MAXCB || g.K < 3 * T2_BK || g.K % T2_BK) return 0;
+    int G = device_cus();
+    if (nblocks < (long)G * 16) G = (int)(nblocks / 16) > 0 ? (int)(nblocks / 16) : 1;          // small launches: >= 16 blocks per workgroup
+    const int nmax = (int)cdiv(nblocks, (long)G);                                               // largest range; its pieces have <= ceil(nmax / 4) blocks
+    const int per_wave = cdiv(nmax, 4);
+    const int max_rt = (ncb - 1 + nmax - 1) / ncb + 1;                                          // row tiles a range of nmax blocks can touch
+    if (per_wave > 17 || max_rt > T2_MAXRT) return 0;
+    if (per_wave_out) *per_wave_out = per_wave;
+    return G;
+}
+
+bool mc_gemm_tail_two_outputs(const TailArgs& g) { return tail2_grid(g, g.tune < 0 ? tune_bits() : g.tune, nullptr) > 0; }
+
 int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream) {
     MC_REQUIRE(g.H && g.Af && g.W && g.bias && g.C, "gemm_tail: null operand");
     MC_REQUIRE(g.K % BK == 0 && g.K >= BK && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.half % 4 == 0 && g.w_gstride % 4 == 0,
@@ -1048,6 +1271,19 @@ int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream) {
     MC_REQUIRE((long)g.N * g.ldw * 4 < (1L << 32), "gemm_tail: weight beyond 4 GB");
     TailArgs gg = g;
     if (gg.tune < 0) gg.tune = tune_bits();
+    // tune bit 10 (round 5): the block-range form, A read once, one partial product per K group (gemm_tail2_k)
+    int per_wave = 0;
+    if (const int G = tail2_grid(gg, gg.tune, &per_wave)) {
+        const int ncb = cdiv(g.N, 16);
+        const long nblocks = (long)cdiv(g.M, 16) * ncb;
+        dim3 grid(2 * G);                      // (range, K group)
+        if (per_wave <= 5) hipLaunchKernelGGL((gemm_tail2_k<4>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
+        else if (per_wave <= 9) hipLaunchKernelGGL((gemm_tail2_k<8>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
+        else if (per_wave <= 13) hipLaunchKernelGGL((gemm_tail2_k<12>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
+        else hipLaunchKernelGGL((gemm_tail2_k<16>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, 48));
     hipLaunchKernelGGL((gemm_tail_k<3>), grid, dim3(256), 0, stream, gg);
     MC_LAUNCH_CHECK();

@@ -1427,8 +1427,10 @@ static int denoise_combined(mc_ctx* c, const float* x_t, int32_t step, const mc_
             t.step_ptr = c->gstep;
         }
         t.tune = options_of(c).gemm_tune;
+        t.C2 = c->out2 + BT * C;               // (out2 holds [2 B T][C]: room for one partial product per K group)
         if ((r = mc_launch_gemm_tail(t, s))) return r;
         *x0a = c->out2;
+        if (mc_gemm_tail_two_outputs(t)) *x0b = t.C2;      // gemm_tail2_k: x0 = C + C2, added by the sampler-update kernel
         return MC_OK;
     }
     if (defer && c->dec_cat_w && chain_on(c, 11)) {
@@ -1708,6 +1710,26 @@ int mc_op_gemm_f16(const float* a, const float* w, const float* bias, const floa
     }
     (void)hipStreamSynchronize(s);
     (void)hipFree(planes);
+    return r;
+}
+
+int mc_op_gemm_tail(const float* h, const float* a, const float* w, const float* bias, float* cdev, float* c2dev, int32_t M, int32_t N,
+                    int32_t K, float wc, float wu, int32_t variant, void* stream) {
+    MC_REQUIRE(h && a && w && bias && cdev && M > 0 && N > 0 && K > 0 && K % 32 == 0, "bad gemm_tail args");
+    MC_REQUIRE(variant >= 0 && variant <= 2, "gemm_tail variant %d (0 default, 1 column tiles, 2 block ranges)", variant);
+    TailArgs t;
+    t.H = h; t.Af = a; t.half = (long)M * K; t.lda = K; t.W = w; t.ldw = K; t.w_gstride = (long)N * K; t.bias = bias; t.b_gstride = N;
+    t.C = cdev; t.ldc = N; t.M = M; t.N = N; t.K = K; t.wc = wc; t.wu = wu;
+    t.tune = options_of(nullptr).gemm_tune;
+    if (variant) {
+        if (t.tune < 0) t.tune = 49 + 256 + 512 + 1024;
+        t.tune = variant == 1 ? (t.tune & ~1024) : (t.tune | 1024);
+    }
+    t.C2 = c2dev;
+    MC_REQUIRE(variant != 2 || c2dev, "gemm_tail variant 2 needs the scratch output c2_dev [M][N]");
+    int r = mc_launch_gemm_tail(t, (hipStream_t)stream);
+    if (r == MC_OK && mc_gemm_tail_two_outputs(t))       // the sampler-update kernel adds the two partial products in the step; here: C += C2
+        r = mc_launch_axpby(cdev, c2dev, 1.f, 1.f, cdev, (long)M * N, (hipStream_t)stream);
     return r;
 }
 

@@ -100,6 +100,8 @@ _SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_int64)]),
     'mc_op_gemm': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                   ctypes.c_int32, ctypes.c_int32, _P]),
+    'mc_op_gemm_tail': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_int32, _P]),
     'mc_op_ln_rows': (ctypes.c_int, [_P, ctypes.c_int64, _P, _P, _P, ctypes.c_int32, _P, ctypes.c_int64,
                                      ctypes.c_int32, _P]),
     'mc_op_sampler_update': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, ctypes.POINTER(StepCoefs), _P]),
