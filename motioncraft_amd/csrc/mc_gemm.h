@@ -45,6 +45,7 @@ struct GemmArgs {
     int tune = -1;                  // -1 = process default (env MC_GEMM_TUNE, 817); bits: 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k, 8 (round 4) XCD-aware tile order in gemm_small_k (a row block's column tiles share one L2), 9 (round 4) the aligned pose-encoder GEMM on gemm_wp_k (table + duplicate rows in its epilogue)
 };
 
+int mc_device_cus();      // compute units of the current device (cached)
 int mc_launch_gemm(int mode, const GemmArgs& g, int groups, int max_tiles, hipStream_t stream);
 // small-M plain GEMM (64 x 64 tiles, one MFMA tile per wave): C = A W^T + bias (+ add) + R, K % 32 == 0; any N (guarded scalar
 // epilogue when rows are not 16-byte aligned); `groups` as in mc_launch_gemm (the *_gstride fields)

@@ -1235,7 +1235,7 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
     return MC_OK;
 }
 
-static int device_cus() {
+int mc_device_cus() {
     static int v = 0;
     if (v <= 0) {
         int dev = 0;
@@ -1251,7 +1251,7 @@ static int tail2_grid(const TailArgs& g, int tune, int* per_wave_out) {
     const int ncb = cdiv(g.N, 16);
     const long nblocks = (long)cdiv(g.M, 16) * ncb;
     if (!(tune & 1024) || !g.C2 || ncb > T2_MAXCB || g.K < 3 * T2_BK || g.K % T2_BK) return 0;
-    int G = device_cus();
+    int G = mc_device_cus();
     if (nblocks < (long)G * 16) G = (int)(nblocks / 16) > 0 ? (int)(nblocks / 16) : 1;          // small launches: >= 16 blocks per workgroup
     const int nmax = (int)cdiv(nblocks, (long)G);                                               // largest range; its pieces have <= ceil(nmax / 4) blocks
     const int per_wave = cdiv(nmax, 4);

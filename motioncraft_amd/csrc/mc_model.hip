@@ -73,7 +73,11 @@ struct McOptions {
     // 20 (round 4) reduced-precision contexts: temporal linear attention on the fp16 MFMA (temporal_h_k)
     // 22 (round 4) L = 64 models: temporal_k takes two adjacent parts per workgroup (all four waves on the MFMA)
     // 21 (round 4) large batches: the folded decoder tail with the CFG combination in its A staging, one pass over both K groups (gemm_tail_k)
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22);     // (all but bit 3)
+    // 23 (round 5) two-stream schedule: the last sample group's gate launch is cut at a whole number of workgroup rounds; the partial last round
+    //    runs as gate_small_k (32-token workgroups, the same bits) on the OTHER group's stream, beside the big launch instead of behind it.
+    //    OFF by default: measured SLOWER (B=64 19.47 -> 19.55 ms/step, B=32 10.10 -> 10.14, same-box A/B twice): the 608 small workgroups
+    //    (each wave re-reads its projector chunks from L2, wave 0 walks the logit chain alone) take longer than the partial round they replace
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22);     // (all but bits 3 and 23)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
                                        // S2G at 32 per GPU 27.65 -> 27.14; at 4704 rows (B=24) the small kernels still do, 7.85 vs 7.91)
@@ -141,6 +145,7 @@ struct mc_ctx {
     hipStream_t side = nullptr;
     bool xpad_ready = false;           // mc_sample_loop: xpad already holds this step's padded x_t (written by the previous sampler update)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_gate = nullptr;      // chain bit 23: the last group's rows are ready (recorded on its stream in front of its gate launch)
     // large batches: the batch is cut into `nparts` groups of whole samples, group k > 0 runs on parts[k-1]
     bool no_alias = false;          // introspection runs (stop_after_layers < num_layers): every intermediate row is materialised
     bool defer_last_gemm = false;   // sampler entry points: the last FiLM GEMM runs on the CFG-combined rows (see denoise_combined)
@@ -787,6 +792,25 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
             for (int k = 0; k < c->nparts; ++k) {
                 if (twin_split) { ga.tok0 = k ? sub_rows * H : 0; ga.N = k ? c->N / 2 : sub_rows * H; }
                 else { ga.tok0 = part_row0(c, k) * H; ga.N = part_row0(c, k + 1) * H; }
+                // The group that reaches the join last runs its gate ALONE on the chip (the other stream already waits for the routing): 1176
+                // tiles of 128 tokens on 512 workgroup slots are 2.3 rounds -- the third one 30 % full.  Cut the launch at whole rounds; the
+                // rest goes to gate_small_k (32-token workgroups whose waves split the projector chunks: bit-identical scores, tested) on
+                // the waiting stream, so it runs BESIDE the big launch.
+                const long slots = 2L * mc_device_cus(), tiles = cdiv(ga.N - ga.tok0, 128L), rem = tiles % slots;
+                if (!twin_split && c->nparts == 2 && k == 1 && chain_on(c, 23) && tiles > slots && rem > 0 && 8 * rem <= 5 * slots) {
+                    hipStream_t sk = part_stream(c, k, s);
+                    MC_HIP(hipEventRecord(c->ev_gate, sk));                      // (the group's rows: behind its last FiLM GEMM)
+                    const long cut = ga.tok0 + (tiles - rem) * 128;
+                    GateArgs gb = ga;
+                    gb.N = cut;
+                    if ((r = mc_launch_gate(gb, sk))) return r;
+                    GateArgs gs = ga;
+                    gs.tok0 = cut;
+                    gs.small_tokens = ga.N - cut;                                // -> gate_small_k
+                    MC_HIP(hipStreamWaitEvent(s, c->ev_gate, 0));
+                    if ((r = mc_launch_gate(gs, s))) return r;
+                    continue;
+                }
                 if ((r = mc_launch_gate(ga, part_stream(c, k, s)))) return r;
             }
         } else {
@@ -983,7 +1007,8 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     if (r != MC_OK) { mc_ctx_destroy(c); return r; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) != hipSuccess) {
         mc_set_error("could not create the side stream / events");
         mc_ctx_destroy(c);
         return MC_ERR_HIP;
@@ -1081,6 +1106,7 @@ void mc_ctx_destroy(mc_ctx* c) {
         if (c->ev_parts[k]) (void)hipEventDestroy(c->ev_parts[k]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }

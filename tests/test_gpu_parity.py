@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 8388599        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3
+DEFAULT_CHAIN = 8388599        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3 and 23
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
@@ -681,7 +681,7 @@ def test_baseline_control_configs_sampler_loop_lockstep(case):
     nm.close()
 
 
-@pytest.mark.parametrize('chain', [8388599 & ~7, 8388599])
+@pytest.mark.parametrize('chain', [DEFAULT_CHAIN & ~7, DEFAULT_CHAIN])
 def test_generic_fallback_path_vs_oracle(chain):
     """chain mask with bits 0-2 cleared: the generic path -- plain gemm_k launches + row kernels instead of the fused
     expert / SFFN MLP, the fused gate and the register-chained proj / q/k/v kernels; the library also takes it whenever a width
@@ -1554,6 +1554,42 @@ def test_fp16_modes_use_the_fp32_kernels_at_tiny_batches(monkeypatch):
     other = run('f16x3')
     assert not torch.equal(ref, other) and maxabs(ref, other) < 1e-3
     nm.close()
+
+
+def test_gate_launch_cut_at_whole_rounds_is_bit_identical(full_model):
+    """chain bit 23 (round 5; measured slower, off by default, kept as a switch): in the two-stream schedule the last sample group's gate launch is cut at a whole number of workgroup
+    rounds and the partial last round runs as gate_small_k on the other group's stream (beside the big launch).  gate_small_k
+    reproduces gate_k's accumulation order, so scores / expert choices / importance keys -- and with them everything downstream --
+    must be the SAME BITS: B=32 x 196 frames (588 tiles per group: 512 + 76), one denoiser call + routing of every layer, bit on / off;
+    and the same through two sampler steps."""
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = full_model
+    B, T = 32, 196
+    g = torch.Generator().manual_seed(15)
+    lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(FULL, B, T, seed=35, lengths=lengths)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+    eps = torch.randn(B, T, 322, generator=g).cuda()
+    got = {}
+    for tag, chain in (('cut', DEFAULT_CHAIN | (1 << 23)), ('whole', DEFAULT_CHAIN)):
+        ctx = nm.context(B, T, max_steps=2)
+        ctx.set_option('chain', chain)
+        ctx.enable_capture()
+        ctx.set_timesteps(d.timestep_map[-2:])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        out2 = ctx.denoise(x_T.cuda(), 1).clone()
+        routes = [ctx.routing(i) for i in range(FULL['NL'])]
+        x = x_T.cuda()
+        for i in (1, 0):
+            x = ctx.sample_step(x, i, d.step_coefs(998 + i, 'ddpm', FULL['scale']), eps)
+        torch.cuda.synchronize()
+        got[tag] = (out2, routes, x.clone())
+        ctx.close()
+    assert bool(torch.isfinite(got['cut'][0]).all())
+    assert torch.equal(got['cut'][0], got['whole'][0]), maxabs(got['cut'][0], got['whole'][0])
+    for a, b in zip(got['cut'][1], got['whole'][1]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(got['cut'][2], got['whole'][2])
 
 
 @pytest.mark.parametrize('L', [32, 128])
