@@ -522,6 +522,38 @@ def main():
                                               'frac': round(achc / PEAK_FP32_MFMA_TFLOPS, 4)}}
             cc.close()
             nmc.close()
+            if key == 'configs3_m2d':
+                # the same 160 windows through the PRODUCT entry point: longform.sample_long_batched (the batched form of the reference's
+                # one-window-at-a-time loop, tools/m2d_test.py:139-232) on the registry-built MotionDiffusion + ControlT2MHalf -- 32 sequences
+                # of 480 frames = 5 windows of 120 advancing by 90 each, repaint off: ONE model call of 160 windows, stitched per sequence
+                import motioncraft_amd as mc
+                from motioncraft_amd import longform
+                from motioncraft_amd.synthetic import reference_model_cfg
+                sched = dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large')
+                cfgm = mc.Config(dict(model=dict(type='MotionDiffusion', model=reference_model_cfg(dict(dm, max_seq_len=max(Tc, dm['max_seq_len']))),
+                                                 loss_recon=dict(type='MSELoss', loss_weight=1, reduction='none'), diffusion_train=sched,
+                                                 diffusion_test=dict(sched, respace='15,15,8,6,6'), inference_type='ddim'),
+                                      condition_encode_cfg=dict(condition_cfg=True)))
+                arch = mc.build_architecture(cfgm.model)
+                arch.model = mc.ControlT2MHalf(arch.model, copy_blocks_num=copy, control_cond_feats=feats, cfg=cfgm)
+                arch.load_state_dict({'model.' + k: v for k, v in make_state_dict(dm, 0, shapes=control_param_shapes(dm, copy, feats)).items()})
+                S_, tot_, pre_ = Bc // 5, 480, 30
+                cseq = torch.randn(S_, tot_, feats, generator=torch.Generator().manual_seed(5))
+                xfs = torch.nn.functional.layer_norm(torch.randn(S_, dm['Nt'], dm['Dt'], device=dev, generator=gen), (dm['Dt'],))
+                tdr = []
+                for rep in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    recs, wins = longform.sample_long_batched(arch, tot_, Tc, pre_, c=cseq, text=[''] * S_, repaint=False, condition_kwargs=dict(xf_out=xfs),
+                                                              max_batch=Bc, shard=False, device=dev)
+                    torch.cuda.synchronize()
+                    tdr.append(time.perf_counter() - t0)
+                assert len(recs) == S_ and recs[0].shape == (4 * 90 + 120, C) and len(wins) == Bc and all(bool((r == r).all()) for r in recs)
+                control_cfgs[key]['through_sample_long_batched'] = {
+                    'sequences': S_, 'frames_per_sequence': tot_, 'windows': Bc, 'model_calls': 1, 'loop_ms': round(min(tdr) * 1e3, 1),
+                    'note': 'motioncraft_amd.longform.sample_long_batched on the registry-built architecture: condition set-up + the 50-step loop of '
+                            '160 windows in one model call + download and stitching of the 32 sequences (host side included)'}
+                arch.model.release()
         control_cfgs['note'] = ('side measurements, not `value`: per-GPU share of BASELINE configs[2] / configs[3], complete 50-step DDIM loop (best of 2 after a '
                                 'warm-up loop), condition features resident in HBM')
 

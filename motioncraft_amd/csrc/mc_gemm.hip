@@ -1253,6 +1253,7 @@ static int tail2_grid(const TailArgs& g, int tune, int* per_wave_out) {
     if (!(tune & 1024) || !g.C2 || ncb > T2_MAXCB || g.K < 3 * T2_BK || g.K % T2_BK) return 0;
     int G = mc_device_cus();
     if (nblocks < (long)G * 16) G = (int)(nblocks / 16) > 0 ? (int)(nblocks / 16) : 1;          // small launches: >= 16 blocks per workgroup
+    else G *= (int)cdiv(nblocks, (long)G * 66);                                                 // large ones: several ranges per CU, each within a wave's 17 blocks
     const int nmax = (int)cdiv(nblocks, (long)G);                                               // largest range; its pieces have <= ceil(nmax / 4) blocks
     const int per_wave = cdiv(nmax, 4);
     const int max_rt = (ncb - 1 + nmax - 1) / ncb + 1;                                          // row tiles a range of nmax blocks can touch
