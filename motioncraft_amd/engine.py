@@ -303,13 +303,15 @@ class NativeContext:
         _lib.check(self.lib.mc_ctx_get_buffer(self.handle, name.encode(), int(layer), ctypes.byref(p), ctypes.byref(n)),
                    'mc_ctx_get_buffer')
         out = torch.empty(n.value, device='cuda', dtype=dtype)
-        torch.cuda.current_stream().synchronize()
+        # stream-ordered copy on the CURRENT torch stream: a plain hipMemcpy device-to-device is enqueued on the null stream and does not
+        # block the host, so under a non-default (non-blocking) torch stream the reads of `out` that follow could overtake it
         import ctypes as _c
         hip = _c.CDLL('libamdhip64.so')
-        hip.hipMemcpy.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int]
-        rc = hip.hipMemcpy(_c.c_void_p(out.data_ptr()), p, n.value * out.element_size(), 3)
+        hip.hipMemcpyAsync.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]
+        rc = hip.hipMemcpyAsync(_c.c_void_p(out.data_ptr()), p, n.value * out.element_size(), 3, _c.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f'hipMemcpy failed: {rc}')
+            raise RuntimeError(f'hipMemcpyAsync failed: {rc}')
+        torch.cuda.current_stream().synchronize()
         return out
 
     def close(self):
