@@ -822,6 +822,28 @@ __device__ __forceinline__ void gload16(f32x4& v, const float* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform n computed from the pipeline's own counts (the hand-counted waits of the tail kernels: in-order
+// vmcnt, "everything but the n youngest operations has landed")
+__device__ __forceinline__ void vm_wait(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;      // (n >= 14: waiting for more than asked is always safe)
+    }
+}
+
 template <int NBLK>
 __global__ __launch_bounds__(256) void gemm_tail_k(TailArgs g) {
     constexpr int NB = 16 * NBLK, NWP = NB / 8;
@@ -890,14 +912,16 @@ __global__ __launch_bounds__(256) void gemm_tail_k(TailArgs g) {
     if (NK > 1) { a_load(1, c1, u1); w_issue(1); }
     if (NK > 2) { a_load(2, c2, u2); w_issue(2); }
     // A(0) has landed once at most W0 A1 W1 A2 W2 are outstanding (NK >= 3 for every model width; otherwise wait for everything)
-    if (NK > 2) { if (nw == 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int A_OPS = 4;                                  // vector-memory operations of one a_load: 2 slots x (conditional + unconditional row)
+    static_assert(NWP <= 8, "a wave issues at most two W pieces per stage: the counted waits below assume nw <= 2");
+    vm_wait(NK > 2 ? 3 * nw + 2 * A_OPS : 0);
+    asm volatile("" : "+v"(c0[0]), "+v"(c0[1]), "+v"(u0[0]), "+v"(u0[1]));      // (the loaded set is consumed only behind the wait: ADVICE r04)
     a_store(0, c0, u0);
     // one iteration: stage kt is consumed; A(kt + 1) (set `st`) goes into its LDS stage; A(kt + 3) is requested into the set tile kt used
     auto step = [&](int kt, f32x4 (&cs)[2], f32x4 (&us)[2], f32x4 (&cl)[2], f32x4 (&ul)[2]) {
         // everything up to A(kt + 1) has landed once only W(kt+1) A(kt+2) W(kt+2) are outstanding
-        if (kt + 2 < NK) { if (nw == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vm_wait(kt + 2 < NK ? 2 * nw + A_OPS : 0);
+        asm volatile("" : "+v"(cs[0]), "+v"(cs[1]), "+v"(us[0]), "+v"(us[1]));
         __syncthreads();
         if (kt + 1 < NK) a_store(kt + 1, cs, us);
         if (kt + 3 < NK) { a_load(kt + 3, cl, ul); w_issue(kt + 3); }
@@ -962,22 +986,6 @@ constexpr int T2_STAGE = 16 * (T2_MAXRT + T2_MAXCB) * T2_BK;            // float
 constexpr int T2_WROW0 = 16 * T2_MAXRT;                                 // first W row of a stage
 
 __device__ __forceinline__ int t2_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }      // F = {0, 2, 3, 1}, two bits each: 0b01111000 >> {0, 2, 4, 6}
-
-__device__ __forceinline__ void t2_wait(int n) {      // s_waitcnt vmcnt(n), n uniform
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    }
-}
 
 template <int NBW>        // blocks per wave handled by the static part (a wave's piece has <= NBW + 1 blocks)
 __global__ __launch_bounds__(256, 2) void gemm_tail2_k(TailArgs g, int ncb, long nblocks) {
@@ -1071,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tail2_k(TailArgs g, int ncb, long
     // two A register sets in rotation: tile k lives in set k & 1, requested three iterations before it is consumed
     f32x4 c0[2], u0[2], c1[2], u1[2];
     a_load(0, c0, u0);
-    t2_wait(0);
+    vm_wait(0);
     asm volatile("" : "+v"(c0[0]), "+v"(c0[1]), "+v"(u0[0]), "+v"(u0[1]));
     a_store(0, c0, u0);
     a_load(1, c1, u1);
@@ -1081,7 +1089,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tail2_k(TailArgs g, int ncb, long
     // queue now: A(1) W(0) A(2) W(1)
     auto step = [&](int kt, f32x4 (&cs)[2], f32x4 (&us)[2]) {
         // A(kt + 1) and W(kt) have landed once only the previous iteration's issues -- A(kt + 2), W(kt + 1) -- are outstanding
-        t2_wait((kt + 2 < nk ? na : 0) + (kt + 1 < nk ? nwp : 0));
+        vm_wait((kt + 2 < nk ? na : 0) + (kt + 1 < nk ? nwp : 0));
         asm volatile("" : "+v"(cs[0]), "+v"(cs[1]), "+v"(us[0]), "+v"(us[1]));              // (the set is consumed only behind the wait)
         if (kt + 1 < nk) a_store(kt + 1, cs, us);
         __syncthreads();
