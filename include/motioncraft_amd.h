@@ -170,7 +170,9 @@ int mc_ctx_set_tie_policy(mc_ctx* c, int32_t policy);
  * meaning only seed the defaults of contexts created afterwards; two contexts of one process may differ.  Keys:
  *   "chain" (bit mask), "big_tokens", "split_groups", "small_gemm_rows", "split_rows_expert",
  *   "split_rows_sffn", "split_expert", "split_sffn", "temporal_split", "rowchain_split", "gemm_tune", "small_tile_n",
- *   "gemm_wp_grid", "half_min_rows", "gate_small", "route_reg", "route_small", "route_coop", "route_per".
+ *   "gemm_wp_grid", "half_min_rows", "gate_small", "route_reg", "route_small", "route_coop", "route_per",
+ *   "dbg_delay_us" (tests: holds the second sample group's stream that long in front of every layer tail, so the two-stream
+ *   schedule runs far out of phase; results must not change).
  * Results never depend on them beyond fp32 summation order where DESIGN.md says so.  Unknown key -> MC_ERR_ARG.
  * Not while a captured graph exists (mc_ctx_graph_release first). */
 int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value);
@@ -227,7 +229,8 @@ int mc_sample_step_inpaint(mc_ctx* c, const float* x_t_dev, int32_t step_index, 
                            void* stream);
 
 /* ---- introspection for tests --------------------------------------------------------- */
-/* named context buffers: "h","z","proj","mf","qkv","ys","yt","a","z2","out2","emb","ss","tf",
+/* named context buffers: "h","z","proj","mf","qkv","ys","yt","a" (fp32 rows; refused while a reduced-precision context keeps fp16
+ * planes there),"a_tail" (the deferred last FiLM block's fp32 rows),"z2","out2","emb","ss","tf",
  * "idx","gate","comb_w","key","cap_idx","cap_w" (layer selects tf / ss / cap slices) */
 int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr, int64_t* numel);
 
