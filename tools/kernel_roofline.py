@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 B, T, H, L, F, E, Nt, D = 64, 196, 12, 128, 512, 16, 77, 1536
 N = 2 * B * T * H                    # tokens of the CFG-doubled batch
 rows = 2 * B * T
@@ -27,6 +27,7 @@ FLOPS = {
     ('pqbody_k<128, 12>', None): TWIN * (2.0 * N * (L * 4 * L + L * 3 * L) + 2.0 * rows * (2 * H * H * L + 8 * 2 * H * (L // 8) ** 2 * 2)),      # + static and dynamic body topology
     ('gemm_small16_k<3, false>', None): 2.0 * (B * T) * 322 * D * 2,
     ('gemm_tail_k<3>', None): 2.0 * (B * T) * 322 * D * 2,                      # round 4: the folded decoder tail in one pass
+    ('gemm_tail2_k<16>', None): 2.0 * (B * T) * 322 * D * 2,                    # round 5: the same as block ranges, A read once (both K groups in one launch)
     ('temporal_k<128, false>', None): 2.0 * B * H * ((Nt + T) * L * L + T * L * L) * 2,
     ('gate_k<128>', 602112): 2.0 * N * (L * 256 + 256 * E),
     ('gemm_small_k<false>', None): 2.0 * (B * T) * 322 * D * 2,
