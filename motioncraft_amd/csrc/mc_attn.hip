@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void body_reg_k(const float* __restrict__ mf, 
 template <int L, bool LSPLIT, bool PAIR = false>
 __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                      const float* __restrict__ mask, float* __restrict__ yt,
-                                                     int b0, int B, int T, int Nt, int H, const int* twin_flag) {
+                                                     int b0, int B, int T, int Nt, int H, const int* twin_flag, int skip_text) {
     static_assert(!PAIR || (L == 64 && !LSPLIT), "temporal_k: PAIR is the L = 64 whole-part form");
     constexpr int LW = PAIR ? 2 * L : L; // columns of the staged slabs
     constexpr int NT = L / 32;           // 32-wide d tiles of a part (= MFMA waves per part)
@@ -193,6 +193,21 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
         mv = n < Nt ? cnd : mm;
     };
 
+    // Unconditional half (round 5): its text keys all carry the -1e6 of st_attention.py:153 and its text values are multiplied by c = 0
+    // (:161), so -- as long as the sample has at least ONE valid frame, whose key then sets the column maximum -- every text row's
+    // softmax numerator underflows to exactly 0 and its value row is exactly 0: the rows contribute nothing, bit for bit.  Whole leading
+    // blocks of them are skipped: multiples of the stats pass's row batch (so every remaining row keeps its slice / slot, i.e. its place in
+    // the online max / sum) and of the 32-row chunks of phase 2 (so the MFMA pairs (n, n + 1) and their order stay what they were).
+    constexpr int BATCH = LSPLIT ? 12 : 8;           // (small batches: 3 round trips to L2 instead of 5 for the 273 rows; the extra registers are free there)
+    int skip1 = 0, skip2 = 0;
+    if constexpr (!LSPLIT) {
+        if (b >= B && skip_text) {                    // (uniform per workgroup)
+            int v = 0;
+            for (int t = tid; t < T; t += 256) v |= mrow[t] != 0.f;
+            if (__syncthreads_or(v)) { skip1 = Nt / (NSL * BATCH) * (NSL * BATCH); skip2 = Nt / 32 * 32; }
+        }
+    }
+
     // ---- phase 1: column max / sum over the sequence (softmax dim=1, st_attention.py:155) ----
     // rows are taken in batches of 8 independent loads (a row-by-row online update serialises one
     // global-load latency per row); one rescale per batch instead of per row
@@ -200,8 +215,7 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
         const int c4 = (tid % C4) * 4, sl = tid / C4;
         // log2 domain: k2 = k * log2(e); exp(k - m) = exp2(k2 - m2) is one v_exp_f32
         f32x4 m = {-3e38f, -3e38f, -3e38f, -3e38f}, s = {0.f, 0.f, 0.f, 0.f};
-        constexpr int BATCH = LSPLIT ? 12 : 8;       // (small batches: 3 round trips to L2 instead of 5 for the 273 rows; the extra registers are free there)
-        for (int n0 = sl; n0 < Nseq; n0 += NSL * BATCH) {
+        for (int n0 = skip1 + sl; n0 < Nseq; n0 += NSL * BATCH) {
             f32x4 kk[BATCH];
             float mv[BATCH];
 #pragma unroll
@@ -258,8 +272,9 @@ __global__ __launch_bounds__(256, 3) void temporal_k(const float* __restrict__ m
             issue_kv(ch * 32 + i / C4, (i % C4) * 4, pk[j], pv[j], pm[j]);
         }
     };
-    prefetch_kv(0);
-    for (int ch = 0; ch < nch; ++ch) {
+    const int ch0 = skip2 / 32;
+    prefetch_kv(ch0);
+    for (int ch = ch0; ch < nch; ++ch) {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int i = tid + 256 * j;
@@ -416,7 +431,8 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 }
 
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
-                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag, long lsplit_max, bool pair) {
+                       int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag, long lsplit_max, bool pair, bool skip_text) {
+    const int sk = skip_text ? 1 : 0;
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
     // small batches: a few dozen (sample, part) workgroups, each bound by its waves' serial MFMA chain -> cut the L output
@@ -425,17 +441,17 @@ int mc_launch_temporal(const float* mf, const float* tf, const float* mask, floa
     if (L >= 64 && (long)nb * H <= lsplit_max) {
         grid.y = L / 32;
         grid.z = (long)nb * H * (L / 32) * 2 <= 256 ? 2 : 1;      // still one workgroup per CU: the output rows halved as well (B=1: 96 -> 192 workgroups)
-        if (L == 128) hipLaunchKernelGGL((temporal_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-        else hipLaunchKernelGGL((temporal_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        if (L == 128) hipLaunchKernelGGL((temporal_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
+        else hipLaunchKernelGGL((temporal_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
         MC_LAUNCH_CHECK();
         return MC_OK;
     }
-    if (L == 128) hipLaunchKernelGGL((temporal_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+    if (L == 128) hipLaunchKernelGGL((temporal_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
     else if (L == 64 && pair && H % 2 == 0) {       // two parts per workgroup: every wave on the MFMA
         grid.x = nb * (H / 2);
-        hipLaunchKernelGGL((temporal_k<64, false, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-    } else if (L == 64) hipLaunchKernelGGL((temporal_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-    else if (L == 32) hipLaunchKernelGGL((temporal_k<32, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        hipLaunchKernelGGL((temporal_k<64, false, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
+    } else if (L == 64) hipLaunchKernelGGL((temporal_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
+    else if (L == 32) hipLaunchKernelGGL((temporal_k<32, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
     else { mc_set_error("temporal: latent_dim=%d unsupported (32, 64, 128)", L); return MC_ERR_ARG; }
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -56,4 +56,4 @@ int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const m
 // temporal_k (mc_attn.hip) with both contractions on the fp16 MFMA (softmax statistics, masks and scalings fp32); L = 128 / 64,
 // whole-(sample, part) workgroups only (the column-sliced small-batch form stays on temporal_k)
 int mc_launch_temporal_h(const float* mf, const float* tf, const float* mask, float* yt, int b0, int nb, int B, int T, int Nt, int H, int L,
-                         bool split, hipStream_t s, const int* twin_flag);
+                         bool split, hipStream_t s, const int* twin_flag, bool skip_text = false);

@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g, const mc_ha
 template <int L, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__ mf, const float* __restrict__ tf,
                                                        const float* __restrict__ mask, float* __restrict__ yt,
-                                                       int b0, int B, int T, int Nt, int H, const int* twin_flag) {
+                                                       int b0, int B, int T, int Nt, int H, const int* twin_flag, int skip_text) {
     static_assert(L == 128 || L == 64, "temporal_h_k: L");
     constexpr int NT = L / 32, C4 = L / 4, NSL = 256 / C4, P = SPLIT ? 2 : 1;
     constexpr int PL = L * 32;                  // halves of one transposed plane chunk [L][32 n] (= one Q slab plane [32 t][L])
@@ -941,6 +941,14 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
         const float* rm = mf + (((long)bm * T + t) * H + h) * D4 + L;
         return txt ? rt : rm;
     };
+    // unconditional half: whole leading 32-row chunks of its text rows (numerators exactly 0, values exactly +-0 while the sample has a
+    // valid frame) are skipped in phase 2 -- see temporal_k (mc_attn.hip); the stats pass keeps all rows (its row batch is wider than the text)
+    int ch0 = 0;
+    if (b >= B && skip_text) {                    // (uniform per workgroup)
+        int v = 0;
+        for (int t = tid; t < T; t += 256) v |= mrow[t] != 0.f;
+        if (__syncthreads_or(v)) ch0 = Nt / 32;
+    }
     // ---- phase 1: column max / sum (log2 domain), temporal_k's pass ----
     {
         const int c4 = (tid % C4) * 4, sl = tid / C4;
@@ -1065,9 +1073,9 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
             }
         }
     };
-    prefetch(0, pfA, pmvA);
+    prefetch(ch0, pfA, pmvA);
     if constexpr (SPLIT) {
-        for (int ch = 0; ch < nch; ch += 2) {
+        for (int ch = ch0; ch < nch; ch += 2) {
             if (ch + 1 < nch) prefetch(ch + 1, pfB, pmvB);
             __builtin_amdgcn_sched_barrier(0);
             commit(ch, pfA, pmvA);
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void temporal_h_k(const float* __restrict__
         }
     } else {
         // plain fp16: one register set (128 VGPRs: four workgroups per CU hide the round trips better than the second set does at two)
-        for (int ch = 0; ch < nch; ++ch) {
+        for (int ch = ch0; ch < nch; ++ch) {
             commit(ch, pfA, pmvA);
             __syncthreads();
             if (ch + 1 < nch) prefetch(ch + 1, pfA, pmvA);
@@ -1329,16 +1337,17 @@ int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half
 }
 
 int mc_launch_temporal_h(const float* mf, const float* tf, const float* mask, float* yt, int b0, int nb, int B, int T, int Nt, int H, int L,
-                         bool split, hipStream_t s, const int* twin_flag) {
+                         bool split, hipStream_t s, const int* twin_flag, bool skip_text) {
     MC_REQUIRE(L == 128 || L == 64, "fp16 temporal attention: latent_dim=%d unsupported (128, 64)", L);
+    const int sk = skip_text ? 1 : 0;
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
     if (L == 128) {
-        if (split) hipLaunchKernelGGL((temporal_h_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-        else hipLaunchKernelGGL((temporal_h_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        if (split) hipLaunchKernelGGL((temporal_h_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
+        else hipLaunchKernelGGL((temporal_h_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
     } else {
-        if (split) hipLaunchKernelGGL((temporal_h_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
-        else hipLaunchKernelGGL((temporal_h_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag);
+        if (split) hipLaunchKernelGGL((temporal_h_k<64, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
+        else hipLaunchKernelGGL((temporal_h_k<64, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
     }
     MC_LAUNCH_CHECK();
     return MC_OK;

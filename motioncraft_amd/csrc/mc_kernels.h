@@ -150,4 +150,5 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
 int mc_launch_temporal(const float* mf, const float* tf, const float* mask, float* yt,
                        int b0, int nb, int B, int T, int Nt, int H, int L, hipStream_t s, const int* twin_flag = nullptr,
                        long lsplit_max = 96,     // up to this many (sample, part) workgroups the output columns are sliced over blockIdx.y
-                       bool pair = false);       // L = 64, even H, beyond lsplit_max: two adjacent parts per workgroup
+                       bool pair = false,        // L = 64: two parts per workgroup
+                       bool skip_text = false);  // the unconditional half skips whole leading blocks of its (masked, zero-valued) text rows: the same bits       // L = 64, even H, beyond lsplit_max: two adjacent parts per workgroup

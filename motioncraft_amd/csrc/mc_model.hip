@@ -77,7 +77,9 @@ struct McOptions {
     //    runs as gate_small_k (32-token workgroups, the same bits) on the OTHER group's stream, beside the big launch instead of behind it.
     //    OFF by default: measured SLOWER (B=64 19.47 -> 19.55 ms/step, B=32 10.10 -> 10.14, same-box A/B twice): the 608 small workgroups
     //    (each wave re-reads its projector chunks from L2, wave 0 walks the logit chain alone) take longer than the partial round they replace
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22);     // (all but bits 3 and 23)
+    // 24 (round 5) temporal_k: the unconditional CFG half skips whole leading blocks of its text rows (keys at -1e6, values x 0: exact zeros
+    //    as long as the sample has a valid frame) -- the same bits, ~20 % less of that half's kernel
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24);     // (all but bits 3 and 23)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
                                        // S2G at 32 per GPU 27.65 -> 27.14; at 4704 rows (B=24) the small kernels still do, 7.85 vs 7.91)
@@ -664,9 +666,9 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     if (use_half(c) && chain_on(c, 20) && (L == 128 || L == 64) && (long)tnb * H > c->opt.temporal_split) {
         // reduced-precision mode: both contractions on the fp16 MFMA (whole-(sample, part) workgroups; the sliced small-batch form stays fp32)
         if ((r = mc_launch_temporal_h(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), tnb, c->B, c->T, g.max_text_len, H, L,
-                                      c->prec == MC_PREC_F16X3, stt, twin_flag))) return r;
+                                      c->prec == MC_PREC_F16X3, stt, twin_flag, chain_on(c, 24)))) return r;
     } else if ((r = mc_launch_temporal(c->mf, tfl, c->mask, c->yt, (int)(row0 / c->T), tnb, c->B, c->T,
-                                       g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split, chain_on(c, 22)))) return r;
+                                       g.max_text_len, H, L, stt, twin_flag, c->opt.temporal_split, chain_on(c, 22), chain_on(c, 24)))) return r;
     if (stt != s) MC_HIP(hipEventRecord(c->ev_join, stt));
     if (st != s) MC_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
     return MC_OK;

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 8388599        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3 and 23
+DEFAULT_CHAIN = 8388599 | (1 << 24)        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3 and 23
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)
@@ -1554,6 +1554,41 @@ def test_fp16_modes_use_the_fp32_kernels_at_tiny_batches(monkeypatch):
     other = run('f16x3')
     assert not torch.equal(ref, other) and maxabs(ref, other) < 1e-3
     nm.close()
+
+
+def test_unconditional_half_skips_its_text_rows_bit_identically(full_model):
+    """chain bit 24 (round 5): in temporal_k the unconditional CFG half's text keys all carry the -1e6 of st_attention.py:153 and its text
+    values are multiplied by c = 0 (:161) -- exact zeros in the column softmax and in K^T V as long as the sample has one valid frame --
+    so whole leading blocks of those rows are skipped.  Must be the SAME BITS: B=16 x 196 frames in the large-batch schedule, ragged
+    lengths, one sample of length 1 and one FULLY masked sample (no valid frame: its text rows are all it has, nothing may be skipped);
+    y_t of base layer 0 and the decoded output, bit on / off.  Also at L = 64 (two parts per workgroup)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    for dims, tag in ((FULL, 'L128'), (W.default_dims(L=64, F=256), 'L64')):
+        nm = full_model[1] if tag == 'L128' else NativeModel(dims, W.make_state_dict(dims, 3), cfg_scale=dims['scale'])
+        B, T = 16, 196
+        g = torch.Generator().manual_seed(25)
+        lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+        lengths[3], lengths[7] = 1, 0
+        x_T, xf, mask = synth_inputs(dims, B, T, seed=36, lengths=lengths)
+        for prec in (('f32', 'f16x3', 'f16') if tag == 'L128' else ('f32',)):      # (reduced-precision contexts: temporal_h_k skips the same chunks)
+            got = {}
+            for arm, chain in (('skip', DEFAULT_CHAIN), ('all_rows', DEFAULT_CHAIN & ~(1 << 24))):
+                ctx = nm.context(B, T, max_steps=1)
+                ctx.set_option('chain', chain)
+                ctx.set_precision(prec)
+                ctx.set_timesteps([640])
+                ctx.set_condition(xf.cuda(), mask.cuda())
+                out = ctx.denoise(x_T.cuda(), 0).clone()
+                ctx.denoise(x_T.cuda(), 0, stop_after_layers=1)
+                torch.cuda.synchronize()
+                got[arm] = (out, ctx.buffer('yt').clone())
+                ctx.close()
+            assert bool(torch.isfinite(got['skip'][0]).all())
+            assert torch.equal(got['skip'][1], got['all_rows'][1]), (tag, prec, maxabs(got['skip'][1], got['all_rows'][1]))
+            assert torch.equal(got['skip'][0], got['all_rows'][0]), (tag, prec, maxabs(got['skip'][0], got['all_rows'][0]))
+        if tag != 'L128':
+            nm.close()
 
 
 def test_gate_launch_cut_at_whole_rounds_is_bit_identical(full_model):
