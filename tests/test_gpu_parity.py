@@ -123,7 +123,7 @@ def test_folded_decoder_tail_op_both_kernels_vs_fp64():
     from motioncraft_amd.engine import _ptr, _stream
     lib = L_.load(require_gpu=True)
     for it, (M, N, K) in enumerate([(75, 263, 512), (72, 322, 1536), (1000, 322, 1536), (12544, 322, 1536), (3136, 251, 768), (200, 16, 64),
-                                    (6272, 322, 1536), (4097, 322, 96)]):
+                                    (6272, 322, 1536), (4097, 322, 96), (5, 322, 64), (17, 100, 128), (300, 336, 96), (33, 17, 160), (19200, 322, 768)]):
         g = torch.Generator(device='cuda').manual_seed(it)
         h = torch.randn(2 * M, K, device='cuda', generator=g)
         a = torch.randn(2 * M, K, device='cuda', generator=g)
