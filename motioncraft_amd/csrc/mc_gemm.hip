@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wp_k(GemmArgs g) {
         return f;
     };
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int bid = xcd_remap(t, ntiles);
+        const int bid = (g.tune & 64) ? t : xcd_remap(t, ntiles);
         const int tm = bid / ntn, tn = bid % ntn;
         const int row0 = tm * BM;
         unsigned voa[4], vow[4];
