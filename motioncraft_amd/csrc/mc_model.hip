@@ -127,7 +127,7 @@ struct mc_ctx {
     // fp16 hi | lo planes of BOTH sample groups there, and fp32 rows written into it by one group's stream would land on the plane rows
     // the other group's gemm_hd_k may still be reading; null in fp32 contexts (then `a` itself holds fp32 rows only)
     float* a_tail = nullptr;
-    long dbg_delay_us = 0;       // tests (option "dbg_delay_us"): hold the SECOND sample group's stream this long in front of every layer tail, so the groups run far out of phase
+    long dbg_delay_us = 0;       // tests (option "dbg_delay_us"): hold the second (> 0) or the first (< 0) sample group's stream this long in front of every layer tail, so the groups run far out of phase
     size_t hbuf_cap = 0;        // floats allocated behind hbuf
     size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
     bool cnt_clean = false;     // the routing state's (choice, expert) counts are known to be zero on the stream (route_small_k cleans up after itself)
@@ -861,8 +861,11 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
             if ((r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 1))) return r;
             if ((r = layer_rows(c, i, hs, step, twin, 0, half_rows, s, s, 2))) return r;
             if ((r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 2))) return r;
-            for (int k = 0; k < c->nparts; ++k)
+            for (int k = 0; k < c->nparts; ++k) {
+                if (c->dbg_delay_us != 0 && k == (c->dbg_delay_us > 0 ? 1 : 0) &&
+                    (r = mc_launch_spin((c->dbg_delay_us > 0 ? c->dbg_delay_us : -c->dbg_delay_us) * 100, part_stream(c, k, s)))) return r;
                 if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+            }
             return MC_OK;
         }
         if (grouped && twin) {         // group 1 combines group 0's expert rows (its own tokens have no slots): fork after them
@@ -885,7 +888,9 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
             }
         }
         for (int k = 0; k < c->nparts; ++k) {
-            if (k == 1 && c->dbg_delay_us > 0 && (r = mc_launch_spin(c->dbg_delay_us * 100, part_stream(c, k, s)))) return r;
+            // (tests) hold one sample group's stream: > 0 the second group, < 0 the first
+            if (c->dbg_delay_us != 0 && k == (c->dbg_delay_us > 0 ? 1 : 0) &&
+                (r = mc_launch_spin((c->dbg_delay_us > 0 ? c->dbg_delay_us : -c->dbg_delay_us) * 100, part_stream(c, k, s)))) return r;
             if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
         }
         if (split == 1 && (r = parts_join(c, s))) return r;
@@ -1205,7 +1210,7 @@ int mc_ctx_set_option(mc_ctx* c, const char* key, int64_t value) {
     else if (k == "small_tile_n") o.small_tile_n = (int)value;
     else if (k == "gemm_wp_grid") o.gemm_wp_grid = (int)value;
     else if (k == "half_min_rows") c->half_min_rows = value;
-    else if (k == "dbg_delay_us") { MC_REQUIRE(value >= 0 && value <= 100000, "dbg_delay_us: 0 .. 100000"); c->dbg_delay_us = value; }
+    else if (k == "dbg_delay_us") { MC_REQUIRE(value >= -100000 && value <= 100000, "dbg_delay_us: -100000 .. 100000"); c->dbg_delay_us = value; }
     else if (k == "gate_small") c->gate_small_tokens = value;
     else if (k == "split_expert") c->split_expert = (int)value;
     else if (k == "split_sffn") c->split_sffn = (int)value;

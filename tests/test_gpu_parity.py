@@ -1556,6 +1556,39 @@ def test_fp16_modes_use_the_fp32_kernels_at_tiny_batches(monkeypatch):
     nm.close()
 
 
+@pytest.mark.parametrize('prec', ['f32', 'f16x3'])
+def test_two_stream_schedule_is_race_free_under_stream_skew(full_model, prec):
+    """The large-batch schedule runs the two sample groups on two HIP streams that only meet at the routing step of a layer and in
+    front of the decoder tail; in a normal run they stay within half a kernel of each other, which can hide a missing dependency.
+    `dbg_delay_us` holds one group's stream for 1.5 ms in front of every layer tail (either group: > 0 the second, < 0 the first), so
+    each group in turn runs a whole FiLM block + SFFN ahead of the other: two sampler steps at B=16 x 196 must give the SAME BITS as the
+    undelayed run (fp32, and the fp16 split mode whose FiLM operand planes share one buffer between the groups)."""
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = full_model
+    B, T = 16, 196
+    g = torch.Generator().manual_seed(45)
+    lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+    x_T, xf, mask = synth_inputs(FULL, B, T, seed=46, lengths=lengths)
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+    eps = torch.randn(B, T, 322, generator=g).cuda()
+    got = {}
+    for arm, delay in (('plain', 0), ('second_late', 1500), ('first_late', -1500)):
+        ctx = nm.context(B, T, max_steps=2)
+        ctx.set_precision(prec)
+        ctx.set_option('dbg_delay_us', delay)
+        ctx.set_timesteps(d.timestep_map[-2:])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        x = x_T.cuda()
+        for i in (1, 0):
+            x = ctx.sample_step(x, i, d.step_coefs(998 + i, 'ddpm', FULL['scale']), eps)
+        torch.cuda.synchronize()
+        got[arm] = x.clone()
+        ctx.close()
+    assert bool(torch.isfinite(got['plain']).all())
+    assert torch.equal(got['plain'], got['second_late']), maxabs(got['plain'], got['second_late'])
+    assert torch.equal(got['plain'], got['first_late']), maxabs(got['plain'], got['first_late'])
+
+
 def test_unconditional_half_skips_its_text_rows_bit_identically(full_model):
     """chain bit 24 (round 5): in temporal_k the unconditional CFG half's text keys all carry the -1e6 of st_attention.py:153 and its text
     values are multiplied by c = 0 (:161) -- exact zeros in the column softmax and in K^T V as long as the sample has one valid frame --
