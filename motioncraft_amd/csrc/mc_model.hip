@@ -642,6 +642,10 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
         MC_HIP(hipEventRecord(c->ev_fork, s));
         MC_HIP(hipStreamWaitEvent(st, c->ev_fork, 0));
         if (chain_on(c, 14) && c->rows <= 1200) sb = st; else stt = st;      // (B <= 3 at 196 frames: -1.5 .. -3 %; B = 4: +1 %)
+        if (c->dbg_delay_us != 0) {        // (tests) hold the side stream (> 0) or the main stream (< 0) behind the fork
+            int r2 = mc_launch_spin((c->dbg_delay_us > 0 ? c->dbg_delay_us : -c->dbg_delay_us) * 100, c->dbg_delay_us > 0 ? st : s);
+            if (r2 != MC_OK) return r2;
+        }
     }
     // ---- dynamic body topology: shared LayerNorm + q/k/v ----
     if (pq_fused || phase == 2) {

@@ -1565,28 +1565,30 @@ def test_two_stream_schedule_is_race_free_under_stream_skew(full_model, prec):
     undelayed run (fp32, and the fp16 split mode whose FiLM operand planes share one buffer between the groups)."""
     from motioncraft_amd.diffusion import build_diffusion
     sd, nm = full_model
-    B, T = 16, 196
-    g = torch.Generator().manual_seed(45)
-    lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
-    x_T, xf, mask = synth_inputs(FULL, B, T, seed=46, lengths=lengths)
     d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
-    eps = torch.randn(B, T, 322, generator=g).cuda()
-    got = {}
-    for arm, delay in (('plain', 0), ('second_late', 1500), ('first_late', -1500)):
-        ctx = nm.context(B, T, max_steps=2)
-        ctx.set_precision(prec)
-        ctx.set_option('dbg_delay_us', delay)
-        ctx.set_timesteps(d.timestep_map[-2:])
-        ctx.set_condition(xf.cuda(), mask.cuda())
-        x = x_T.cuda()
-        for i in (1, 0):
-            x = ctx.sample_step(x, i, d.step_coefs(998 + i, 'ddpm', FULL['scale']), eps)
-        torch.cuda.synchronize()
-        got[arm] = x.clone()
-        ctx.close()
-    assert bool(torch.isfinite(got['plain']).all())
-    assert torch.equal(got['plain'], got['second_late']), maxabs(got['plain'], got['second_late'])
-    assert torch.equal(got['plain'], got['first_late']), maxabs(got['plain'], got['first_late'])
+    # B = 16: the large-batch two-stream schedule; B = 2: the small-batch schedule (temporal branch / body branch forked onto the side stream
+    # inside every layer: the same option holds the side or the main stream behind the fork)
+    for B, T in ((16, 196), (2, 196)):
+        g = torch.Generator().manual_seed(45)
+        lengths = [int(v) for v in torch.randint(64, 197, (B,), generator=g)]
+        x_T, xf, mask = synth_inputs(FULL, B, T, seed=46, lengths=lengths)
+        eps = torch.randn(B, T, 322, generator=g).cuda()
+        got = {}
+        for arm, delay in (('plain', 0), ('second_late', 1500 if B > 2 else 300), ('first_late', -1500 if B > 2 else -300)):
+            ctx = nm.context(B, T, max_steps=2)
+            ctx.set_precision(prec)
+            ctx.set_option('dbg_delay_us', delay)
+            ctx.set_timesteps(d.timestep_map[-2:])
+            ctx.set_condition(xf.cuda(), mask.cuda())
+            x = x_T.cuda()
+            for i in (1, 0):
+                x = ctx.sample_step(x, i, d.step_coefs(998 + i, 'ddpm', FULL['scale']), eps)
+            torch.cuda.synchronize()
+            got[arm] = x.clone()
+            ctx.close()
+        assert bool(torch.isfinite(got['plain']).all())
+        assert torch.equal(got['plain'], got['second_late']), (B, maxabs(got['plain'], got['second_late']))
+        assert torch.equal(got['plain'], got['first_late']), (B, maxabs(got['plain'], got['first_late']))
 
 
 def test_unconditional_half_skips_its_text_rows_bit_identically(full_model):
