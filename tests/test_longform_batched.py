@@ -116,6 +116,40 @@ def _worker(rank, ws, port, q):
         dist.destroy_process_group()
 
 
+def _worker_repaint(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    try:
+        # uneven shard (5 sequences over 2 ranks: 3 + 2), ragged lengths, RePaint chaining, chunks smaller than the shard
+        totals, L, pre, C = [60, 42, 100, 78, 60], 24, 6, 5
+        g = torch.Generator().manual_seed(21)
+        c = [torch.randn(t, 7, generator=g) for t in totals]
+        first = torch.randn(len(totals), 6, C, generator=g)
+        kw = dict(c=c, text='x', repaint=True, overlap_len=6, first_gt=first, input_dim=C, device=torch.device('cpu'), max_batch=2)
+        recs, wins = longform.sample_long_batched(WindowFn(), totals, L, pre, shard=True, **kw)
+        ref, _ = longform.sample_long_batched(WindowFn(), totals, L, pre, shard=False, **kw)
+        mine = longform.rank_sequences(len(totals), rank, ws)
+        ok = (mine == ([0, 1, 2] if rank == 0 else [3, 4]) and sorted({s for s, _ in wins}) == mine
+              and all(np.array_equal(a, b) for a, b in zip(recs, ref)) and [r.shape[0] for r in recs] == [18 * (n - 1) + 24 for n in (3, 2, 5, 4, 3)])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_repaint_mode_uneven_shards_ragged_lengths_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_repaint, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
+
+
 def test_configs3_partition_640_windows_over_4_ranks_gloo():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
