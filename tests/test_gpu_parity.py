@@ -1309,6 +1309,26 @@ def test_repaint_outpainting_mode_vs_reference_golden(small_model):
         m.ctx.close()
 
 
+def test_sample_tool_writes_the_amass_style_npz(tmp_path):
+    """tools/sample.py (the counterpart of the reference's tools/visualize.py:170-260 flow: config + checkpoint -> sampled motion -> SMPL-X
+    .npz) end to end in a child process on the small config with deterministic random-init weights: two prompts of different lengths in
+    one call, then the fp16 split mode with hipGraph replay; the file holds the AMASS-style arrays of the concatenated valid frames."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    base = [sys.executable, os.path.join(root, 'tools', 'sample.py'), os.path.join(HERE, 'configs', 'stmogen_small.py'), 'synthetic:3',
+            '--random-condition', '5', '--out', str(tmp_path)]
+    r = subprocess.run(base + ['--text', 'a person walks', 'a dancer spins', '--motion_length', '24', '18'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    path = os.path.join(str(tmp_path), 'res_a_person_walks_24.npz')
+    z = np.load(path)
+    assert z['poses'].shape[0] == 24 + 18 and z['poses'].shape[1] == 165 and z['trans'].shape == (42, 3)
+    assert all(np.isfinite(z[k]).all() for k in z.files if z[k].dtype.kind == 'f')
+    r = subprocess.run(base + ['--text', 'a person walks', '--motion_length', '24', '--fp16', 'split', '--graph'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.load(path)['poses'].shape == (24, 165)
+
+
 def test_smplx_postprocessing_vs_scipy_restatement(tmp_path):
     """de-normalise + 322 -> poses/expressions/trans + scipy gaussian_filter(mode='nearest') on the
     device, against oracle/postprocess_oracle.py (the reference tools' own numpy/scipy lines), for float32 stats files
