@@ -82,6 +82,11 @@ struct RowChainArgs {
     float* ys = nullptr;
     long split_tokens = 20480;     // rowchain: launches of up to this many tokens slice the output chunks 4 ways over blockIdx.y
     long pad_row = -1;             // projqkv: first of 128 PADDING rows of Y and Y2 (behind the last real token): invalid lanes store there unconditionally
+    // pqbody: an optional SECOND token range [tok2, N2) covered by the same launch (workgroups nblk1 .. of the grid; nblk1 = 0: none).
+    // The twin layer's front launches it for the aliased rows of the second CFG half: those workgroups exit at once in the usual case,
+    // and as part of the front's own launch they start inside its tail instead of queueing for LDS behind the next kernel
+    long tok2 = 0, N2 = 0;
+    int nblk1 = 0;
 };
 
 bool mc_mlp_supported(int L, int hidden);

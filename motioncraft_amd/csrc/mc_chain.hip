@@ -896,7 +896,11 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
 // NQ = H: the set produces all H parts of its frames; NQ < H: parts [h0, h0 + NQ) only (the fifth pass is cut 4 ways by parts:
 // every wave rebuilds A = k^T v of the two odd frames and projects H / 4 of their query rows)
 template <int L, int H>
-__global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
+__global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g_in) {
+    RowChainArgs g = g_in;                       // (uniform copy: workgroups of the second token range swap in its bounds)
+    long bidx = blockIdx.x;
+    if (g.nblk1 > 0 && bidx >= g.nblk1) { bidx -= g.nblk1; g.tok0 = g.tok2; g.N = g.N2; }
+    if (g.alias.split_flag && *g.alias.split_flag == 0 && g.tok0 + bidx * (long)BodyPhase<L, H>::TR >= g.alias.from) return;      // (before anything is staged)
     constexpr int NJ = L / 8, NC0 = 4 * L / 32, NG = L / 32, NKEEP = L / 32, NSEQ = NC0 + 3 * NG;
     using BP = BodyPhase<L, H>;
     constexpr int TR = BP::TR, XS = BP::XS;         // token rows of a tile, exchange slot row stride
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void pqbody_k(RowChainArgs g) {
     for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
     for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
     for (int i = tid; i < H * H; i += 256) s_w[i] = g.wsm[i];
-    const long tile_tok0 = g.tok0 + (long)blockIdx.x * TR;
+    const long tile_tok0 = g.tok0 + bidx * TR;
     const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
     if (aliasing && tile_tok0 >= g.alias.from) return;
     const int r = wave * 32 + (lane & 31);
@@ -1017,9 +1021,16 @@ int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s) {
     MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
     if (g.N <= g.tok0) return MC_OK;
     const long frames = (g.N - g.tok0) / H;
+    RowChainArgs gg = g;
     dim3 grid(cdiv(frames, 128 / H));
-    if (g.L == 128) hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((pqbody_k<64, 12>), grid, dim3(256), 0, s, g);
+    gg.nblk1 = 0;
+    if (g.nblk1 != 0) {           // second token range in the same launch (any non-zero nblk1 asks for it; the real count is set here)
+        MC_REQUIRE(g.tok2 % H == 0 && g.N2 % H == 0 && g.N2 >= g.tok2 && g.pad_row >= g.N2, "pqbody: bad second token range [%ld, %ld)", g.tok2, g.N2);
+        gg.nblk1 = (int)grid.x;
+        grid.x += cdiv((g.N2 - g.tok2) / H, 128 / H);
+    }
+    if (g.L == 128) hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, gg);
+    else hipLaunchKernelGGL((pqbody_k<64, 12>), grid, dim3(256), 0, s, gg);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -748,9 +748,13 @@ __global__ __launch_bounds__(256, 2) void projqkv_h_k(RowChainArgs g, const mc_h
 // LDS slots; q/k/v never reach HBM, ys is written from here.  Body arithmetic fp32 (identical to body_reg_k's).
 // =================================================================================================
 template <int L, int H, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g, const mc_half* __restrict__ Wph, const mc_half* __restrict__ Wpl,
+__global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g_in, const mc_half* __restrict__ Wph, const mc_half* __restrict__ Wpl,
                                                      const mc_half* __restrict__ Wqh, const mc_half* __restrict__ Wql) {
     using BP = BodyPhase<L, H>;
+    RowChainArgs g = g_in;                       // (second token range: see pqbody_k)
+    long bidx = blockIdx.x;
+    if (g.nblk1 > 0 && bidx >= g.nblk1) { bidx -= g.nblk1; g.tok0 = g.tok2; g.N = g.N2; }
+    if (g.alias.split_flag && *g.alias.split_flag == 0 && g.tok0 + bidx * (long)BP::TR >= g.alias.from) return;
     constexpr int TR = BP::TR, XS = BP::XS;
     constexpr int P = SPLIT ? 2 : 1, NKB = L / 16, NJ = L / 8, NC0 = 4 * L / 32, NG = L / 32, NKEEP = L / 32, NSEQ = NC0 + 3 * NG;
     constexpr int LD1 = L + 8, S1 = 32 * LD1;             // weight chunk [32 out rows][L] per plane
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void pqbody_h_k(RowChainArgs g, const mc_ha
     for (int i = tid; i < 4 * L; i += 256) s_bias[i] = g.bias[i];
     for (int i = tid; i < 3 * L; i += 256) s_bias[4 * L + i] = g.bias2[i];
     for (int i = tid; i < H * H; i += 256) s_w[i] = g.wsm[i];
-    const long tile_tok0 = g.tok0 + (long)blockIdx.x * TR;
+    const long tile_tok0 = g.tok0 + bidx * TR;
     const bool aliasing = g.alias.split_flag && *g.alias.split_flag == 0;
     if (aliasing && tile_tok0 >= g.alias.from) return;
     const int r = wave * 32 + (lane & 31);
@@ -1306,12 +1310,19 @@ int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const m
     MC_REQUIRE(g.tok0 % H == 0 && g.N % H == 0, "fp16 pqbody: token range [%ld, %ld) is not made of whole frames", g.tok0, g.N);
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv((g.N - g.tok0) / H, 128 / H));
+    RowChainArgs gg = g;
+    gg.nblk1 = 0;
+    if (g.nblk1 != 0) {           // second token range in the same launch (mc_launch_pqbody)
+        MC_REQUIRE(g.tok2 % H == 0 && g.N2 % H == 0 && g.N2 >= g.tok2 && g.pad_row >= g.N2, "fp16 pqbody: bad second token range [%ld, %ld)", g.tok2, g.N2);
+        gg.nblk1 = (int)grid.x;
+        grid.x += cdiv((g.N2 - g.tok2) / H, 128 / H);
+    }
     if (g.L == 128) {
-        if (split) hipLaunchKernelGGL((pqbody_h_k<128, 12, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
-        else hipLaunchKernelGGL((pqbody_h_k<128, 12, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+        if (split) hipLaunchKernelGGL((pqbody_h_k<128, 12, true>), grid, dim3(256), 0, s, gg, Wph, Wpl, Wqh, Wql);
+        else hipLaunchKernelGGL((pqbody_h_k<128, 12, false>), grid, dim3(256), 0, s, gg, Wph, Wpl, Wqh, Wql);
     } else {
-        if (split) hipLaunchKernelGGL((pqbody_h_k<64, 12, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
-        else hipLaunchKernelGGL((pqbody_h_k<64, 12, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql);
+        if (split) hipLaunchKernelGGL((pqbody_h_k<64, 12, true>), grid, dim3(256), 0, s, gg, Wph, Wpl, Wqh, Wql);
+        else hipLaunchKernelGGL((pqbody_h_k<64, 12, false>), grid, dim3(256), 0, s, gg, Wph, Wpl, Wqh, Wql);
     }
     MC_LAUNCH_CHECK();
     return MC_OK;

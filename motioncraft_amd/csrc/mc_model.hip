@@ -79,7 +79,15 @@ struct McOptions {
     //    (each wave re-reads its projector chunks from L2, wave 0 walks the logit chain alone) take longer than the partial round they replace
     // 24 (round 5) temporal_k: the unconditional CFG half skips whole leading blocks of its text rows (keys at -1e6, values x 0: exact zeros
     //    as long as the sample has a valid frame) -- the same bits, ~20 % less of that half's kernel
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24);     // (all but bits 3 and 23)
+    // 25 (round 5) twin layer: the fused front of a sample sub-group covers that sub-group's aliased twins in the same launch (pqbody_k's second
+    //    token range) instead of a launch of its own behind the cross-join
+    //    OFF by default: the same bits, but measured SLOWER (B=64 19.20 -> 19.30, 19.25 -> 19.36 ms/step): the 125 us by which the separate no-op
+    //    launch held the second group's stream back were doing useful work -- they kept the two chains out of phase (see bit 26)
+    // 26 (round 5) the second sample group's first FiLM block (proj_out) starts behind the first group's FiLM ROW kernel (one event per layer):
+    //    the two HBM-bound row kernels never run against each other and the groups' GEMM / SFFN launches leave the seam half a kernel apart
+    //    instead of in lockstep (B=64 19.08 -> 18.94, 19.14 -> 19.01, 19.12 -> 19.00 ms/step; a 60 us spin at the same place: the same).
+    //    Only in exact-fp32 contexts at L = 128: measured slower in the fp16 modes (f16 6.86 -> 7.08) and at L = 64 (M2D 17.62 -> 18.00), neutral at batch 32
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26);     // (all but bits 3, 23 and 25)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
                                        // S2G at 32 per GPU 27.65 -> 27.14; at 4704 rows (B=24) the small kernels still do, 7.85 vs 7.91)
@@ -527,7 +535,9 @@ static float* deferred_a(const mc_ctx* c) { return c->a_tail ? c->a_tail : c->a;
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
-               bool prologue_only = false, TwinAlias y1_alias = TwinAlias(), const HalfW* hw = nullptr, int y1_parts = 1) {
+               bool prologue_only = false, TwinAlias y1_alias = TwinAlias(), const HalfW* hw = nullptr, int y1_parts = 1,
+               hipEvent_t ev_after_rows = nullptr) {
+    // ev_after_rows: recorded on s behind the row kernel (the other sample group's FiLM block may be ordered behind it: run_layer)
     // y1_parts > 1: y1 = that many partial planes of [nrows][D] starting AT y1 (rows relative to row0), summed by the row kernel
     const int D = c->m->cfg.latent_dim * c->m->cfg.num_parts;
     const long o = row0 * D;
@@ -544,6 +554,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     float* a_out = planes ? reinterpret_cast<float*>(reinterpret_cast<mc_half*>(c->a) + o) : a_rows + o;
     if ((r = mc_launch_film_rows(y1_parts > 1 ? y1 : y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, a_out, nrows, D, s, y1_alias, row0, sref,
                                  y1_parts, nrows * D, planes ? (c->prec == MC_PREC_F16X3 ? 2 : 1) : 0, pstride))) return r;
+    if (ev_after_rows) MC_HIP(hipEventRecord(ev_after_rows, s));
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
     if (planes) {
@@ -581,7 +592,8 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
 // FiLM block.  Every kernel here is row-independent, so disjoint row ranges can run on different streams.
 // `phase`: 0 = everything; 1 = the front only (combine + proj, LN + q/k/v, body topology); 2 = the temporal attention only
 // (the twin layer of the large-batch schedule runs the front per sample sub-group and the rest per CFG half: run_layer)
-int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st, int phase = 0) {
+int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipStream_t st, int phase = 0, long rows2_0 = -1) {
+    // rows2_0 >= 0 (phase 1, fused front only): the same launch also covers rows [rows2_0, rows2_0 + nrows) -- the aliased twins of this range
     // twin layer: rows of the second CFG half whose routing equals their twin's are aliased, not recomputed
     TwinAlias tok_alias, frame_alias;
     const int* twin_flag = nullptr;
@@ -616,6 +628,7 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
             p.pad_row = c->N;      // mf / qkv carry 128 padding rows (mc_ctx_create): projqkv_k's stores are unconditional
             if (body_fused) {
                 p.wsm = w.wsm; p.ys = c->ys;
+                if (rows2_0 >= 0) { p.tok2 = rows2_0 * H; p.N2 = (rows2_0 + nrows) * H; p.nblk1 = 1; }
                 if (use_half(c) && w.h_proj.hi && w.h_qkv.hi) {
                     if ((r = mc_launch_pqbody_h(p, H, w.h_proj.hi, w.h_proj.lo, w.h_qkv.hi, w.h_qkv.lo, c->prec == MC_PREC_F16X3, s))) return r;
                 } else if ((r = mc_launch_pqbody(p, H, s))) return r;
@@ -678,7 +691,10 @@ int layer_rows(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long
     return MC_OK;
 }
 
-int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s) {
+int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0, long nrows, hipStream_t s, hipEvent_t ev_rows = nullptr,
+                    hipEvent_t wait_first = nullptr) {
+    // ev_rows: recorded behind the first FiLM block's row kernel; wait_first: this range's tail starts behind that event of the other group
+    if (wait_first) MC_HIP(hipStreamWaitEvent(s, wait_first, 0));
     const mc_model_config& g = c->m->cfg;
     const int L = g.latent_dim, H = g.num_parts, D = L * H, F = g.ffn_dim;
     const LayerW& w = c->lw[i];
@@ -686,7 +702,7 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
     const float* ss0 = c->ss + ((long)(i * 2 + 0) * c->maxS + step) * 2 * D;
     TwinAlias ys_alias;
     if (twin && chain_on(c, 8) && !c->no_alias) { ys_alias.split_flag = mc_route_split_flag_ptr(c->rb); ys_alias.from = c->rows / 2; }
-    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias, &w.h_ca_out))) return r;
+    if ((r = film_block(c, hs, c->ys, c->yt, w.ca_ln_g, w.ca_ln_b, ss0, w.ca_out_w, w.ca_out_b, row0, nrows, s, false, ys_alias, &w.h_ca_out, 1, ev_rows))) return r;
     // ---- SFFN (stmogen.py:596-607): 12 part-wise FFNs as grouped GEMMs ----
     const long o = row0 * D;
     int z2_parts = 1;
@@ -844,6 +860,9 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
     }
     // ---- the row-independent rest of the layer ----
     const long half = (long)c->B * c->T;        // rows of one CFG half
+    // (measured per shape, same-box A/B: helps the exact-fp32 L = 128 step; the fp16 modes -- whose GEMMs are a small part of the chain -- lose 0.1 - 0.2 ms and the
+    //  L = 64 models (M2D) 0.35 ms with it, batch 32 is neutral: applied where it helps)
+    const bool evstag = split == 2 && c->nparts == 2 && chain_on(c, 26) && !chain_on(c, 23) && !use_half(c) && L == 128;      // (bit 23 uses the same event)
     if (split) {
         // Large batches: the two CFG halves go down two streams.  Each kernel of the chain fills 4.59 "waves" of
         // workgroups at B=64, so ~8 % of every launch is a tail on a partly idle chip; with two independent chains in
@@ -854,21 +873,30 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
             if ((r = parts_fork(c, s))) return r;
             if ((r = moe_experts(c, w.mm, c->z, c->N, 0, s, &w.h_fc1, &w.h_fc2))) return r;
             if ((r = moe_experts(c, w.mm, c->z, c->N, 1, s1, &w.h_fc1, &w.h_fc2))) return r;
-            if ((r = layer_rows(c, i, hs, step, twin, 0, sub_rows, s, s, 1))) return r;
-            if ((r = layer_rows(c, i, hs, step, twin, sub_rows, half_rows - sub_rows, s1, s1, 1))) return r;
+            // (round 5, chain bit 25) the fused front of a sub-group also covers that sub-group's twins in the second CFG half: in the usual case
+            // (no twin pair split by a capacity cut) those workgroups exit at once, and as part of THIS launch they start inside its tail --
+            // as a launch of their own behind the cross-join they queued for LDS behind the other stream's temporal kernel (~125 us per step
+            // in front of the second group's temporal kernel: profiles/r05_b64_timeline.txt).  A twin reads its ORIGINAL's expert rows, and the
+            // original belongs to the same sub-group, i.e. the same stream: no new dependency.
+            const int L_ = g.latent_dim;
+            const bool front_covers_twins = chain_on(c, 25) && chain_on(c, 2) && chain_on(c, 10) && chain_on(c, 15) && c->N > c->opt.big_tokens &&
+                                            mc_mlp_supported(L_, 32) && H == 12 && g.dyn_heads == 8 && (L_ == 128 || L_ == 64);
+            if ((r = layer_rows(c, i, hs, step, twin, 0, sub_rows, s, s, 1, front_covers_twins ? half_rows : -1))) return r;
+            if ((r = layer_rows(c, i, hs, step, twin, sub_rows, half_rows - sub_rows, s1, s1, 1, front_covers_twins ? half_rows + sub_rows : -1))) return r;
             // cross-join: each stream waits for the other's front
             MC_HIP(hipEventRecord(c->ev_join, s));
             MC_HIP(hipEventRecord(c->ev_parts[0], s1));
             MC_HIP(hipStreamWaitEvent(s1, c->ev_join, 0));
             MC_HIP(hipStreamWaitEvent(s, c->ev_parts[0], 0));
             // the second CFG half's own front: exits at once while no twin pair was split by a capacity cut (the usual case)
-            if ((r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 1))) return r;
+            if (!front_covers_twins && (r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 1))) return r;
             if ((r = layer_rows(c, i, hs, step, twin, 0, half_rows, s, s, 2))) return r;
             if ((r = layer_rows(c, i, hs, step, twin, half_rows, half_rows, s1, s1, 2))) return r;
             for (int k = 0; k < c->nparts; ++k) {
                 if (c->dbg_delay_us != 0 && k == (c->dbg_delay_us > 0 ? 1 : 0) &&
                     (r = mc_launch_spin((c->dbg_delay_us > 0 ? c->dbg_delay_us : -c->dbg_delay_us) * 100, part_stream(c, k, s)))) return r;
-                if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+                if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s),
+                                         (evstag && k == 0) ? c->ev_gate : nullptr, (evstag && k == 1) ? c->ev_gate : nullptr))) return r;
             }
             return MC_OK;
         }
@@ -895,7 +923,8 @@ int run_layer(mc_ctx* c, int i, float* hs, int step, bool twin_ok, int split, hi
             // (tests) hold one sample group's stream: > 0 the second group, < 0 the first
             if (c->dbg_delay_us != 0 && k == (c->dbg_delay_us > 0 ? 1 : 0) &&
                 (r = mc_launch_spin((c->dbg_delay_us > 0 ? c->dbg_delay_us : -c->dbg_delay_us) * 100, part_stream(c, k, s)))) return r;
-            if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s)))) return r;
+            if ((r = layer_rows_tail(c, i, hs, step, twin, part_row0(c, k), part_row0(c, k + 1) - part_row0(c, k), part_stream(c, k, s),
+                                     (evstag && k == 0) ? c->ev_gate : nullptr, (evstag && k == 1) ? c->ev_gate : nullptr))) return r;
         }
         if (split == 1 && (r = parts_join(c, s))) return r;
         return MC_OK;
