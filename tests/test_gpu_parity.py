@@ -1060,7 +1060,8 @@ def test_hipgraph_replay_of_the_sampler_step_is_bit_identical(prec):
     d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x',
                              model_var_type='fixed_large', respace='15,15,8,6,6'))
     S = d.num_timesteps
-    for dims, copy, feats, B, T, seed in ((CTRL, CTRL_COPY, CTRL_FEATS, 2, 24, SMALL_SEED), (FULL, 2, 35, 3, 196, 0)):
+    # (third case: B = 16 -- the large-batch two-stream schedule with its fork / join / ordering events inside the capture)
+    for dims, copy, feats, B, T, seed in ((CTRL, CTRL_COPY, CTRL_FEATS, 2, 24, SMALL_SEED), (FULL, 2, 35, 3, 196, 0), (FULL, 2, 35, 16, 196, 0)):
         sd = W.make_state_dict(dims, seed, shapes=W.control_param_shapes(dims, copy, feats))
         nm = NativeModel(dims, sd, cfg_scale=dims['scale'])
         x_T, xf, mask = synth_inputs(dims, B, T, seed=51, lengths=[T - 3] + [T] * (B - 1))
