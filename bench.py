@@ -98,6 +98,16 @@ def executed_flops_per_sample_step(d, T):
     return total + T * 2 * 322 * 2 * D                        # folded tail on the combined rows
 
 
+def csrc_digest():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'motioncraft_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def lone_dominant_kernel():
     """The dominant kernel's LONE-launch figure (serial single-stream schedule, so a launch's duration is the kernel's own): read from the
     newest tracked profiles/rNN_kernel_roofline.txt (tools/kernel_roofline.py over the rocprofv3 --pmc pass; its header carries the
@@ -107,11 +117,14 @@ def lone_dominant_kernel():
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_roofline.txt')))
     if not files:
         return None
-    src, commit, row = files[-1], None, None
+    src, commit, row, digest = files[-1], None, None, None
     for line in open(src):
         mc_ = re.match(r'# commit (\S+)', line)
         if mc_:
             commit = mc_.group(1)
+        md = re.match(r'# csrc sha256 (\S+)', line)
+        if md:
+            digest = md.group(1)
         if row is None and line.startswith('gemm_wp_k'):
             row = line.split()
     if not row:
@@ -120,6 +133,9 @@ def lone_dominant_kernel():
             'avg_us': float(row[3]), 'gflop_per_launch': float(row[4]), 'achieved': float(row[5]), 'frac': round(float(row[6]) / 100, 4),
             'mfma_util_pct': float(row[7]), 'clock_ghz': float(row[8]),
             'source': os.path.relpath(src, ROOT) + (f' @ commit {commit}' if commit else ''),
+            # the table is a tracked profile, not measured in this run: `stale` = the kernel sources it was profiled from are not the ones of
+            # the library being timed now (sha256 over motioncraft_amd/csrc, written by tools/kernel_roofline.py; None = the table carries no digest)
+            'stale': (digest != csrc_digest()) if digest else None,
             'how': 'lone whole-batch launches of the serial schedule, rocprofv3 --kernel-trace --pmc pass (duration and counters of the same dispatches)'}
 
 
@@ -228,8 +244,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # MC_BENCH_FORCE_DIST=1: initialise the process group at world size 1 too, so a 1-GPU lease executes the RCCL branch (device
+    # broadcast, barrier(device_ids), all_gather_into_tensor, the fp64 max-over-ranks reduce) -- profiles/r06_bench_n1_rccl_world1.json
+    use_dist = world > 1 or os.environ.get('MC_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if a.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -253,7 +275,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank]) if a.backend == 'nccl' else dist.barrier()
         torch.cuda.synchronize()
 
@@ -573,7 +595,7 @@ def main():
             control_cfgs = {'error': f'{type(e).__name__}: {e}'}
 
     t = torch.tensor([t_loop, t_setup, t_gather, ev_ms, t_full or 0.0], device=dev if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_loop, t_setup, t_gather, ev_ms, t_full_max = (float(v) for v in t)
     t_step = t_loop / a.steps
@@ -601,6 +623,8 @@ def main():
                        'batch_per_gpu': B, 'global_batch': GB, 'frames': T, 'parallelism': f'dp{world}',
                        'weights': 'random-init (name-keyed deterministic), no checkpoint offline',
                        'setup_s': round(t_setup, 4), 'gather_s': round(t_gather, 4),
+                       'process_group': (f'{a.backend} (RCCL), world size {world}' + (' -- forced at one rank by MC_BENCH_FORCE_DIST=1' if world == 1 else '')
+                                         if a.backend == 'nccl' else f'{a.backend}, world size {world}') if use_dist else None,
                        'frames_per_s_formula': 'N*B*T / (setup_s + 1000*ms_per_step/1e3 + gather_s)',
                        'full_loop': full_loop, 'reduced_precision_modes': reduced, 'configs0_gpu': configs0, 'configs4': configs4, 'control_configs': control_cfgs,
                        'batches_in_flight': 1, 'two_batches_in_flight': inflight2,
@@ -627,7 +651,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -234,6 +234,12 @@ int mc_sample_step_inpaint(mc_ctx* c, const float* x_t_dev, int32_t step_index, 
  * "idx","gate","comb_w","key","cap_idx","cap_w" (layer selects tf / ss / cap slices) */
 int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr, int64_t* numel);
 
+/* FLOP ledger for the per-kernel roofline (tools/kernel_roofline.py; off by default): while enabled, every launcher books the useful
+ * multiply-add work (x 2) of each launch under its kernel's name.  mc_debug_flop_ledger(1) clears and starts, (0) stops;
+ * mc_debug_flop_ledger_dump writes "kernel<TAB>calls<TAB>flops" lines into buf (truncated at cap) and returns the size needed. */
+int mc_debug_flop_ledger(int32_t enable);
+int64_t mc_debug_flop_ledger_dump(char* buf, int64_t cap);
+
 /* op-level entry points (kernel parity tests call these through the same ABI) */
 int mc_op_gemm(const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                float* c_dev, int32_t M, int32_t N, int32_t K, int32_t ldw, int32_t act, void* stream);

@@ -420,6 +420,7 @@ int mc_launch_body(const float* mf, long ldmf, const float* qkv, const float* ws
     const long groups = frames * G;               // (frame, head) groups of hd lanes
     const long waves = (groups * hd + 63) / 64;
     dim3 grid((unsigned)((waves + 3) / 4));
+    MC_LEDGER("body_reg_k", grid, (double)frames * (2.0 * H * H * L + G * 2.0 * (2.0 * H * hd * hd)));       // static mix + per-head linear attention over the H parts
 #define MC_BODY_CASE(HH)                                                                                          \
     if (hd == 16) hipLaunchKernelGGL((body_reg_k<16, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames, alias, frame0);    \
     else if (hd == 8) hipLaunchKernelGGL((body_reg_k<8, HH>), grid, dim3(256), 0, s, mf, ldmf, qkv, wsm, ys, frames, alias, frame0); \
@@ -435,6 +436,14 @@ int mc_launch_temporal(const float* mf, const float* tf, const float* mask, floa
     const int sk = skip_text ? 1 : 0;
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
+    if (mc_ledger_on) {       // per (sample, part): K^T V over Nt + T keys [L x L] and Q (K^T V) over T queries (efficient_attention.py:25-46)
+        char name[32];
+        snprintf(name, sizeof(name), "temporal_k<%d", L);
+        dim3 lg = grid;          // (the grid of the form launched below)
+        if (L >= 64 && (long)nb * H <= lsplit_max) { lg.y = L / 32; lg.z = (long)nb * H * (L / 32) * 2 <= 256 ? 2 : 1; }
+        else if (L == 64 && pair && H % 2 == 0) lg.x = nb * (H / 2);
+        MC_LEDGER(name, lg, (double)nb * H * (2.0 * (Nt + T) * L * L + 2.0 * T * L * L));
+    }
     // small batches: a few dozen (sample, part) workgroups, each bound by its waves' serial MFMA chain -> cut the L output
     // columns into 32-wide slices on blockIdx.y (temporal_k<L, true>).  50-step DDIM, 196 frames: B=1 70.4 -> 66.4 ms, B=2 96.1 ->
     // 92.3, B=4 128.3 -> 127.0; from B=8 (192 workgroups) the unsplit kernel is faster again

@@ -32,6 +32,7 @@ struct MlpArgs {
     // data-dependent and known on the device only.  The launch is then 1-D: workgroup b = (slice b / tiles, tile b % tiles).
     int dyn_split = 0;
     int dma = 0;                // L = 128, nsplit = 1: the LDS-DMA staged kernel mlp2d_k (same bits)
+    long ledger_rows = 0;       // MLP_EXPERT: slots of the routing this launch walks (FLOP ledger only; the real tile count lives on the device)
 };
 // ways a small-batch expert launch splits its hidden dimension, from the number of real tiles (host + device)
 __host__ __device__ inline int mc_mlp_dyn_ways(int real_tiles) { return (real_tiles * 4 <= 256 || real_tiles * 3 > 256) ? 4 : 3; }

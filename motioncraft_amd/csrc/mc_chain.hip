@@ -725,7 +725,14 @@ int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStre
         grid = dim3(cdiv(g.M, 128), groups, g.nsplit);
     }
     // L = 128 / 64 without a hidden split: the LDS-DMA staged form (needs 32-bit byte offsets into one group's weights)
-    if (g.dma && (g.L == 128 || g.L == 64) && g.nsplit == 1 && !g.dyn_split && (long)g.hidden * 128 * 4 < (1L << 31)) {
+    const bool dma_form = g.dma && (g.L == 128 || g.L == 64) && g.nsplit == 1 && !g.dyn_split && (long)g.hidden * 128 * 4 < (1L << 31);
+    if (mc_ledger_on) {
+        char name[48];
+        snprintf(name, sizeof(name), "%s<%d, %d>", dma_form ? "mlp2d_k" : "mlp2_k", g.L, mode == MLP_EXPERT ? 0 : 1);
+        const double rows = mode == MLP_EXPERT ? (double)g.ledger_rows : (double)g.M * groups;
+        MC_LEDGER(name, grid, rows * 4.0 * g.L * g.hidden);          // FC1 + FC2, multiply-add = 2
+    }
+    if (dma_form) {
         if (g.L == 128) {
             if (mode == MLP_EXPERT) hipLaunchKernelGGL((mlp2d_k<128, MLP_EXPERT>), grid, dim3(256), 0, s, g);
             else hipLaunchKernelGGL((mlp2d_k<128, MLP_PARTS>), grid, dim3(256), 0, s, g);
@@ -756,6 +763,12 @@ int mc_launch_gate(const GateArgs& g, hipStream_t s) {
     MC_REQUIRE(g.E >= 2 && g.E <= 16, "gate: num_experts=%d unsupported (2..16)", g.E);
     if (g.zero_cnt) MC_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * 32, s));
     if (g.N <= g.tok0) return MC_OK;
+    if (mc_ledger_on) {
+        char name[32];
+        snprintf(name, sizeof(name), "%s<%d>", g.N - g.tok0 <= g.small_tokens ? "gate_small_k" : "gate_k", g.L);
+        const dim3 lg(cdiv(g.N - g.tok0, g.N - g.tok0 <= g.small_tokens ? 32 : 128));
+        MC_LEDGER(name, lg, 2.0 * (double)(g.N - g.tok0) * (g.L * 256.0 + 256.0 * g.E));       // cosine projector + logits
+    }
     if (g.N - g.tok0 <= g.small_tokens) {        // latency-bound sizes (B <= 2 at 196 frames; B=1 -2.8 ms per 50 steps, B=4 +1 ms): 32-token workgroups
         dim3 grid(cdiv(g.N - g.tok0, 32));
         switch (g.L) {
@@ -869,6 +882,11 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
     MC_REQUIRE(g.pad_row >= g.N, "projqkv: pad_row (128 padding rows of Y / Y2 behind the last token) not set");
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv(g.N - g.tok0, 128));
+    if (mc_ledger_on) {
+        char name[32];
+        snprintf(name, sizeof(name), "projqkv_k<%d>", g.L);
+        MC_LEDGER(name, grid, 2.0 * (double)(g.N - g.tok0) * 7.0 * g.L * g.L);        // proj [4L, L] + q/k/v [3L, L]
+    }
     switch (g.L) {
         case 128: hipLaunchKernelGGL(projqkv_k<128>, grid, dim3(256), 0, s, g); break;
         case 64: hipLaunchKernelGGL(projqkv_k<64>, grid, dim3(256), 0, s, g); break;
@@ -1029,6 +1047,12 @@ int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s) {
         gg.nblk1 = (int)grid.x;
         grid.x += cdiv((g.N2 - g.tok2) / H, 128 / H);
     }
+    if (mc_ledger_on) {       // proj + q/k/v per token; per frame the static topology (H x H mix of L-vectors) and the dynamic one (8 heads of linear attention over the H parts: k^T v and q (k^T v), [hd x hd] each)
+        char name[32];
+        snprintf(name, sizeof(name), "pqbody_k<%d", g.L);
+        const double toks = (double)(g.N - g.tok0) + (g.nblk1 != 0 ? (double)(g.N2 - g.tok2) : 0.0), hd = g.L / 8.0;
+        MC_LEDGER(name, grid, 2.0 * toks * 7.0 * g.L * g.L + (toks / H) * (2.0 * H * H * g.L + 8 * 2.0 * (2.0 * H * hd * hd)));
+    }
     if (g.L == 128) hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, gg);
     else hipLaunchKernelGGL((pqbody_k<64, 12>), grid, dim3(256), 0, s, gg);
     MC_LAUNCH_CHECK();
@@ -1039,6 +1063,11 @@ int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s) {
     MC_REQUIRE(g.Nout % 32 == 0 && g.ldy % 4 == 0, "rowchain: Nout=%d / ldy unsupported", g.Nout);
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv(g.N - g.tok0, 128), (g.N - g.tok0 <= g.split_tokens && (g.Nout / 32) % 4 == 0) ? 4 : 1);
+    if (mc_ledger_on) {
+        char name[32];
+        snprintf(name, sizeof(name), "rowchain_k<%d, %d>", g.L, kind ? 1 : 0);
+        MC_LEDGER(name, grid, 2.0 * (double)(g.N - g.tok0) * g.Nout * g.L);
+    }
 #define MC_RC_CASE(LL)                                                                    \
     case LL:                                                                              \
         if (kind == 0) hipLaunchKernelGGL((rowchain_k<LL, 0>), grid, dim3(256), 0, s, g);  \

@@ -35,6 +35,15 @@ void mc_set_error(const char* fmt, ...);
 
 #define MC_LAUNCH_CHECK() MC_HIP(hipGetLastError())
 
+// debug FLOP ledger (mc_error.cpp; off unless mc_debug_flop_ledger(1)): launchers book the useful work of each launch under the kernel's name
+extern bool mc_ledger_on;
+void mc_ledger_add_(const char* kernel, long grid_threads, double flops);
+// `grid` = the launch's dim3 grid of 256-thread workgroups: rows are keyed "kernel@<work-items>", the `grid` column of a rocprofv3 kernel trace
+#define MC_LEDGER(kernel, grid, flops)                                                                                          \
+    do {                                                                                                                        \
+        if (mc_ledger_on) mc_ledger_add_((kernel), (long)(grid).x * (grid).y * (grid).z * 256, (double)(flops));              \
+    } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device math --------------------------------------------------------------------

@@ -42,7 +42,7 @@ struct GemmArgs {
     // launch options (a context passes its own, mc_ctx_set_option; the defaults come from the environment once per process)
     int small_tile_n = 0;           // mc_launch_gemm_small: force the tile width (64, 48, 96); 0 = the load model's choice (env MC_SMALL_TILE_N)
     int wp_grid = 0;                // workgroups of the persistent gemm_wp_k launch; 0 = default 512 (env MC_GEMM_WP_GRID), < 0 one per tile
-    int tune = -1;                  // -1 = process default (env MC_GEMM_TUNE, 817); bits: 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k, 8 (round 4) XCD-aware tile order in gemm_small_k (a row block's column tiles share one L2), 9 (round 4) the aligned pose-encoder GEMM on gemm_wp_k (table + duplicate rows in its epilogue)
+    int tune = -1;                  // -1 = process default (mc_gemm_default_tune(): env MC_GEMM_TUNE, else 1841 = 49 + 256 + 512 + 1024); bits: 0 mid-loop staging writes in gemm_k, 4 LDS-DMA kernels for full-tile plain launches, 5 (with 4) the persistent wave-private pipeline gemm_wp_k instead of gemm_dma_k, 6 no XCD remap in gemm_dma_k, 8 (round 4) XCD-aware tile order in gemm_small_k (a row block's column tiles share one L2), 9 (round 4) the aligned pose-encoder GEMM on gemm_wp_k (table + duplicate rows in its epilogue), 10 (round 5) the folded decoder tail as block ranges with A read once (gemm_tail2_k); bit 6 also switches the XCD remap of gemm_wp_k off
 };
 
 int mc_device_cus();      // compute units of the current device (cached)
@@ -72,4 +72,5 @@ struct TailArgs {
     int tune = -1;
 };
 int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream);
+int mc_gemm_default_tune();          // the resolved process default of GemmArgs::tune / TailArgs::tune
 bool mc_gemm_tail_two_outputs(const TailArgs& g);      // true: this launch writes the two partial products C and C2 (x0 = C + C2), else C alone

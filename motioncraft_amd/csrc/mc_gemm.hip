@@ -1152,6 +1152,7 @@ static int tune_bits() {
     }
     return v;
 }
+int mc_gemm_default_tune() { return tune_bits(); }
 
 int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     MC_REQUIRE(g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.a_col % 4 == 0 && g.a_gstride % 4 == 0 && g.w_gstride % 4 == 0 &&
@@ -1190,6 +1191,7 @@ int mc_launch_gemm_small(const GemmArgs& g, hipStream_t stream, int groups) {
     if (fnb == 64 || fnb == 48 || fnb == 96) nb = fnb;
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, nb), ng);
     const bool vec16 = vec && g.N % nb == 0;       // the float4 epilogue has no column guard
+    MC_LEDGER(nb == 48 ? "gemm_small16_k<3" : nb == 96 ? "gemm_small16_k<6" : "gemm_small_k", grid, 2.0 * g.M * g.N * g.K * ng);
     if (nb == 48) {
         if (vec16) hipLaunchKernelGGL((gemm_small16_k<3, true>), grid, dim3(256), 0, stream, gg);
         else hipLaunchKernelGGL((gemm_small16_k<3, false>), grid, dim3(256), 0, stream, gg);
@@ -1225,11 +1227,20 @@ int mc_launch_gemm(int mode, const GemmArgs& g0, int groups, int max_tiles, hipS
             static const int wp_grid = [] { const char* e = getenv("MC_GEMM_WP_GRID"); return e ? atoi(e) : 512; }();
             const int wpg = g.wp_grid ? g.wp_grid : wp_grid;
             const int persistent = wpg > 0 ? wpg : (int)grid.x;          // default: 2 workgroups per CU (64 KB of LDS each) on 256 CUs; <= 0: one workgroup per tile
+            MC_LEDGER("gemm_wp_k", dim3(grid.x < persistent ? grid.x : persistent), 2.0 * g.M * g.N * g.K);
             hipLaunchKernelGGL(gemm_wp_k, dim3(grid.x < persistent ? grid.x : persistent), dim3(256), 0, stream, g);
-        } else
+        } else {
+            MC_LEDGER("gemm_dma_k", grid, 2.0 * g.M * g.N * g.K);
             hipLaunchKernelGGL(gemm_dma_k, grid, dim3(256), 0, stream, g);
+        }
         MC_LAUNCH_CHECK();
         return MC_OK;
+    }
+    if (mc_ledger_on) {      // expert modes: booked at the tile capacity of the launch (the real tile count lives on the device)
+        char name[24];
+        snprintf(name, sizeof(name), "gemm_k<%d>", mode);
+        const double rows = (mode == GM_EXP1 || mode == GM_EXP2) ? (double)ntm * BM : (double)g.M;
+        MC_LEDGER(name, grid, 2.0 * rows * g.N * g.K * (groups > 0 ? groups : 1));
     }
     switch (mode) {
         case GM_PLAIN: hipLaunchKernelGGL(gemm_k<GM_PLAIN>, grid, dim3(256), 0, stream, g); break;
@@ -1272,8 +1283,28 @@ static int tail2_grid(const TailArgs& g, int tune, int* per_wave_out) {
 
 bool mc_gemm_tail_two_outputs(const TailArgs& g) { return tail2_grid(g, g.tune < 0 ? tune_bits() : g.tune, nullptr) > 0; }
 
+// The tail kernels wait for their LDS-DMA pieces with HAND-COUNTED s_waitcnt vmcnt(n) values: correct only while the compiler emits no
+// vector-memory instruction of its own inside the k-loop.  A register spill (scratch) would add such instructions and make the loops
+// under-wait without any error, so a build whose tail kernels use scratch is refused here, once per process.
+static int tail_kernels_scratch_free() {
+    static const int verdict = [] {
+        const void* fns[] = {(const void*)gemm_tail_k<3>, (const void*)gemm_tail2_k<4>, (const void*)gemm_tail2_k<8>, (const void*)gemm_tail2_k<12>,
+                             (const void*)gemm_tail2_k<16>};
+        for (const void* f : fns) {
+            hipFuncAttributes at;
+            if (hipFuncGetAttributes(&at, f) != hipSuccess) return -1;
+            if (at.localSizeBytes != 0) return (int)at.localSizeBytes;
+        }
+        return 0;
+    }();
+    return verdict;
+}
+
 int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream) {
     MC_REQUIRE(g.H && g.Af && g.W && g.bias && g.C, "gemm_tail: null operand");
+    MC_REQUIRE(tail_kernels_scratch_free() == 0,
+               "gemm_tail: a tail kernel of this build uses scratch memory (%d bytes per lane; -1 = attributes unreadable): its hand-counted vmcnt "
+               "waits are invalid -- rebuild with the toolchain the kernels were counted for", tail_kernels_scratch_free());
     MC_REQUIRE(g.K % BK == 0 && g.K >= BK && g.lda % 4 == 0 && g.ldw % 4 == 0 && g.half % 4 == 0 && g.w_gstride % 4 == 0,
                "gemm_tail: unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
     if (g.M <= 0 || g.N <= 0) return MC_OK;
@@ -1286,6 +1317,7 @@ int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream) {
         const int ncb = cdiv(g.N, 16);
         const long nblocks = (long)cdiv(g.M, 16) * ncb;
         dim3 grid(2 * G);                      // (range, K group)
+        MC_LEDGER("gemm_tail2_k", grid, 2.0 * g.M * g.N * g.K * 2);      // both K groups
         if (per_wave <= 5) hipLaunchKernelGGL((gemm_tail2_k<4>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
         else if (per_wave <= 9) hipLaunchKernelGGL((gemm_tail2_k<8>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
         else if (per_wave <= 13) hipLaunchKernelGGL((gemm_tail2_k<12>), grid, dim3(256), 0, stream, gg, ncb, nblocks);
@@ -1294,6 +1326,7 @@ int mc_launch_gemm_tail(const TailArgs& g, hipStream_t stream) {
         return MC_OK;
     }
     dim3 grid(cdiv(g.M, SM) * cdiv(g.N, 48));
+    MC_LEDGER("gemm_tail_k", grid, 2.0 * g.M * g.N * g.K * 2);
     hipLaunchKernelGGL((gemm_tail_k<3>), grid, dim3(256), 0, stream, gg);
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -1239,6 +1239,7 @@ int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
                    "fp16 gemm (planes): unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
         if (g.M <= 0) return MC_OK;
         dim3 grid(cdiv(g.M, 128) * (g.N / 128));
+        MC_LEDGER(split ? "gemm_hd_k<true>" : "gemm_hd_k<false>", grid, 2.0 * g.M * g.N * g.K);      // (fp32-equivalent product: the split form runs 3 fp16 MFMAs per operand pair)
         if (split) hipLaunchKernelGGL(gemm_hd_k<true>, grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL(gemm_hd_k<false>, grid, dim3(256), 0, s, g);
         MC_LAUNCH_CHECK();
@@ -1249,6 +1250,7 @@ int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
                "fp16 gemm: unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
     if (g.M <= 0) return MC_OK;
     dim3 grid(cdiv(g.M, 128) * (g.N / 128));
+    MC_LEDGER(split ? "gemm_h_k<true>" : "gemm_h_k<false>", grid, 2.0 * g.M * g.N * g.K);
     if (split) hipLaunchKernelGGL(gemm_h_k<true>, grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(gemm_h_k<false>, grid, dim3(256), 0, s, g);
     MC_LAUNCH_CHECK();
@@ -1269,6 +1271,13 @@ int mc_launch_mlp_h(int mode, const MlpArgs& g, const mc_half* W1h, const mc_hal
     } else {
         if (g.M <= 0) return MC_OK;
         grid = dim3(cdiv(g.M, 128), groups, 1);
+    }
+    if (mc_ledger_on) {
+        char name[48];
+        snprintf(name, sizeof(name), "%s<%d, %d, %s>", (g.dma && (g.L == 128 || g.L == 64)) ? "mlp2hd_k" : "mlp2_h_k", g.L, mode == MLP_EXPERT ? 0 : 1,
+                 split ? "true" : "false");
+        const double rows = mode == MLP_EXPERT ? (double)g.ledger_rows : (double)g.M * groups;
+        MC_LEDGER(name, grid, rows * 4.0 * g.L * g.hidden);
     }
     if (g.dma && (g.L == 128 || g.L == 64)) {     // LDS-DMA staged weight chunks (chain bit 18): the same bits
 #define MC_MLPHD(LL, MM, SS) hipLaunchKernelGGL((mlp2hd_k<LL, MM, SS>), grid, dim3(256), 0, s, g, W1h, W1l, W2h, W2l)
@@ -1317,6 +1326,12 @@ int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const m
         gg.nblk1 = (int)grid.x;
         grid.x += cdiv((g.N2 - g.tok2) / H, 128 / H);
     }
+    if (mc_ledger_on) {
+        char name[40];
+        snprintf(name, sizeof(name), "pqbody_h_k<%d, 12, %s>", g.L, split ? "true" : "false");
+        const double toks = (double)(g.N - g.tok0) + (g.nblk1 != 0 ? (double)(g.N2 - g.tok2) : 0.0), hd = g.L / 8.0;
+        MC_LEDGER(name, grid, 2.0 * toks * 7.0 * g.L * g.L + (toks / H) * (2.0 * H * H * g.L + 8 * 2.0 * (2.0 * H * hd * hd)));
+    }
     if (g.L == 128) {
         if (split) hipLaunchKernelGGL((pqbody_h_k<128, 12, true>), grid, dim3(256), 0, s, gg, Wph, Wpl, Wqh, Wql);
         else hipLaunchKernelGGL((pqbody_h_k<128, 12, false>), grid, dim3(256), 0, s, gg, Wph, Wpl, Wqh, Wql);
@@ -1334,6 +1349,11 @@ int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half
                "fp16 projqkv: bad arguments");
     if (g.N <= g.tok0) return MC_OK;
     dim3 grid(cdiv(g.N - g.tok0, 128));
+    if (mc_ledger_on) {
+        char name[40];
+        snprintf(name, sizeof(name), "projqkv_h_k<%d, %s>", g.L, split ? "true" : "false");
+        MC_LEDGER(name, grid, 2.0 * (double)(g.N - g.tok0) * 7.0 * g.L * g.L);
+    }
 #define MC_PQH(LL) case LL: if (split) hipLaunchKernelGGL((projqkv_h_k<LL, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql); \
                             else hipLaunchKernelGGL((projqkv_h_k<LL, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql); break;
     switch (g.L) {
@@ -1353,6 +1373,11 @@ int mc_launch_temporal_h(const float* mf, const float* tf, const float* mask, fl
     const int sk = skip_text ? 1 : 0;
     if (nb <= 0) return MC_OK;
     dim3 grid(nb * H), blk(256);
+    if (mc_ledger_on) {
+        char name[40];
+        snprintf(name, sizeof(name), "temporal_h_k<%d, %s>", L, split ? "true" : "false");
+        MC_LEDGER(name, grid, (double)nb * H * (2.0 * (Nt + T) * L * L + 2.0 * T * L * L));
+    }
     if (L == 128) {
         if (split) hipLaunchKernelGGL((temporal_h_k<128, true>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);
         else hipLaunchKernelGGL((temporal_h_k<128, false>), grid, blk, 0, s, mf, tf, mask, yt, b0, B, T, Nt, H, twin_flag, sk);

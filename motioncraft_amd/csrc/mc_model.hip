@@ -440,6 +440,7 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         // fused expert FFN: hidden activations stay on chip (mc_chain.hip)
         MlpArgs m;
         m.dma = chain_on(c, 18) ? 1 : 0;
+        m.ledger_rows = 2 * Ntok;
         m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
         m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
         m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
@@ -532,6 +533,15 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
 // the array the deferred last FiLM block's fp32 rows live in (read back by denoise_combined)
 static float* deferred_a(const mc_ctx* c) { return c->a_tail ? c->a_tail : c->a; }
 
+// ONE answer per context to "does `a` hold fp16 hi | lo planes instead of fp32 rows?" -- asked by film_block (which writes them) and by
+// mc_ctx_get_buffer("a") (which must not hand planes out as fp32 rows): reduced-precision context, chain bit 17, the plane launcher's
+// shape preconditions (N % 128, K % 64 via D % 128; 32-bit byte offsets into a plane).  Every per-step FiLM weight of a reduced-precision
+// context has planes (mc_ctx_set_precision builds them for all layers or fails), so the weight is not part of the answer.
+bool a_holds_planes(const mc_ctx* c) {
+    const long D = (long)c->m->cfg.latent_dim * c->m->cfg.num_parts;
+    return use_half(c) && chain_on(c, 17) && D % 128 == 0 && c->rows * D * 2 < (1L << 31);
+}
+
 // rows [row0, row0 + nrows) of:  a = silu(LN(y1 (+ y2)) * (1 + scale) + shift);  h += Linear(a)   (StylizationBlock)
 int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const float* ln_g, const float* ln_b,
                const float* ss, const float* out_w, const float* out_b, long row0, long nrows, hipStream_t s,
@@ -548,7 +558,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     // buffer: the rows of this range start at halves offset o, the lo plane sits rows * D halves behind the hi plane
     const bool half_gemm = !prologue_only && hw && hw->hi && use_half(c);
     // (the plane path's launcher needs N % 128 == 0, K % 64 == 0 and 32-bit byte offsets into a plane: anything else stays on dense_h)
-    const bool planes = half_gemm && chain_on(c, 17) && D % 128 == 0 && c->rows * D * 2 < (1L << 31);      // (one answer per context: plane rows and fp32 rows never share `a`)
+    const bool planes = half_gemm && a_holds_planes(c);      // (one answer per context: plane rows and fp32 rows never share `a`)
     const long pstride = c->rows * D;
     float* a_rows = prologue_only ? deferred_a(c) : c->a;
     float* a_out = planes ? reinterpret_cast<float*>(reinterpret_cast<mc_half*>(c->a) + o) : a_rows + o;
@@ -1732,7 +1742,7 @@ int mc_ctx_get_buffer(mc_ctx* c, const char* name, int32_t layer, void** dev_ptr
     else if (n == "yt") { p = c->yt; cnt = c->rows * D; }
     else if (n == "a") {
         // reduced-precision contexts keep fp16 hi | lo PLANES in `a` (film_block): not the fp32 [rows][D] rows this call promises
-        MC_REQUIRE(!(use_half(c) && chain_on(c, 17) && D % 128 == 0), "buffer 'a' holds fp16 planes in a reduced-precision context (clear chain bit 17 to read fp32 rows)");
+        MC_REQUIRE(!a_holds_planes(c), "buffer 'a' holds fp16 planes in a reduced-precision context (clear chain bit 17 to read fp32 rows)");
         p = c->a; cnt = c->rows * D;
     }
     else if (n == "a_tail") { p = deferred_a(c); cnt = c->rows * D; }
@@ -1788,11 +1798,13 @@ int mc_op_gemm_tail(const float* h, const float* a, const float* w, const float*
     t.C = cdev; t.ldc = N; t.M = M; t.N = N; t.K = K; t.wc = wc; t.wu = wu;
     t.tune = options_of(nullptr).gemm_tune;
     if (variant) {
-        if (t.tune < 0) t.tune = 49 + 256 + 512 + 1024;
+        if (t.tune < 0) t.tune = mc_gemm_default_tune();       // MC_GEMM_TUNE, or the built-in default
         t.tune = variant == 1 ? (t.tune & ~1024) : (t.tune | 1024);
     }
     t.C2 = c2dev;
     MC_REQUIRE(variant != 2 || c2dev, "gemm_tail variant 2 needs the scratch output c2_dev [M][N]");
+    MC_REQUIRE(variant != 2 || mc_gemm_tail_two_outputs(t),
+               "gemm_tail variant 2: the block-range form is not eligible for M=%d N=%d K=%d (N <= 336, K %% 16 == 0, K >= 48, <= 17 blocks per wave)", M, N, K);
     int r = mc_launch_gemm_tail(t, (hipStream_t)stream);
     if (r == MC_OK && mc_gemm_tail_two_outputs(t))       // the sampler-update kernel adds the two partial products in the step; here: C += C2
         r = mc_launch_axpby(cdev, c2dev, 1.f, 1.f, cdev, (long)M * N, (hipStream_t)stream);

@@ -134,6 +134,8 @@ _SIGNATURES = {
     'mc_wavenc_out_len': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'mc_wavenc_forward': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
     'mc_op_renoise': (ctypes.c_int, [_P, _P, ctypes.c_float, ctypes.c_float, _P, ctypes.c_int64, _P]),
+    'mc_debug_flop_ledger': (ctypes.c_int, [ctypes.c_int32]),
+    'mc_debug_flop_ledger_dump': (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -113,26 +113,26 @@ def rank_sequences(n_seq, rank, ws):
     return list(range(lo, lo + base + (1 if rank < extra else 0)))
 
 
-def _gather_ragged(local, n_seq, owners, input_dim, device):
-    """all-gather of per-sequence motions of different lengths: padded to the longest, one collective (dist.gather_results)."""
+def _gather_ragged(local, lengths, owners, input_dim, device):
+    """all-gather of per-sequence motions of different lengths in ONE collective (dist.gather_results): every rank pads its block to
+    the longest sequence of the job.  No length exchange: a stitched motion has (n_windows - 1) * stride + window frames, which every
+    rank computes from the global `total_frames` list (`lengths`: sequence -> frames)."""
     from . import dist as mcd
     if not mcd.is_dist():
         return local
     rank, ws = mcd.world()
     per = max(len(o) for o in owners)
-    lens = torch.zeros(per, dtype=torch.int64, device=device)
-    for k, s in enumerate(owners[rank]):
-        lens[k] = local[s].shape[0]
-    all_lens = mcd.gather_results(lens.view(per, 1)).view(ws, per)
-    maxlen = int(all_lens.max())
+    maxlen = max(lengths)
     buf = torch.zeros(per, maxlen, input_dim, device=device)
     for k, s in enumerate(owners[rank]):
-        buf[k, :local[s].shape[0]] = torch.as_tensor(local[s], device=device)
+        if local[s].shape[0] != lengths[s]:
+            raise RuntimeError(f'sequence {s}: stitched {local[s].shape[0]} frames, expected {lengths[s]}')
+        buf[k, :lengths[s]] = torch.as_tensor(local[s], device=device)
     allb = mcd.gather_results(buf).view(ws, per, maxlen, input_dim).cpu().numpy()
     out = {}
     for r in range(ws):
         for k, s in enumerate(owners[r]):
-            out[s] = allb[r, k, :int(all_lens[r, k])]
+            out[s] = allb[r, k, :lengths[s]]
     return out
 
 
@@ -149,7 +149,9 @@ def sample_long_batched(model, total_frames, motion_length, pre_frames=30, c=Non
     configs[3]: 128 sequences x 5 windows / 4 GPUs = 160).  shard: split the SEQUENCES over the ranks of an initialised process group
     (contiguous blocks) and gather the stitched motions on every rank.
 
-    Returns (list of S stitched de-normalised motions [frames_s, input_dim] float32 numpy, dict (sequence, window) -> window output)."""
+    Returns (list of S stitched de-normalised motions [frames_s, input_dim] float32 numpy -- ALL S sequences on every rank, gathered
+    by one padded all-gather --, dict (sequence, window) -> window output of THIS RANK's sequences only: the raw windows are not
+    gathered)."""
     dev = device or torch.device('cuda', torch.cuda.current_device())
     S = len(total_frames) if not isinstance(total_frames, int) else (len(c) if c is not None else (len(text) if isinstance(text, (list, tuple)) else 1))
     totals = [int(total_frames)] * S if isinstance(total_frames, int) else [int(t) for t in total_frames]
@@ -220,6 +222,7 @@ def sample_long_batched(model, total_frames, motion_length, pre_frames=30, c=Non
         for k in range(0, len(todo), max_batch):
             run(todo[k:k + max_batch])
     local = {s: stitch_windows([windows[(s, w)] for w in range(n_wins[s])], pre_frames, repaint, mean, std) for s in mine}
-    full = _gather_ragged(local, S, owners, input_dim, dev) if (shard and ws > 1) else local
+    lengths = [(n_wins[s] - 1) * stride + motion_length for s in range(S)]
+    full = _gather_ragged(local, lengths, owners, input_dim, dev) if (shard and mcd.is_dist()) else local
     return [full[s] for s in range(S)], windows
 

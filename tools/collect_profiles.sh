@@ -29,6 +29,9 @@ db=$(MC_CHAIN=$SERIAL run ${tag}_mfma --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VA
 dbf=$(run ${tag}_fetch --kernel-trace --pmc FETCH_SIZE -d $out/prof_${tag}_fetch -o s -- $BENCH --steps 4 --warmup 1)
 dbw=$(run ${tag}_write --kernel-trace --pmc WRITE_SIZE -d $out/prof_${tag}_write -o s -- $BENCH --steps 4 --warmup 1)
 { echo "# commit $COMMIT"; echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (separate passes) over"; echo "#   python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --no-full-loop   (B=64, T=196; 5 steps + setup per pass); table by tools/hbm_traffic.py"; echo "# units: KiB per dispatch (average).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B requests of wide coalesced reads as 64 B -> fetch_x2 doubles it (calibrated on sampler_update_k in round 1); WRITE_SIZE exact."; python tools/hbm_traffic.py $dbf $dbw 5; } > $out/${tag}_pmc_hbm_traffic.txt
+# FLOP ledger of one step of the serial schedule (what the launchers book; keyed kernel@grid like the trace) -> prices the roofline table
+MC_CHAIN=$SERIAL GIT_COMMIT=$COMMIT python tools/flop_ledger.py 64 > $out/${tag}_flop_ledger_serial.txt 2> $out/${tag}_flop_ledger_serial.err
+cp $out/${tag}_flop_ledger_serial.txt $root/profiles/ 2>/dev/null
 # per-kernel roofline table from the two PMC summaries (bench.py reads its gemm_wp_k row as `roofline.dominant_kernel`)
 cp $out/${tag}_pmc_mfma_busy.txt $out/${tag}_pmc_hbm_traffic.txt $root/profiles/ 2>/dev/null
 python tools/kernel_roofline.py $tag > $out/${tag}_kernel_roofline.txt

@@ -64,22 +64,79 @@ def parse_hbm(path):
     return out
 
 
+def parse_ledger(path):
+    """profiles/<tag>_flop_ledger_serial.txt (tools/flop_ledger.py under the serial chain mask): (kernel, grid) -> (launches, GFLOP) per step"""
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        if line.startswith('#') or not line.strip():
+            continue
+        key, calls, gf = line.rstrip('\n').split('\t')
+        name, grid = key.rsplit('@', 1)
+        out[(name, int(grid))] = (int(calls), float(gf))
+    return out
+
+
+def csrc_digest():
+    """sha256 over the kernel sources the profiled library was built from (bench.py recomputes it: a table from other sources is `stale`)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'motioncraft_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+STEPS = 4                            # steps of the PMC pass (bench.py --steps 3 --warmup 1)
 for line in open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma_busy.txt')):
     if line.startswith('# commit'):
         print(line.rstrip())
         break
+print(f'# csrc sha256 {csrc_digest()}')
 pmc = parse_pmc(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma_busy.txt'))
 hbm = parse_hbm(os.path.join(ROOT, 'profiles', f'{tag}_pmc_hbm_traffic.txt'))
+ledger = parse_ledger(os.path.join(ROOT, 'profiles', f'{tag}_flop_ledger_serial.txt'))
 print(f'# tools/kernel_roofline.py {tag}: B=64 step, serial single-stream schedule (single-stream chain mask, PMC pass: profiles/{tag}_pmc_mfma_busy.txt), HBM bytes per launch of the')
-print(f'# default two-stream schedule (half-batch launches: profiles/{tag}_pmc_hbm_traffic.txt).  GFLOP = algorithmic work of the AVERAGE launch of a step as the reference')
-print('# performs it (layer-0 launches of the expert / proj kernels do half: twin dedupe; gemm_wp_k: 7 FiLM GEMMs + the encoder); peak 157.3 TFLOP/s fp32 MFMA at 2.4 GHz, HBM 8 TB/s.')
+print(f'# default two-stream schedule (half-batch launches: profiles/{tag}_pmc_hbm_traffic.txt).  GFLOP = useful multiply-add work (x 2) of the AVERAGE launch of a step as the')
+if ledger:
+    print(f'# launchers booked it (profiles/{tag}_flop_ledger_serial.txt: mc_debug_flop_ledger over one step of the same schedule, keyed kernel@grid; expert MLPs at the slot count')
+    print('# of their routing, i.e. before capacity drops); peak 157.3 TFLOP/s fp32 MFMA at 2.4 GHz, HBM 8 TB/s.  `-` = not an MFMA kernel (row / routing / sampler passes).')
+else:
+    print('# reference performs it (layer-0 launches of the expert / proj kernels do half: twin dedupe; gemm_wp_k: 7 FiLM GEMMs + the encoder); peak 157.3 TFLOP/s fp32 MFMA at 2.4 GHz, HBM 8 TB/s.')
 print(f'{"kernel":28s} {"grid":>9s} {"calls":>5s} {"us":>8s} {"GFLOP":>8s} {"TFLOP/s":>8s} {"%peak":>6s} {"MfmaUtil":>8s} {"GHz":>6s} {"MB/launch (2-stream)":>22s}')
+sum_us = sum_gf = 0.0
+used = set()
 for r in pmc:
     if r['us'] < 10 or 'rocclr' in r['name'] or r['name'].startswith('at::'):
         continue
-    fl = FLOPS.get((r['name'], r['grid']), FLOPS.get((r['name'], None)))
+    fl = None
+    per_step = r['n'] / STEPS
+    if ledger:
+        hit = [(k, v) for k, v in ledger.items() if r['name'].startswith(k[0]) and k[1] == r['grid'] * max(r['gy'], 1)]
+        if not hit:
+            hit = [(k, v) for k, v in ledger.items() if r['name'].startswith(k[0]) and k[1] == r['grid']]
+        if hit:
+            used.update(k for k, _ in hit)
+            calls = sum(v[0] for _, v in hit)
+            fl = sum(v[1] for _, v in hit) * 1e9 / calls
+            if per_step >= 1:
+                sum_gf += fl / 1e9 * per_step
+    else:
+        fl = FLOPS.get((r['name'], r['grid']), FLOPS.get((r['name'], None)))
+    if per_step >= 1:
+        sum_us += r['us'] * per_step
     tf = fl / r['us'] / 1e6 if fl else None
     hb = next((v for k, v in hbm.items() if r['name'].startswith(k[:20]) or k.startswith(r['name'][:20])), None)
-    print(f'{r["name"][:28]:28s} {r["grid"]:9d} {r["n"]:5d} {r["us"]:8.1f} {(fl / 1e9 if fl else 0):8.1f} '
+    print(f'{r["name"][:28]:28s} {r["grid"]:9d} {r["n"]:5d} {r["us"]:8.1f} {(f"{fl / 1e9:8.1f}" if fl else "       -")} '
           f'{(f"{tf:8.1f}" if tf else "       -")} {(f"{tf / 1.573:6.1f}" if tf else "     -")} {r.get("util", 0):8.1f} {r.get("clk", 0):6.2f} '
           f'{(f"{hb[0] + hb[1]:10.0f} ({hb[0]:.0f} rd + {hb[1]:.0f} wr)" if hb else ""):>22s}')
+if ledger:
+    missed = {k: v for k, v in ledger.items() if k not in used}
+    total_gf = sum(v[1] for v in ledger.values())
+    print(f'# closing: sum(calls x us) of the listed kernels = {sum_us / 1e3:.3f} ms per step of the serial schedule (kernels under 10 us not listed); sum of their GFLOP = '
+          f'{sum_gf:.1f} of the {total_gf:.1f} GFLOP the ledger books per step = {total_gf / B:.3f} GFLOP per sample and step')
+    print('#   (bench.py `executed_gflop_per_sample_step` counts the expert MLPs at tokens x top-2 as well; the reference-counted figure is `algorithmic_gflop_per_sample_step`)')
+    if missed:
+        print('# ledger rows without a listed kernel (launches under 10 us, or setup-only): ' + ', '.join(f'{k[0]}@{k[1]} {v[1]:.2f} GFLOP' for k, v in sorted(missed.items())))
