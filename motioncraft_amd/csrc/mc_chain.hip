@@ -1050,7 +1050,7 @@ int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s) {
     if (mc_ledger_on) {       // proj + q/k/v per token; per frame the static topology (H x H mix of L-vectors) and the dynamic one (8 heads of linear attention over the H parts: k^T v and q (k^T v), [hd x hd] each)
         char name[32];
         snprintf(name, sizeof(name), "pqbody_k<%d", g.L);
-        const double toks = (double)(g.N - g.tok0) + (g.nblk1 != 0 ? (double)(g.N2 - g.tok2) : 0.0), hd = g.L / 8.0;
+        const double toks = (double)(g.N - g.tok0), hd = g.L / 8.0;      // (the optional second token range = aliased twins: its workgroups exit at once in the usual case)
         MC_LEDGER(name, grid, 2.0 * toks * 7.0 * g.L * g.L + (toks / H) * (2.0 * H * H * g.L + 8 * 2.0 * (2.0 * H * hd * hd)));
     }
     if (g.L == 128) hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, gg);

@@ -1329,7 +1329,7 @@ int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const m
     if (mc_ledger_on) {
         char name[40];
         snprintf(name, sizeof(name), "pqbody_h_k<%d, 12, %s>", g.L, split ? "true" : "false");
-        const double toks = (double)(g.N - g.tok0) + (g.nblk1 != 0 ? (double)(g.N2 - g.tok2) : 0.0), hd = g.L / 8.0;
+        const double toks = (double)(g.N - g.tok0), hd = g.L / 8.0;      // (the optional second token range = aliased twins: its workgroups exit at once in the usual case)
         MC_LEDGER(name, grid, 2.0 * toks * 7.0 * g.L * g.L + (toks / H) * (2.0 * H * H * g.L + 8 * 2.0 * (2.0 * H * hd * hd)));
     }
     if (g.L == 128) {

@@ -139,6 +139,7 @@ struct mc_ctx {
     size_t hbuf_cap = 0;        // floats allocated behind hbuf
     size_t hbuf_floats = 0;     // > 0: hbuf is free scratch (fused expert path), used for split-K partial sums
     bool cnt_clean = false;     // the routing state's (choice, expert) counts are known to be zero on the stream (route_small_k cleans up after itself)
+    long led_nsrc = 0, led_gsplit = 0;      // FLOP ledger only: routed source tokens of the last routing and its slot-group boundary
     float *xfn, *tf;          // tf: [NL][B2*Nt][2L]
     const float* mask = nullptr;   // = mask_own after mc_ctx_set_condition (a private copy: the pointer is baked into captured graphs)
     float* mask_own = nullptr;
@@ -440,7 +441,10 @@ int moe_experts(mc_ctx* c, const MoeW& w, const float* z, long Ntok, int group, 
         // fused expert FFN: hidden activations stay on chip (mc_chain.hip)
         MlpArgs m;
         m.dma = chain_on(c, 18) ? 1 : 0;
-        m.ledger_rows = 2 * Ntok;
+        {   // top-2 slots of this slot group's source tokens (twins of base layer 0 have no slots of their own)
+            const long nsrc = c->led_nsrc > 0 ? c->led_nsrc : Ntok, gs = c->led_gsplit;
+            m.ledger_rows = 2 * ((gs <= 0 || gs >= nsrc) ? nsrc : (group == 0 ? gs : nsrc - gs));
+        }
         m.X = z; m.ldx = din; m.W1 = w.fc1_w; m.b1 = w.fc1_b; m.W2t = w.fc2_wt; m.b2 = w.fc2_b;
         m.Y = c->y2; m.ldy = din; m.L = din; m.hidden = hid;
         m.tile_group = c->rb.tile_group + to; m.tile_row0 = c->rb.tile_row0 + to; m.tile_nrows = c->rb.tile_nrows + to;
@@ -509,6 +513,8 @@ int run_moe(mc_ctx* c, const MoeW& w, const float* z, long Ntok, float* out, lon
     }
     const int capacity = g.topk * (int)((double)g.capacity_factor * (double)((Ntok + E - 1) / E));  // tutel extract_critical
     c->cnt_clean = false;
+    c->led_nsrc = twin ? Ntok / 2 : Ntok;
+    c->led_gsplit = gsplit;
     if ((r = mc_launch_route(Ntok, twin ? Ntok / 2 : Ntok, gsplit, E, capacity, c->rb, s))) return r;
     c->cnt_clean = mc_route_cleans_counts(c->rb, Ntok);
     if (gsplit < Ntok) return MC_OK;

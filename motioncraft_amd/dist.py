@@ -35,9 +35,20 @@ def _device_collectives():
     return dist.get_backend() == 'nccl'
 
 
+def _staging_device(t):
+    """Where tensor `t` has to live for a collective of the active backend, or None if it is already there: RCCL only takes HBM
+    tensors (a host tensor -- e.g. the `motion` placeholder a caller built on the CPU -- goes to this rank's GPU and the result comes
+    back to the host: found by the world-size-1 RCCL run of round 6, "No backend type associated with device type cpu"); gloo only
+    takes host tensors."""
+    if _device_collectives():
+        return None if t.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu') if t.is_cuda else None
+
+
 def _bcast(t, src):
-    if t.is_cuda and not _device_collectives():
-        h = t.cpu()
+    dev = _staging_device(t)
+    if dev is not None:
+        h = t.to(dev)
         dist.broadcast(h, src=src)
         t.copy_(h)
     else:
@@ -49,14 +60,14 @@ def _scatter_rows(t, src):
     link instead of the whole tensor to everyone (RCCL scatter = grouped send/recv over xGMI)."""
     rank, ws = world()
     lo, hi = shard_range(t.shape[0])
-    staged = t.is_cuda and not _device_collectives()
-    out = torch.empty((hi - lo,) + tuple(t.shape[1:]), dtype=t.dtype, device='cpu' if staged else t.device)
+    dev = _staging_device(t)
+    out = torch.empty((hi - lo,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev if dev is not None else t.device)
     parts = None
     if rank == src:
-        g = t.cpu() if staged else t
+        g = t.to(dev) if dev is not None else t
         parts = [g[r * (hi - lo):(r + 1) * (hi - lo)].contiguous() for r in range(ws)]
     dist.scatter(out, parts, src=src)
-    return out.to(t.device) if staged else out
+    return out.to(t.device) if dev is not None else out
 
 
 def broadcast_condition(xf_out, motion_mask, src=0, c=None):
@@ -77,18 +88,18 @@ def broadcast_condition(xf_out, motion_mask, src=0, c=None):
 
 
 def gather_results(local):
-    """all-gather of the finished sequences: [B/W, T, C] on every rank -> [B, T, C] on every rank."""
+    """all-gather of the finished sequences: [B/W, T, C] on every rank -> [B, T, C] on every rank (on the device `local` lives on)."""
     if not is_dist():
         return local
     rank, ws = world()
-    if local.is_cuda and _device_collectives():
-        out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous())
-        return out
-    h = local.detach().cpu().contiguous()
-    out = torch.empty((ws * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
-    dist.all_gather(list(out.chunk(ws, dim=0)), h)
-    return out.to(local.device)
+    dev = _staging_device(local)
+    h = (local.detach().to(dev) if dev is not None else local.detach()).contiguous()
+    out = torch.empty((ws * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype, device=h.device)
+    if _device_collectives():
+        dist.all_gather_into_tensor(out, h)              # one RCCL all-gather into the contiguous result
+    else:
+        dist.all_gather(list(out.chunk(ws, dim=0)), h)
+    return out.to(local.device) if dev is not None else out
 
 
 def sample_sharded(arch, motion, motion_mask, xf_out, noise=None, step_noise=None, c=None, c_local=None, **kwargs):

@@ -132,12 +132,15 @@ def _rccl_world1_worker(port, q):
     c = torch.randn(B, Tc, CTRL_FEATS, generator=g)
     S = 50
 
-    def sharded():
+    def sharded(on_device):
         xs, ms, cs = mcd.broadcast_condition(xf.to(dev), mask.to(dev), src=0, c=c.to(dev))
         assert xs.is_cuda and torch.equal(xs.cpu(), xf) and torch.equal(ms.cpu(), mask) and torch.equal(cs.cpu(), c)
-        return mcd.sample_sharded(arch, torch.zeros(B, T, dims['input_feats']), ms.cpu(), xs.cpu(), noise=x_T,
-                                  step_noise=lambda i: steps[S - 1 - i], c_local=cs.cpu(), motion_metas=[{'text': ''}] * B,
-                                  inference_kwargs=dict(num_steps=NSTEPS))
+        if not on_device:           # host tensors through the same entry points (RCCL only moves HBM tensors: dist.py stages them on the rank's GPU)
+            xh, mh, ch = mcd.broadcast_condition(xf.clone(), mask.clone(), src=0, c=c.clone())
+            assert not xh.is_cuda and torch.equal(xh, xf) and torch.equal(mh, mask) and torch.equal(ch, c)
+        motion = torch.zeros(B, T, dims['input_feats'], device=dev if on_device else 'cpu')
+        return mcd.sample_sharded(arch, motion, ms.cpu(), xs.cpu(), noise=x_T, step_noise=lambda i: steps[S - 1 - i], c_local=cs.cpu(),
+                                  motion_metas=[{'text': ''}] * B, inference_kwargs=dict(num_steps=NSTEPS))
 
     # batched window driver on the same architecture: 3 sequences of different lengths, 2-3 windows each, one model call
     totals, L, pre = [42, 60, 42], 24, 6
@@ -153,19 +156,19 @@ def _rccl_world1_worker(port, q):
                                             max_batch=160, shard=True)[0]
 
     assert not mcd.is_dist()
-    ref, ref_w = sharded(), windows()
+    ref, ref_w = sharded(False), windows()
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
         assert mcd.is_dist() and mcd._device_collectives() and mcd.world() == (0, 1)
         dist.barrier(device_ids=[0])
-        out, out_w = sharded(), windows()
+        out, out_h, out_w = sharded(True), sharded(False), windows()
         # the collectives themselves on HBM tensors, incl. the fp64 tensor bench.py's max-over-ranks reduce uses
         t = torch.arange(12, dtype=torch.float32, device=dev).view(3, 4)
         assert torch.equal(mcd.gather_results(t), t)
         t64 = torch.tensor([1.25, 2.5], dtype=torch.float64, device=dev)
         dist.all_reduce(t64, op=dist.ReduceOp.MAX)
         torch.cuda.synchronize()
-        ok = (out.is_cuda and torch.equal(out, ref) and all(a.shape == b.shape and bool((a == b).all()) for a, b in zip(out_w, ref_w))
+        ok = (out.is_cuda and torch.equal(out.cpu(), ref) and not out_h.is_cuda and torch.equal(out_h, ref) and all(a.shape == b.shape and bool((a == b).all()) for a, b in zip(out_w, ref_w))
               and t64.tolist() == [1.25, 2.5] and bool(torch.isfinite(out).all()))
         arch.model.release()
         q.put((ok, tuple(out.shape), [tuple(w.shape) for w in out_w], dist.get_backend()))
