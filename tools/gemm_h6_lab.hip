@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256, 2) void hd_k(HArgs g) {
 // hr_k: generic staged ring.  LDS slot = [TM rows of A | TN rows of W][BK halves], 16-byte chunk c of row r at position c ^ swz(r)
 // (BK = 64: (r >> 1) & 7, BK = 32: (r >> 2) & 3 -- conflict-free for the ds_read_b128 lane groups of the guide's LDS table).
 // FLAGS: 1 no residual read / (almost) no store, 2 no DMA inside the loop (stale operands), 4 no barrier in the loop (invalid, with 2),
-//        8 odd workgroups start half a tile late (s_sleep) to put the two workgroups of a CU out of phase, 16 s_setprio(1) around the MFMAs
+//        8 odd workgroups start half a tile late (s_sleep) to put the two workgroups of a CU out of phase, 16 s_setprio(1) around the MFMAs,
+//        32 the slab's DMA pieces are issued one at a time BETWEEN the MFMAs (pinned by sched_barrier) instead of as a burst behind the barrier,
+//        64 the accumulators start as R + bias (loads issued at the top of the tile, in flight during the DMA prologue): the epilogue is stores only
+//           (another fp32 summation order: not bit-equal to the library kernel), 128 both workgroups of a CU out of phase by a longer sleep
 // ---------------------------------------------------------------------------------------------------------------------
 template <int N_>
 __device__ __forceinline__ void wait_vm() {
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void hr_k(HA
     auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     if (FLAGS & 8) {
         if (blockIdx.x >= 256 && blockIdx.x < 512)              // (the second workgroup slot of each CU, if the dispatcher fills one slot per CU first)
-            for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+            for (int i = 0; i < ((FLAGS & 128) ? 12 : 4); ++i) __builtin_amdgcn_s_sleep(127);
     }
     // DMA pieces of this wave: piece p covers slab rows [(wave P + p) RPI, + RPI); lane -> row lane / CH, LDS position lane % CH
     const int dr = lane / CH, dpos = lane % CH;
@@ -188,12 +191,28 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void hr_k(HA
         }
     };
     f32x16 acc[MI][NI];
+    if (FLAGS & 64) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            const int m = min(wm * (TM / WM) + i * 32 + frow, nrows - 1);
+            const float* rrow = g.R + (long)(row0 + m) * g.N;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const int n = tn * TN + wn * (TN / WN) + j * 32 + 8 * q + 4 * hf;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rrow + n) + *reinterpret_cast<const f32x4*>(g.bias + n);
+                    acc[i][j][4 * q] = v[0]; acc[i][j][4 * q + 1] = v[1]; acc[i][j][4 * q + 2] = v[2]; acc[i][j][4 * q + 3] = v[3];
+                }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
     const int ns = g.K / BK;
     // fragment byte offsets inside a slot (row-dependent swizzle term folded per k-step below)
     int arow[MI], wrow[NI];
@@ -211,20 +230,53 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void hr_k(HA
             else wait_vm<0>();                                   // (tail: fewer slabs behind this one)
         }
         if (!(FLAGS & 4)) __builtin_amdgcn_s_barrier();
-        if (!(FLAGS & 2) && s + D < ns) issue(s + D);            // into the slot of slab s - 1: every wave has passed the barrier, so has read it
+        const bool dma_now = !(FLAGS & 2) && s + D < ns;
+        if (!(FLAGS & 32) && dma_now) issue(s + D);            // into the slot of slab s - 1: every wave has passed the barrier, so has read it
         const unsigned char* sl = smem + (s % ST) * SLOT;
         if (FLAGS & 16) __builtin_amdgcn_s_setprio(1);
+        if (FLAGS & 32) {
+            // all fragments of the slab first (KS (MI + NI) ds_read_b128), then the MFMAs with one DMA piece behind every STRIDE-th of them
+            f16x8 fa[KS][MI], fw[KS][NI];
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            f16x8 fa[MI], fw[NI];
+            for (int k = 0; k < KS; ++k) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f16x8*>(sl + arow[i] * RB + (((2 * k + hf) ^ swz(arow[i])) * 16));
+                for (int i = 0; i < MI; ++i) fa[k][i] = *reinterpret_cast<const f16x8*>(sl + arow[i] * RB + (((2 * k + hf) ^ swz(arow[i])) * 16));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) fw[j] = *reinterpret_cast<const f16x8*>(sl + wrow[j] * RB + (((2 * k + hf) ^ swz(wrow[j])) * 16));
+                for (int j = 0; j < NI; ++j) fw[k][j] = *reinterpret_cast<const f16x8*>(sl + wrow[j] * RB + (((2 * k + hf) ^ swz(wrow[j])) * 16));
+            }
+            constexpr int NMF = KS * MI * NI, STRIDE = NMF / P > 0 ? NMF / P : 1;
+            const unsigned slot = lds0 + (unsigned)(((s + D) % ST) * SLOT);
+            int n = 0;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int k = 0; k < KS; ++k)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[k][j], fa[k][i], acc[i][j], 0, 0, 0);
+                        if (n % STRIDE == 0 && n / STRIDE < P) {
+                            const int p = n / STRIDE;
+                            if (dma_now) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                dma16h(goff[p], (isA[p] ? g.A : g.W) + (s + D) * BK, slot + (unsigned)((wave_u * P + p) * RPI * RB));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        ++n;
+                    }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                f16x8 fa[MI], fw[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f16x8*>(sl + arow[i] * RB + (((2 * k + hf) ^ swz(arow[i])) * 16));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fw[j] = *reinterpret_cast<const f16x8*>(sl + wrow[j] * RB + (((2 * k + hf) ^ swz(wrow[j])) * 16));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            }
         }
         if (FLAGS & 16) __builtin_amdgcn_s_setprio(0);
     }
@@ -240,6 +292,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void hr_k(HA
             for (int q = 0; q < 4; ++q) {
                 const int n = tn * TN + wn * (TN / WN) + j * 32 + 8 * q + 4 * hf;
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (FLAGS & 64) {
+                    *reinterpret_cast<f32x4*>(crow + n) = v;
+                    continue;
+                }
                 v += *reinterpret_cast<const f32x4*>(g.bias + n);
                 if (FLAGS & 1) {
                     if (v[0] == 1234.56789f) *reinterpret_cast<f32x4*>(crow + n) = v;
@@ -335,6 +391,9 @@ static void run_hr(const char* name, int M, bool check) {
     if (check) compare(M, "vs the library kernel");
 }
 
+// run one kernel back to back for ~8 s so that rocm-smi can sample clock and power under it: 0 bare MFMA stream, 1 library kernel, 2 hr_k 256x128 without
+// epilogue traffic, 3 hr_k 256x128 MFMAs + fragment reads only
+static int power_loop(int which);
 int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -366,6 +425,8 @@ int main(int argc, char** argv) {
                fl / us * 1e-6 / 2500.0);
     }
     const int only = argc > 1 ? atoi(argv[1]) : 0;
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;
+    if (argc > 3) return power_loop(atoi(argv[3]));
     for (int pass = 0; pass < 2; ++pass) {
         printf("---- pass %d\n", pass);
         for (int M : {25088, 12544, 6272}) {
@@ -377,6 +438,7 @@ int main(int argc, char** argv) {
                 report("gemm_hd_k<false> as in the library (128 x 128 x 64, 2 stages, drain + barrier per k-tile)", M,
                        time_us([&] { hipLaunchKernelGGL(hd_k, dim3(grid), dim3(256), 0, 0, g); }));
             }
+            if (mode == 0) {
             // ---- the same tile, deeper ring, counted vmcnt, more workgroups per CU
             run_hr<128, 128, 64, 2, 2, 2, 2, 0>("", M, chk);
             run_hr<128, 128, 32, 3, 2, 2, 3, 0>("", M, chk);
@@ -405,6 +467,52 @@ int main(int argc, char** argv) {
                 run_hr<256, 256, 32, 4, 2, 4, 1, 3>("  (no DMA in the loop, no epilogue traffic)", M, false);
                 run_hr<256, 256, 32, 4, 2, 4, 1, 7>("  (MFMAs + fragment reads only)", M, false);
             }
+            } else {
+            // ---- second experiment set: DMA pieces between the MFMAs; R + bias as the accumulators' start value
+            run_hr<256, 128, 32, 3, 2, 2, 2, 0>("", M, false);
+            run_hr<256, 128, 32, 3, 2, 2, 2, 32>(" + DMA between MFMAs", M, chk);
+            run_hr<256, 128, 32, 3, 2, 2, 2, 33>(" + DMA between MFMAs (no epilogue traffic)", M, false);
+            run_hr<256, 128, 32, 3, 2, 2, 2, 64>(" + acc starts as R + b", M, chk);
+            run_hr<256, 128, 32, 3, 2, 2, 2, 96>(" + both", M, chk);
+            run_hr<256, 128, 32, 3, 2, 2, 2, 96 + 8 + 128>(" + both + slot-B workgroups 45 us late", M, false);
+            run_hr<256, 128, 32, 3, 4, 2, 2, 32>(" + DMA between MFMAs", M, chk);
+            run_hr<256, 128, 32, 3, 4, 2, 2, 96>(" + both", M, chk);
+            run_hr<128, 128, 32, 3, 2, 2, 3, 32>(" + DMA between MFMAs", M, chk);
+            run_hr<128, 128, 32, 3, 2, 2, 3, 96>(" + both", M, chk);
+            run_hr<128, 128, 64, 2, 2, 2, 2, 64>(" + acc starts as R + b", M, chk);
+            run_hr<128, 128, 64, 2, 2, 2, 2, 96>(" + both", M, chk);
+            run_hr<256, 256, 32, 4, 2, 4, 1, 32>(" + DMA between MFMAs", M, chk);
+            run_hr<256, 256, 32, 4, 2, 4, 1, 33>(" + DMA between MFMAs (no epilogue traffic)", M, false);
+            run_hr<256, 256, 32, 4, 2, 4, 1, 96>(" + both", M, chk);
+            run_hr<128, 256, 32, 3, 2, 2, 2, 96>(" + both", M, chk);
+            }
+        }
+    }
+    return 0;
+}
+
+static int power_loop(int which) {
+    const int M = 25088;
+    HArgs g{dA, dW, dB, dR, dC2, M, 1536, 1536};
+    auto k2 = hr_k<256, 128, 32, 3, 2, 2, 2, 1>;
+    auto k3 = hr_k<256, 128, 32, 3, 2, 2, 2, 7>;
+    hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    int n = 0;
+    for (;; ++n) {
+        if (which == 0) hipLaunchKernelGGL(bare_k, dim3(2 * NCU), dim3(256), 0, 0, dC2, 2000, dA);
+        else if (which == 1) hipLaunchKernelGGL(hd_k, dim3(196 * 12), dim3(256), 0, 0, g);
+        else if (which == 2) hipLaunchKernelGGL(k2, dim3(98 * 12), dim3(256), 72 * 1024, 0, g);
+        else hipLaunchKernelGGL(k3, dim3(98 * 12), dim3(256), 72 * 1024, 0, g);
+        if (n % 64 == 63) {
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms > 8000.f) { printf("power loop %d: %d launches in %.0f ms = %.1f us each\n", which, n + 1, ms, ms * 1000.f / (n + 1)); break; }
         }
     }
     return 0;
