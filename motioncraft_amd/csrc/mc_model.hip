@@ -161,6 +161,15 @@ struct mc_ctx {
     bool no_alias = false;          // introspection runs (stop_after_layers < num_layers): every intermediate row is materialised
     bool defer_last_gemm = false;   // sampler entry points: the last FiLM GEMM runs on the CFG-combined rows (see denoise_combined)
     hipStream_t parts[3] = {nullptr, nullptr, nullptr};
+    // Two HIP streams only overlap when the runtime maps them to different HARDWARE queues (GPU_MAX_HW_QUEUES, default 4, handed out round-robin as streams
+    // are created): with an RCCL process group initialised in the host process the caller's stream and the one side stream of round 5 landed on the SAME
+    // queue and the two-stream schedule ran serially (+7 % step time at B=64: 19.05 -> 20.47 ms, profiles/r06_hw_queue_collision.txt).  The context creates
+    // SIDE_CAND candidates back to back (they cover consecutive queues) and times, once per caller stream, which of them really runs beside it.
+    static constexpr int SIDE_CAND = 4;
+    hipStream_t side_cand[SIDE_CAND] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side_for = nullptr;         // the caller stream the current `side` was picked for
+    bool side_picked = false;
+    float side_probe_ms[SIDE_CAND] = {0.f, 0.f, 0.f, 0.f};
     hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
     int nparts = 2;
     // hipGraph replay of the sampler step (mc_ctx_graph_capture / _step): ONE graph for all steps of the schedule; the step
@@ -778,6 +787,48 @@ int layer_rows_tail(mc_ctx* c, int i, float* hs, int step, bool twin, long row0,
 
 // groups of whole samples for the multi-stream schedule: group k = rows [part_row0(k), part_row0(k + 1))
 long part_row0(const mc_ctx* c, int k) { return ((long)2 * c->B * k / c->nparts) * c->T; }
+// Pick the side stream that runs BESIDE the caller's stream `s` (see mc_ctx::side_cand): a 60 us spin kernel on `s` and one on the candidate, started
+// together -- ~65 us when the two streams sit on different hardware queues, ~125 us when they share one.  Once per (context, caller stream); host-synchronous
+// (~0.5 ms), so never inside a stream capture (a captured step keeps the stream picked by the eager calls before it).  MC_SIDE_PROBE=0 switches it off.
+int pick_side_stream(mc_ctx* c, hipStream_t s) {
+    if (c->side_picked && c->side_for == s) return MC_OK;
+    static const bool enabled = [] { const char* e = getenv("MC_SIDE_PROBE"); return !e || atoi(e) != 0; }();
+    if (!enabled || c->graph_mode || c->graph_exec) return MC_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return MC_OK; }
+    hipEvent_t e0 = nullptr, e1 = nullptr, eq = nullptr;
+    MC_HIP(hipEventCreate(&e0));
+    MC_HIP(hipEventCreate(&e1));
+    MC_HIP(hipEventCreateWithFlags(&eq, hipEventDisableTiming));
+    int best = 0, r = MC_OK;
+    float best_ms = 1e30f;
+    for (int rep = 0; rep < 2 && r == MC_OK; ++rep)           // (the first round also pays the candidates' first-use cost: the second one decides)
+        for (int k = 0; k < mc_ctx::SIDE_CAND && r == MC_OK; ++k) {
+            hipStream_t q = c->side_cand[k];
+            bool ok = hipEventRecord(e0, s) == hipSuccess && hipStreamWaitEvent(q, e0, 0) == hipSuccess;
+            ok = ok && mc_launch_spin(6000, s) == MC_OK && mc_launch_spin(6000, q) == MC_OK;
+            ok = ok && hipEventRecord(eq, q) == hipSuccess && hipStreamWaitEvent(s, eq, 0) == hipSuccess && hipEventRecord(e1, s) == hipSuccess &&
+                 hipEventSynchronize(e1) == hipSuccess;
+            float ms = 0.f;
+            ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (!ok) { mc_set_error("side-stream probe failed: %s", hipGetErrorString(hipGetLastError())); r = MC_ERR_HIP; break; }
+            if (rep == 1) {
+                c->side_probe_ms[k] = ms;
+                if (ms < best_ms - 0.02f) { best_ms = ms; best = k; }      // (20 us margin: near ties keep the earlier candidate)
+            }
+        }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eq);
+    if (r != MC_OK) return r;
+    c->side = c->side_cand[best];
+    c->parts[0] = c->side;
+    c->side_for = s;
+    c->side_picked = true;
+    if (getenv("MC_SIDE_PROBE_VERBOSE"))
+        fprintf(stderr, "[motioncraft_amd] side stream for caller stream %p: candidate %d (spin pair %.0f %.0f %.0f %.0f us)\n", (void*)s, best,
+                c->side_probe_ms[0] * 1e3f, c->side_probe_ms[1] * 1e3f, c->side_probe_ms[2] * 1e3f, c->side_probe_ms[3] * 1e3f);
+    return MC_OK;
+}
+
 hipStream_t part_stream(const mc_ctx* c, int k, hipStream_t s) { return k == 0 ? s : c->parts[k - 1]; }
 int parts_fork(mc_ctx* c, hipStream_t s) {
     MC_HIP(hipEventRecord(c->ev_fork, s));
@@ -1061,7 +1112,10 @@ int mc_ctx_create(mc_model* m, int32_t batch, int32_t frames, int32_t max_steps,
     int r = bind_weights(c);
     if (r == MC_OK) r = build_ctx_weights(c);
     if (r != MC_OK) { mc_ctx_destroy(c); return r; }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    bool cand_ok = true;
+    for (int k = 0; k < mc_ctx::SIDE_CAND; ++k) cand_ok = cand_ok && hipStreamCreateWithFlags(&c->side_cand[k], hipStreamNonBlocking) == hipSuccess;
+    c->side = c->side_cand[0];
+    if (!cand_ok ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) != hipSuccess) {
@@ -1155,7 +1209,8 @@ void mc_ctx_destroy(mc_ctx* c) {
     graph_release(c);
     if (c->coop_reserved) { mc_route_coop_release(c->device, c->coop_reserved); c->coop_reserved = 0; }
     prof_clear(c);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    for (int k = 0; k < mc_ctx::SIDE_CAND; ++k)
+        if (c->side_cand[k]) { (void)hipStreamSynchronize(c->side_cand[k]); (void)hipStreamDestroy(c->side_cand[k]); }
     for (int k = 1; k < 3; ++k)
         if (c->parts[k]) { (void)hipStreamSynchronize(c->parts[k]); (void)hipStreamDestroy(c->parts[k]); }
     for (int k = 0; k < 3; ++k)
@@ -1404,6 +1459,7 @@ static int denoise_impl(mc_ctx* c, const float* x_t, int32_t step, float* out2_d
     const int L = g.latent_dim, H = g.num_parts, D = L * H, C = g.input_feats;
     const long BT = (long)c->B * c->T;
     int r;
+    if ((r = pick_side_stream(c, s))) return r;        // once per caller stream: the side stream that really runs beside it (hardware queues)
     // PoseEncoder as one dense [C -> D] GEMM with the scattered weight, + sequence_embedding[:T],
     // written to both CFG halves (stmogen.py:336-353; diffusion_transformer.py:215-218; stmogen.py:740)
     {
