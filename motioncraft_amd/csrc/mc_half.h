@@ -35,6 +35,8 @@ struct GemmHArgs {
     long ldc = 0;
     int M = 0, N = 0, K = 0;      // N % 128 == 0, K % 32 == 0, lda/ldc/ldr % 4 == 0
     int act = 0;
+    int acc_init = 0;             // plane kernel, plain f16, R and bias set, no activation: the accumulators START as R + bias (loads in flight during the
+                                  // DMA prologue; the epilogue is stores only) -- another fp32 summation order than (sum + bias) + R: not for the split mode
 };
 // C = act(A W^T + bias) + R with fp16 MFMA; split = three-product hi/lo form
 int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s);

@@ -196,7 +196,7 @@ __device__ __forceinline__ void dma16h(unsigned voff, const mc_half* sbase, unsi
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool INIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
     constexpr int P = SPLIT ? 2 : 1;
     constexpr int BKH = SPLIT ? 32 : 64;            // halves per k-tile
@@ -241,12 +241,30 @@ __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
         }
     };
     f32x16 acc[2][2];
+    if constexpr (INIT) {
+        // (round 6, tools/gemm_h6_lab.hip) the kernel runs at the package power cap, where the cost of its parts adds up; what the lab found movable is
+        // the load -> add -> store chain at the end of every tile: with R + bias as the accumulators' start value the loads fly during the DMA prologue
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = min(wm * 64 + mi * 32 + frow, nrows - 1);
+            const float* rrow = g.R + (long)(row0 + m) * g.ldr;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const int n = tn * 128 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rrow + n) + *reinterpret_cast<const f32x4*>(g.bias + n);
+                    acc[mi][ni][4 * q] = v[0]; acc[mi][ni][4 * q + 1] = v[1]; acc[mi][ni][4 * q + 2] = v[2]; acc[mi][ni][4 * q + 3] = v[3];
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
     const int nk = g.K / BKH;
     const int sw = swz(frow);                        // rows frow, frow + 32, + 64, + 96 share the swizzle term
     issue(0, 0);
@@ -288,6 +306,10 @@ __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
             for (int q = 0; q < 4; ++q) {
                 const int n = tn * 128 + wn * 64 + ni * 32 + 8 * q + 4 * hf;
                 f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                if constexpr (INIT) {
+                    *reinterpret_cast<f32x4*>(crow + n) = v;
+                    continue;
+                }
                 if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
                 if (g.act != ACT_NONE) {
 #pragma unroll
@@ -1241,6 +1263,7 @@ int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
         dim3 grid(cdiv(g.M, 128) * (g.N / 128));
         MC_LEDGER(split ? "gemm_hd_k<true>" : "gemm_hd_k<false>", grid, 2.0 * g.M * g.N * g.K);      // (fp32-equivalent product: the split form runs 3 fp16 MFMAs per operand pair)
         if (split) hipLaunchKernelGGL(gemm_hd_k<true>, grid, dim3(256), 0, s, g);
+        else if (g.acc_init && g.R && g.bias && g.act == ACT_NONE) hipLaunchKernelGGL((gemm_hd_k<false, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL(gemm_hd_k<false>, grid, dim3(256), 0, s, g);
         MC_LAUNCH_CHECK();
         return MC_OK;

@@ -87,7 +87,11 @@ struct McOptions {
     //    the two HBM-bound row kernels never run against each other and the groups' GEMM / SFFN launches leave the seam half a kernel apart
     //    instead of in lockstep (B=64 19.08 -> 18.94, 19.14 -> 19.01, 19.12 -> 19.00 ms/step; a 60 us spin at the same place: the same).
     //    Only in exact-fp32 contexts at L = 128: measured slower in the fp16 modes (f16 6.86 -> 7.08) and at L = 64 (M2D 17.62 -> 18.00), neutral at batch 32
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26);     // (all but bits 3, 23 and 25)
+    // 27 (round 6) plain-f16 contexts: the FiLM plane GEMM starts its accumulators as R + bias (gemm_hd_k<false, true>: loads in flight during the DMA
+    //    prologue, stores-only epilogue; tools/gemm_h6_lab.hip) -- another fp32 summation order than (sum + bias) + R, 1e-5-level on O(1) rows: never in
+    //    the split mode, never in exact-fp32 contexts
+    //    (same-box A/B, f16: B=64 6.926 -> 6.814 ms/step, B=32 3.856 -> 3.700)
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26) | (1 << 27);     // (all but bits 3, 23 and 25)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
                                        // S2G at 32 per GPU 27.65 -> 27.14; at 4704 rows (B=24) the small kernels still do, 7.85 vs 7.91)
@@ -587,6 +591,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
         g.Ah = reinterpret_cast<mc_half*>(c->a) + o; g.Al = g.Ah + pstride;
         g.Wh = hw->hi; g.Wl = hw->lo; g.bias = out_b; g.R = hs + o; g.ldr = D; g.C = hs + o; g.ldc = D;
         g.M = (int)nrows; g.N = D; g.K = D;
+        g.acc_init = chain_on(c, 27) ? 1 : 0;          // plain f16 only (the launcher ignores it in the split mode)
         return mc_launch_gemm_h(g, c->prec == MC_PREC_F16X3, s);
     }
     if (half_gemm)
