@@ -196,7 +196,7 @@ __device__ __forceinline__ void dma16h(unsigned voff, const mc_half* sbase, unsi
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 
-template <bool SPLIT, bool INIT = false>
+template <bool SPLIT, bool INIT = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
     constexpr int P = SPLIT ? 2 : 1;
     constexpr int BKH = SPLIT ? 32 : 64;            // halves per k-tile
@@ -240,6 +240,22 @@ __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
             }
         }
     };
+    // PRE (round 6): the residual rows this lane adds in the epilogue are requested HERE, into 64 registers of their own, and fly during the DMA prologue and the
+    // first k-tile (whose vmcnt(0) covers them): the epilogue adds them in the SAME order as before -- (sum + bias) + R, the same bits -- without a
+    // load -> add -> store chain at the end of every tile.  (sched_barrier: the scheduler must not sink the loads down to their uses)
+    f32x4 rpre[PRE ? 2 : 1][2][4];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = min(wm * 64 + mi * 32 + frow, nrows - 1);
+            const float* rrow = g.R + (long)(row0 + m) * g.ldr;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rpre[mi][ni][q] = *reinterpret_cast<const f32x4*>(rrow + tn * 128 + wn * 64 + ni * 32 + 8 * q + 4 * hf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     f32x16 acc[2][2];
     if constexpr (INIT) {
         // (round 6, tools/gemm_h6_lab.hip) the kernel runs at the package power cap, where the cost of its parts adds up; what the lab found movable is
@@ -315,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], g.act);
                 }
-                if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+                if constexpr (PRE) v += rpre[mi][ni][q];
+                else if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
                 *reinterpret_cast<f32x4*>(crow + n) = v;
             }
     }
@@ -1262,8 +1279,12 @@ int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
         if (g.M <= 0) return MC_OK;
         dim3 grid(cdiv(g.M, 128) * (g.N / 128));
         MC_LEDGER(split ? "gemm_hd_k<true>" : "gemm_hd_k<false>", grid, 2.0 * g.M * g.N * g.K);      // (fp32-equivalent product: the split form runs 3 fp16 MFMAs per operand pair)
-        if (split) hipLaunchKernelGGL(gemm_hd_k<true>, grid, dim3(256), 0, s, g);
-        else if (g.acc_init && g.R && g.bias && g.act == ACT_NONE) hipLaunchKernelGGL((gemm_hd_k<false, true>), grid, dim3(256), 0, s, g);
+        const bool pre = (g.acc_init & 1) && g.R, init = (g.acc_init & 2) && g.R && g.bias && g.act == ACT_NONE;
+        if (split) {
+            if (pre) hipLaunchKernelGGL((gemm_hd_k<true, false, true>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL(gemm_hd_k<true>, grid, dim3(256), 0, s, g);
+        } else if (init) hipLaunchKernelGGL((gemm_hd_k<false, true>), grid, dim3(256), 0, s, g);
+        else if (pre) hipLaunchKernelGGL((gemm_hd_k<false, false, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL(gemm_hd_k<false>, grid, dim3(256), 0, s, g);
         MC_LAUNCH_CHECK();
         return MC_OK;

@@ -87,10 +87,12 @@ struct McOptions {
     //    the two HBM-bound row kernels never run against each other and the groups' GEMM / SFFN launches leave the seam half a kernel apart
     //    instead of in lockstep (B=64 19.08 -> 18.94, 19.14 -> 19.01, 19.12 -> 19.00 ms/step; a 60 us spin at the same place: the same).
     //    Only in exact-fp32 contexts at L = 128: measured slower in the fp16 modes (f16 6.86 -> 7.08) and at L = 64 (M2D 17.62 -> 18.00), neutral at batch 32
-    // 27 (round 6) plain-f16 contexts: the FiLM plane GEMM starts its accumulators as R + bias (gemm_hd_k<false, true>: loads in flight during the DMA
-    //    prologue, stores-only epilogue; tools/gemm_h6_lab.hip) -- another fp32 summation order than (sum + bias) + R, 1e-5-level on O(1) rows: never in
-    //    the split mode, never in exact-fp32 contexts
-    //    (same-box A/B, f16: B=64 6.926 -> 6.814 ms/step, B=32 3.856 -> 3.700)
+    // 27 (round 6) reduced-precision contexts: the FiLM plane GEMM requests the residual rows of its epilogue at the TOP of the tile, into registers of their own
+    //    (gemm_hd_k<., false, true>: in flight during the DMA prologue; no load -> add -> store chain at the end of every tile) -- the same order (sum + bias) + R,
+    //    the same bits (tools/gemm_h6_lab.hip: the kernel runs at the package power cap, this chain is the part that moves).  Same-box A/B: f16 B=64 6.87 -> 6.82,
+    //    B=32 3.98 -> 3.81 ms/step; f16x3 10.72 -> 10.62, 5.52 -> 5.45
+    // 28 (round 6, OFF) plain f16 only: the accumulators START as R + bias instead (stores-only epilogue; f16 B=32 3.75 against bit 27's 3.81) -- another fp32
+    //    summation order (2.6e-4 on h after one layer, 1.1e-3 on x0 against the exact order: inside plain f16's own error, but not free): a switch, not the default
     int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26) | (1 << 27);     // (all but bits 3, 23 and 25)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
@@ -591,7 +593,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
         g.Ah = reinterpret_cast<mc_half*>(c->a) + o; g.Al = g.Ah + pstride;
         g.Wh = hw->hi; g.Wl = hw->lo; g.bias = out_b; g.R = hs + o; g.ldr = D; g.C = hs + o; g.ldc = D;
         g.M = (int)nrows; g.N = D; g.K = D;
-        g.acc_init = chain_on(c, 27) ? 1 : 0;          // plain f16 only (the launcher ignores it in the split mode)
+        g.acc_init = (chain_on(c, 27) ? 1 : 0) | (chain_on(c, 28) ? 2 : 0);      // 1: residual rows prefetched into registers (same bits), 2: accumulators start as R + bias (plain f16 only)
         return mc_launch_gemm_h(g, c->prec == MC_PREC_F16X3, s);
     }
     if (half_gemm)
