@@ -90,6 +90,14 @@ struct RowChainArgs {
     int nblk1 = 0;
 };
 
+// FLOP ledger: tokens of [tok0, N) a row-chain launch really computes -- with twin aliasing armed (alias.split_flag set) the tokens from alias.from on
+// are skipped while no twin pair is split by a capacity cut (the usual case; the flag lives on the device)
+inline long mc_ledger_tokens(const RowChainArgs& g) {
+    long hi = g.N;
+    if (g.alias.split_flag && g.alias.from < hi) hi = g.alias.from;          // (a launch that starts at alias.from books nothing: it exits at once)
+    return hi > g.tok0 ? hi - g.tok0 : 0;
+}
+
 bool mc_mlp_supported(int L, int hidden);
 int mc_launch_mlp(int mode, const MlpArgs& g, int groups, int max_tiles, hipStream_t s);
 int mc_launch_gate(const GateArgs& g, hipStream_t s);

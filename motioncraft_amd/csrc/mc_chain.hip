@@ -885,7 +885,7 @@ int mc_launch_projqkv(const RowChainArgs& g, hipStream_t s) {
     if (mc_ledger_on) {
         char name[32];
         snprintf(name, sizeof(name), "projqkv_k<%d>", g.L);
-        MC_LEDGER(name, grid, 2.0 * (double)(g.N - g.tok0) * 7.0 * g.L * g.L);        // proj [4L, L] + q/k/v [3L, L]
+        MC_LEDGER(name, grid, 2.0 * (double)mc_ledger_tokens(g) * 7.0 * g.L * g.L);        // proj [4L, L] + q/k/v [3L, L]
     }
     switch (g.L) {
         case 128: hipLaunchKernelGGL(projqkv_k<128>, grid, dim3(256), 0, s, g); break;
@@ -1050,7 +1050,7 @@ int mc_launch_pqbody(const RowChainArgs& g, int H, hipStream_t s) {
     if (mc_ledger_on) {       // proj + q/k/v per token; per frame the static topology (H x H mix of L-vectors) and the dynamic one (8 heads of linear attention over the H parts: k^T v and q (k^T v), [hd x hd] each)
         char name[32];
         snprintf(name, sizeof(name), "pqbody_k<%d", g.L);
-        const double toks = (double)(g.N - g.tok0), hd = g.L / 8.0;      // (the optional second token range = aliased twins: its workgroups exit at once in the usual case)
+        const double toks = (double)(mc_ledger_tokens(g)), hd = g.L / 8.0;      // (aliased twins -- the tail of the range, or the optional second range -- exit at once in the usual case)
         MC_LEDGER(name, grid, 2.0 * toks * 7.0 * g.L * g.L + (toks / H) * (2.0 * H * H * g.L + 8 * 2.0 * (2.0 * H * hd * hd)));
     }
     if (g.L == 128) hipLaunchKernelGGL((pqbody_k<128, 12>), grid, dim3(256), 0, s, gg);
@@ -1066,7 +1066,7 @@ int mc_launch_rowchain(int kind, const RowChainArgs& g, hipStream_t s) {
     if (mc_ledger_on) {
         char name[32];
         snprintf(name, sizeof(name), "rowchain_k<%d, %d>", g.L, kind ? 1 : 0);
-        MC_LEDGER(name, grid, 2.0 * (double)(g.N - g.tok0) * g.Nout * g.L);
+        MC_LEDGER(name, grid, 2.0 * (double)mc_ledger_tokens(g) * g.Nout * g.L);
     }
 #define MC_RC_CASE(LL)                                                                    \
     case LL:                                                                              \

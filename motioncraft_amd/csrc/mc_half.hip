@@ -1373,7 +1373,7 @@ int mc_launch_pqbody_h(const RowChainArgs& g, int H, const mc_half* Wph, const m
     if (mc_ledger_on) {
         char name[40];
         snprintf(name, sizeof(name), "pqbody_h_k<%d, 12, %s>", g.L, split ? "true" : "false");
-        const double toks = (double)(g.N - g.tok0), hd = g.L / 8.0;      // (the optional second token range = aliased twins: its workgroups exit at once in the usual case)
+        const double toks = (double)(mc_ledger_tokens(g)), hd = g.L / 8.0;      // (aliased twins -- the tail of the range, or the optional second range -- exit at once in the usual case)
         MC_LEDGER(name, grid, 2.0 * toks * 7.0 * g.L * g.L + (toks / H) * (2.0 * H * H * g.L + 8 * 2.0 * (2.0 * H * hd * hd)));
     }
     if (g.L == 128) {
@@ -1396,7 +1396,7 @@ int mc_launch_projqkv_h(const RowChainArgs& g, const mc_half* Wph, const mc_half
     if (mc_ledger_on) {
         char name[40];
         snprintf(name, sizeof(name), "projqkv_h_k<%d, %s>", g.L, split ? "true" : "false");
-        MC_LEDGER(name, grid, 2.0 * (double)(g.N - g.tok0) * 7.0 * g.L * g.L);
+        MC_LEDGER(name, grid, 2.0 * (double)mc_ledger_tokens(g) * 7.0 * g.L * g.L);
     }
 #define MC_PQH(LL) case LL: if (split) hipLaunchKernelGGL((projqkv_h_k<LL, true>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql); \
                             else hipLaunchKernelGGL((projqkv_h_k<LL, false>), grid, dim3(256), 0, s, g, Wph, Wpl, Wqh, Wql); break;

@@ -31,25 +31,35 @@ d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_me
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, T, 322, generator=g).cuda()
 xf = torch.nn.functional.layer_norm(torch.randn(B, dims['Nt'], dims['Dt'], generator=g), (dims['Dt'],)).cuda()
-ctx.set_timesteps(d.timestep_map)
+lib = L_.load(require_gpu=True)
+
+
+def dump():
+    n = lib.mc_debug_flop_ledger_dump(None, 0)
+    buf = ctypes.create_string_buffer(int(n))
+    lib.mc_debug_flop_ledger_dump(buf, n)
+    return [l.split('\t') for l in buf.value.decode().splitlines() if l]
+
+
+lib.mc_debug_flop_ledger(1)
+ctx.set_timesteps(d.timestep_map)                            # once-per-batch set-up: time embedding for all steps, FiLM tables, text MoE + K/V per layer
 ctx.set_condition(xf, torch.ones(B, T).cuda())
+torch.cuda.synchronize()
+lib.mc_debug_flop_ledger(0)
+setup_rows = dump()
 order = [999, 998]
 coefs = [d.step_coefs(i, 'ddpm', dims['scale']) for i in order]
 ctx.sample_loop(x, order[:1], coefs[:1], seed=1)            # warm-up step (lazy allocations, routing buffers)
 torch.cuda.synchronize()
-lib = L_.load(require_gpu=True)
 lib.mc_debug_flop_ledger(1)
 ctx.sample_loop(x, order[1:], coefs[1:], seed=1)            # the booked step
 torch.cuda.synchronize()
 lib.mc_debug_flop_ledger(0)
-n = lib.mc_debug_flop_ledger_dump(None, 0)
-buf = ctypes.create_string_buffer(int(n))
-lib.mc_debug_flop_ledger_dump(buf, n)
 try:
     commit = subprocess.check_output(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
 except Exception:
     commit = os.environ.get('GIT_COMMIT', 'unknown')
-rows = [l.split('\t') for l in buf.value.decode().splitlines() if l]
+rows = dump()
 total = sum(float(r[2]) for r in rows)
 print(f'# commit {commit}')
 print(f'# tools/flop_ledger.py: one mc_sample_loop step, B={B} x {T} frames, precision {prec}, MC_CHAIN={os.environ.get("MC_CHAIN", "default")}')
@@ -57,3 +67,6 @@ print('# kernel@grid-work-items <TAB> launches per step <TAB> GFLOP per step (mu
 for name, calls, fl in sorted(rows, key=lambda r: -float(r[2])):
     print(f'{name}\t{calls}\t{float(fl) / 1e9:.3f}')
 print(f'# total {total / 1e9:.3f} GFLOP per step = {total / 1e9 / B:.3f} GFLOP per sample and step')
+print('# setup (mc_ctx_set_timesteps + mc_ctx_set_condition, once per batch): kernel@grid <TAB> launches <TAB> GFLOP')
+for name, calls, fl in sorted(setup_rows, key=lambda r: -float(r[2])):
+    print(f'setup:{name}\t{calls}\t{float(fl) / 1e9:.3f}')

@@ -74,8 +74,14 @@ def parse_ledger(path):
             continue
         key, calls, gf = line.rstrip('\n').split('\t')
         name, grid = key.rsplit('@', 1)
-        out[(name, int(grid))] = (int(calls), float(gf))
+        if name.startswith('setup:'):        # once-per-batch kernels (mc_ctx_set_condition): priced per launch, not part of the step's sums
+            setup[(name[6:], int(grid))] = (int(calls), float(gf))
+        else:
+            out[(name, int(grid))] = (int(calls), float(gf))
     return out
+
+
+setup = {}
 
 
 def csrc_digest():
@@ -117,15 +123,23 @@ for r in pmc:
         hit = [(k, v) for k, v in ledger.items() if r['name'].startswith(k[0]) and k[1] == r['grid'] * max(r['gy'], 1)]
         if not hit:
             hit = [(k, v) for k, v in ledger.items() if r['name'].startswith(k[0]) and k[1] == r['grid']]
+        is_setup = False
         if hit:
             used.update(k for k, _ in hit)
             calls = sum(v[0] for _, v in hit)
             fl = sum(v[1] for _, v in hit) * 1e9 / calls
             if per_step >= 1:
                 sum_gf += fl / 1e9 * per_step
+        else:
+            hs = [(k, v) for k, v in setup.items() if r['name'].startswith(k[0]) and k[1] in (r['grid'] * max(r['gy'], 1), r['grid'])]
+            if hs:
+                is_setup = True
+                fl = sum(v[1] for _, v in hs) * 1e9 / sum(v[0] for _, v in hs)
+                r['name'] = '(setup) ' + r['name']
     else:
+        is_setup = False
         fl = FLOPS.get((r['name'], r['grid']), FLOPS.get((r['name'], None)))
-    if per_step >= 1:
+    if per_step >= 1 and not is_setup and 'spin_k' not in r['name']:
         sum_us += r['us'] * per_step
     tf = fl / r['us'] / 1e6 if fl else None
     hb = next((v for k, v in hbm.items() if r['name'].startswith(k[:20]) or k.startswith(r['name'][:20])), None)
