@@ -589,6 +589,51 @@ def test_baseline_b64_free_running_envelope_vs_free_running_oracle(full_model):
     assert maxabs(hip[-1], ref) <= TOL_FINAL
 
 
+def test_flop_ledger_books_the_executed_flops_of_a_step(full_model):
+    """mc_debug_flop_ledger (round 6): what the launchers book for ONE step of the headline workload (B = 64 x 196 frames, both the two-stream
+    default and the single-stream schedule the per-kernel roofline is profiled on) equals the closed-form count `bench.py` prints as
+    `executed_gflop_per_sample_step` -- the per-kernel roofline (tools/kernel_roofline.py) and the bench line are priced from the same FLOPs.
+    (0.2 % allowance: the ledger books the pose-encoder GEMM at its padded K = 352, the closed form at 324.)"""
+    import ctypes
+    import sys
+    from motioncraft_amd import lib as L_
+    from motioncraft_amd.diffusion import build_diffusion
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    _, nm = full_model
+    lib = L_.load(require_gpu=True)
+    B, T = 64, 196
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+    x, xf, mask = synth_inputs(FULL, B, T, seed=3)
+    want = bench.executed_flops_per_sample_step(bench.DIMS, T) * B
+    for tag, chain in (('two-stream', DEFAULT_CHAIN), ('single-stream', DEFAULT_CHAIN & ~((1 << 5) | (1 << 6) | (1 << 9) | (1 << 16)))):
+        ctx = nm.context(B, T, max_steps=1000)
+        ctx.set_option('chain', chain)
+        ctx.set_timesteps(d.timestep_map)
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        xd = x.cuda()
+        ctx.sample_loop(xd, [999], [d.step_coefs(999, 'ddpm', FULL['scale'])], seed=1)
+        torch.cuda.synchronize()
+        lib.mc_debug_flop_ledger(1)
+        ctx.sample_loop(xd, [998], [d.step_coefs(998, 'ddpm', FULL['scale'])], seed=1)
+        torch.cuda.synchronize()
+        lib.mc_debug_flop_ledger(0)
+        n = lib.mc_debug_flop_ledger_dump(None, 0)
+        buf = ctypes.create_string_buffer(int(n))
+        lib.mc_debug_flop_ledger_dump(buf, n)
+        rows = [l.split('\t') for l in buf.value.decode().splitlines() if l]
+        got = sum(float(r[2]) for r in rows)
+        print(f'{tag}: ledger {got / 1e9 / B:.3f} GFLOP per sample and step over {sum(int(r[1]) for r in rows)} launches of {len(rows)} (kernel, grid) kinds; '
+              f'bench.py closed form {want / 1e9 / B:.3f}')
+        assert abs(got - want) <= 2e-3 * want, (tag, got, want)
+        assert all('@' in r[0] and int(r[1]) > 0 for r in rows)
+        ctx.close()
+    # off again: nothing is booked
+    lib.mc_debug_flop_ledger(1)
+    lib.mc_debug_flop_ledger(0)
+    assert lib.mc_debug_flop_ledger_dump(None, 0) == 1
+
+
 def test_complete_loop_free_running_b8_full_size_vs_the_oracles_own_band(full_model):
     """The north-star sentence at batch > 1, end to end and with NOTHING teacher-forced (VERDICT r05 "What's missing" 2; reference loop
     gaussian_diffusion.py:925-1049): full-size 0.125b, B = 8 x 196 frames, the COMPLETE 50-step DDIM loop, the same x_T / condition /
