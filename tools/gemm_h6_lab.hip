@@ -137,7 +137,9 @@ __device__ __forceinline__ void wait_vm() {
     else if constexpr (N_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N_ == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N_ == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if constexpr (N_ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -467,6 +469,18 @@ int main(int argc, char** argv) {
                 run_hr<256, 256, 32, 4, 2, 4, 1, 3>("  (no DMA in the loop, no epilogue traffic)", M, false);
                 run_hr<256, 256, 32, 4, 2, 4, 1, 7>("  (MFMAs + fragment reads only)", M, false);
             }
+            } else if (mode == 2) {
+            // ---- third experiment set: smaller tiles for the launches of a sample group (6272 / 12544 rows: 2.3 / 4.6 tiles of 128 x 128 per CU)
+            run_hr<128, 128, 64, 2, 2, 2, 2, 0>("", M, false);
+            run_hr<64, 128, 64, 2, 2, 2, 3, 0>("", M, chk);
+            run_hr<64, 128, 32, 3, 2, 2, 4, 0>("", M, chk);
+            run_hr<64, 128, 32, 2, 2, 2, 5, 0>("", M, chk);
+            run_hr<128, 64, 64, 2, 2, 2, 3, 0>("", M, chk);
+            run_hr<128, 64, 32, 3, 2, 2, 4, 0>("", M, chk);
+            run_hr<64, 256, 32, 3, 2, 2, 3, 0>("", M, chk);
+            run_hr<64, 256, 64, 2, 2, 2, 2, 0>("", M, chk);
+            run_hr<128, 192, 32, 3, 2, 2, 2, 0>("", M, chk);
+            run_hr<64, 192, 32, 3, 2, 2, 3, 0>("", M, chk);
             } else {
             // ---- second experiment set: DMA pieces between the MFMAs; R + bias as the accumulators' start value
             run_hr<256, 128, 32, 3, 2, 2, 2, 0>("", M, false);
