@@ -176,6 +176,11 @@ struct mc_ctx {
     hipStream_t side_for = nullptr;         // the caller stream the current `side` was picked for
     bool side_picked = false;
     float side_probe_ms[SIDE_CAND] = {0.f, 0.f, 0.f, 0.f};
+    // earlier answers (a host that alternates between a few caller streams must not re-probe -- and re-synchronise -- on every call)
+    static constexpr int SIDE_MEMO = 4;
+    hipStream_t side_memo_for[SIDE_MEMO] = {nullptr, nullptr, nullptr, nullptr};
+    int side_memo_pick[SIDE_MEMO] = {-1, -1, -1, -1};
+    int side_memo_n = 0;
     hipEvent_t ev_parts[3] = {nullptr, nullptr, nullptr};
     int nparts = 2;
     // hipGraph replay of the sampler step (mc_ctx_graph_capture / _step): ONE graph for all steps of the schedule; the step
@@ -801,6 +806,13 @@ int pick_side_stream(mc_ctx* c, hipStream_t s) {
     if (c->side_picked && c->side_for == s) return MC_OK;
     static const bool enabled = [] { const char* e = getenv("MC_SIDE_PROBE"); return !e || atoi(e) != 0; }();
     if (!enabled || c->graph_mode || c->graph_exec) return MC_OK;
+    for (int k = 0; k < c->side_memo_n; ++k)
+        if (c->side_memo_for[k] == s) {          // answered before for this caller stream: switch without a probe (the previous call joined its side work)
+            c->side = c->side_cand[c->side_memo_pick[k]];
+            c->parts[0] = c->side;
+            c->side_for = s;
+            return MC_OK;
+        }
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return MC_OK; }
     hipEvent_t e0 = nullptr, e1 = nullptr, eq = nullptr;
@@ -830,6 +842,11 @@ int pick_side_stream(mc_ctx* c, hipStream_t s) {
     c->parts[0] = c->side;
     c->side_for = s;
     c->side_picked = true;
+    {
+        const int slot = c->side_memo_n < mc_ctx::SIDE_MEMO ? c->side_memo_n++ : 0;      // (more than SIDE_MEMO caller streams: the oldest answer is re-probed)
+        c->side_memo_for[slot] = s;
+        c->side_memo_pick[slot] = best;
+    }
     if (getenv("MC_SIDE_PROBE_VERBOSE"))
         fprintf(stderr, "[motioncraft_amd] side stream for caller stream %p: candidate %d (spin pair %.0f %.0f %.0f %.0f us)\n", (void*)s, best,
                 c->side_probe_ms[0] * 1e3f, c->side_probe_ms[1] * 1e3f, c->side_probe_ms[2] * 1e3f, c->side_probe_ms[3] * 1e3f);
