@@ -1787,6 +1787,39 @@ def test_two_stream_schedule_is_race_free_under_stream_skew(full_model, prec):
         assert torch.equal(got['plain'], got['first_late']), (B, maxabs(got['plain'], got['first_late']))
 
 
+def test_side_stream_is_picked_per_caller_stream_and_results_do_not_depend_on_it(full_model):
+    """Round 6: a context times its four candidate side streams against the CALLER's stream (two HIP streams overlap only on different hardware
+    queues; with an RCCL process group in the process the single side stream of round 5 shared the caller's queue and the two-stream
+    schedule ran serially) and remembers the answer per caller stream.  The same two sampler steps issued on the default stream, on two
+    other streams and on the default stream again (probe, probe, probe, memo) must give the SAME BITS -- which side stream carries the
+    second sample group is a scheduling matter only; B = 16 (large-batch two-stream schedule) and B = 2 (temporal branch on the side stream)."""
+    from motioncraft_amd.diffusion import build_diffusion
+    sd, nm = full_model
+    d = build_diffusion(dict(beta_scheduler='linear', diffusion_steps=1000, model_mean_type='start_x', model_var_type='fixed_large'))
+    for B, T in ((16, 196), (2, 196)):
+        g = torch.Generator().manual_seed(51)
+        x_T, xf, mask = synth_inputs(FULL, B, T, seed=52, lengths=[int(v) for v in torch.randint(64, 197, (B,), generator=g)])
+        eps = torch.randn(B, T, 322, generator=g).cuda()
+        ctx = nm.context(B, T, max_steps=2)
+        ctx.set_timesteps(d.timestep_map[-2:])
+        ctx.set_condition(xf.cuda(), mask.cuda())
+        torch.cuda.synchronize()
+        streams = [None, torch.cuda.Stream(), torch.cuda.Stream(), None, None]
+        outs = []
+        for st in streams:
+            with torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.default_stream()):
+                x = x_T.cuda()
+                for i in (1, 0):
+                    x = ctx.sample_step(x, i, d.step_coefs(998 + i, 'ddpm', FULL['scale']), eps)
+                torch.cuda.current_stream().synchronize()
+                outs.append(x.clone())
+        torch.cuda.synchronize()
+        ctx.close()
+        assert bool(torch.isfinite(outs[0]).all())
+        for k in range(1, len(outs)):
+            assert torch.equal(outs[0], outs[k]), (B, k, maxabs(outs[0], outs[k]))
+
+
 def test_unconditional_half_skips_its_text_rows_bit_identically(full_model):
     """chain bit 24 (round 5): in temporal_k the unconditional CFG half's text keys all carry the -1e6 of st_attention.py:153 and its text
     values are multiplied by c = 0 (:161) -- exact zeros in the column softmax and in K^T V as long as the sample has one valid frame --
