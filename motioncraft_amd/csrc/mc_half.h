@@ -35,6 +35,7 @@ struct GemmHArgs {
     long ldc = 0;
     int M = 0, N = 0, K = 0;      // N % 128 == 0, K % 32 == 0, lda/ldc/ldr % 4 == 0
     int act = 0;
+    int a_fm = 0;                 // the A planes are fragment-major (film_rows_k planes | 4): gemm_hf_k reads its fragments straight into registers
     int acc_init = 0;             // plane kernel, plain f16, R and bias set, no activation: the accumulators START as R + bias (loads in flight during the
                                   // DMA prologue; the epilogue is stores only) -- another fp32 summation order than (sum + bias) + R: not for the split mode
 };

@@ -339,6 +339,134 @@ __global__ __launch_bounds__(256, 2) void gemm_hd_k(GemmHArgs g) {
 }
 
 // =================================================================================================
+// gemm_hf_k (round 6, tools/gemm_h6_lab.hip ha_k): gemm_hd_k whose A operand NEVER touches LDS.  film_rows_k writes the activation planes FRAGMENT-MAJOR --
+// per 32-row block and 16-wide k-step the 64 lanes' 16-byte MFMA operands contiguous (1 KB) -- so a wave fetches the fragments of ITS 32 rows with one
+// coalesced global_load_dwordx4 per k-step and plane, straight into VGPRs: no LDS-DMA piece, no ds_read, no barrier dependency for A.  4 waves, each 32 rows x
+// all 128 columns of the tile (4 accumulator blocks); only W rides the LDS-DMA ring (3 slots of [plane][128 rows][BKH halves]: 48 KB), ONE raw barrier per
+// slab, A fragments and W pieces requested two slabs ahead and retired together by counted vmcnt (loads return in order; everything inline asm, so the compiler
+// neither counts nor drains them).  Lab, plain f16, same passes: 193 us against 218 at 25088 rows, 82 vs 92 at 12544, 48.5 vs 57 at 6272; bit-equal to
+// gemm_hd_k (the same k order per output, the same three products per operand pair in the split mode).
+// The residual rows are prefetched at the top of the tile as in gemm_hd_k<., ., true>.
+// =================================================================================================
+__device__ __forceinline__ void gload16h(f16x8& dst, const mc_half* base, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_hf_k(GemmHArgs g) {
+    constexpr int P = SPLIT ? 2 : 1;
+    constexpr int BKH = SPLIT ? 32 : 64, KS = BKH / 16;      // halves per slab, k-steps per slab
+    constexpr int CH = BKH / 8, RPI = 64 / CH;               // 16-byte chunks per W row, W rows per wave-wide DMA instruction
+    constexpr int PT = 128 * BKH;                            // halves per W plane tile
+    constexpr int ST = 3;
+    constexpr int NQ = 32 / RPI;                             // DMA instructions per plane tile per wave (4 / 2)
+    constexpr int NVM = P * NQ + P * KS;                     // vector-memory operations of one slab per wave: W pieces + A fragments (= 8 in both modes)
+    static_assert(NVM == 8, "gemm_hf_k: the counted wait below is written for 8 operations per slab");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[ST * P * PT];     // [slot][plane][128][BKH] = 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int frow = lane & 31, hf = lane >> 5;
+    const int ntn = g.N / 128;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * 128, nrows = min(128, g.M - row0);
+    auto swz = [&](int r) { return SPLIT ? ((r >> 2) & 3) : ((r >> 1) & 7); };
+    const int dr = lane / CH, dpos = lane % CH;
+    unsigned gow[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int r = 32 * wave + q * RPI + dr;              // W row inside the tile
+        gow[q] = (unsigned)(((long)(tn * 128 + r) * g.K + (dpos ^ swz(r)) * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto issue_w = [&](int s) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const mc_half* wp = (p ? g.Wl : g.Wh) + s * BKH;
+            const unsigned lw = lds0 + (unsigned)((((s % ST) * P + p) * PT + 32 * wave_u * BKH) * 2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dma16h(gow[q], wp, lw + q * RPI * BKH * 2);
+        }
+    };
+    // this wave's row block of the fragment-major planes (rows past M: the last block -- valid memory, never stored)
+    const int nrb = g.M >> 5;
+    const int rb = min((row0 >> 5) + wave_u, nrb - 1);
+    const unsigned abase = (unsigned)(((long)rb * (g.K >> 4) * 64 + lane) * 16);
+    f16x8 fa[3][P][KS];
+    auto issue_a = [&](int s, int set) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int k = 0; k < KS; ++k) gload16h(fa[set][p][k], p ? g.Al : g.Ah, abase + (unsigned)((s * KS + k) * 1024));
+    };
+    // residual rows of the epilogue, requested first (they are the oldest loads: every counted wait below covers them)
+    const int m = wave * 32 + frow;
+    f32x4 rpre[4][4];
+    const bool has_r = g.R != nullptr;
+    if (has_r) {
+        const float* rrow = g.R + (long)(row0 + min(m, nrows - 1)) * g.ldr + tn * 128 + 4 * hf;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rpre[ni][q] = *reinterpret_cast<const f32x4*>(rrow + ni * 32 + 8 * q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    const int ns = g.K / BKH;
+    issue_w(0); issue_a(0, 0);
+    if (ns > 1) { issue_w(1); issue_a(1, 1); }
+    const int sw = swz(frow);                                 // rows frow, frow + 32, + 64, + 96 share the swizzle term
+    auto body = [&](int s, int set, int nset) {
+        // outstanding, oldest first: W(s) A(s) W(s + 1) A(s + 1): slab s has landed when at most the 8 operations of slab s + 1 remain
+        if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave's pieces of slab s are in LDS; every wave has read slab s - 1
+        if (s + 2 < ns) { issue_w(s + 2); issue_a(s + 2, nset); }
+        const _Float16* sl = smem + (s % ST) * P * PT;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int pos = ((2 * k + hf) ^ sw) * 8;
+            f16x8 fw[4][P];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int p = 0; p < P; ++p) fw[ni][p] = *reinterpret_cast<const f16x8*>(sl + p * PT + (ni * 32 + frow) * BKH + pos);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = mma3<SPLIT>(fw[ni][0], fw[ni][P - 1], fa[set][0][k], fa[set][P - 1][k], acc[ni]);
+        }
+    };
+    // (the register ring is indexed statically: three slabs per trip)
+    int s = 0;
+    for (; s + 2 < ns; s += 3) {
+        body(s, 0, 2);
+        body(s + 1, 1, 0);
+        body(s + 2, 2, 1);
+    }
+    if (s < ns) body(s, 0, 2);
+    if (s + 1 < ns) body(s + 1, 1, 0);
+    if (m >= nrows) return;
+    float* crow = g.C + (long)(row0 + m) * g.ldc;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = tn * 128 + ni * 32 + 8 * q + 4 * hf;
+            f32x4 v = {acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]};
+            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+            if (g.act != ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], g.act);
+            }
+            if (has_r) v += rpre[ni][q];
+            *reinterpret_cast<f32x4*>(crow + n) = v;
+        }
+}
+
+// =================================================================================================
 // Fused 2-layer MLP on the fp16 MFMA (structure of mlp2_k, mc_chain.hip): X fragment in VGPRs, hidden in 32-wide chunks
 // whose FC1 accumulator -- bias + exact GELU in fp32, then split -- is directly the B operand of FC2
 // =================================================================================================
@@ -1278,7 +1406,22 @@ int mc_launch_gemm_h(const GemmHArgs& g, bool split, hipStream_t s) {
                    "fp16 gemm (planes): unsupported shape (M=%d N=%d K=%d)", g.M, g.N, g.K);
         if (g.M <= 0) return MC_OK;
         dim3 grid(cdiv(g.M, 128) * (g.N / 128));
-        MC_LEDGER(split ? "gemm_hd_k<true>" : "gemm_hd_k<false>", grid, 2.0 * g.M * g.N * g.K);      // (fp32-equivalent product: the split form runs 3 fp16 MFMAs per operand pair)
+        if (!g.a_fm) MC_LEDGER(split ? "gemm_hd_k<true>" : "gemm_hd_k<false>", grid, 2.0 * g.M * g.N * g.K);      // (fp32-equivalent product: the split form runs 3 fp16 MFMAs per operand pair)
+        if (g.a_fm) {          // fragment-major planes: A straight into registers (M % 32 == 0, K % 64 == 0; the producer wrote the rows of THIS launch)
+            MC_REQUIRE(g.M % 32 == 0 && g.K >= 192, "fp16 gemm (fragment-major planes): M=%d K=%d", g.M, g.K);
+            // its A fragments arrive by inline-asm loads the compiler does not track: a spilled (copied) fragment register would be read before it landed
+            static const int scratch = [] {
+                hipFuncAttributes a0, a1;
+                if (hipFuncGetAttributes(&a0, (const void*)gemm_hf_k<false>) != hipSuccess || hipFuncGetAttributes(&a1, (const void*)gemm_hf_k<true>) != hipSuccess) return -1;
+                return (int)(a0.localSizeBytes + a1.localSizeBytes);
+            }();
+            MC_REQUIRE(scratch == 0, "gemm_hf_k of this build uses scratch memory (%d bytes; -1 = attributes unreadable): its asynchronous fragment loads are unsafe", scratch);
+            MC_LEDGER(split ? "gemm_hf_k<true>" : "gemm_hf_k<false>", grid, 2.0 * g.M * g.N * g.K);
+            if (split) hipLaunchKernelGGL(gemm_hf_k<true>, grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL(gemm_hf_k<false>, grid, dim3(256), 0, s, g);
+            MC_LAUNCH_CHECK();
+            return MC_OK;
+        }
         const bool pre = (g.acc_init & 1) && g.R, init = (g.acc_init & 2) && g.R && g.bias && g.act == ACT_NONE;
         if (split) {
             if (pre) hipLaunchKernelGGL((gemm_hd_k<true, false, true>), grid, dim3(256), 0, s, g);

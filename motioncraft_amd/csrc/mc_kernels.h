@@ -25,7 +25,7 @@ struct StepRef {
 int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, const float* beta,
                         const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias = TwinAlias(), long row0 = 0,
                         StepRef step = StepRef(), int y1_parts = 1, long y1_pstride = 0,    // y1_parts > 1: Y1 = sum of that many partial planes
-                        int planes = 0, long plane_stride = 0);   // planes 1 / 2: A is written as fp16 plane(s) [rows][D] halves (hi | lo plane_stride halves behind) for gemm_hd_k
+                        int planes = 0, long plane_stride = 0);   // planes 1 / 2: A is written as fp16 plane(s) [rows][D] halves (hi | lo plane_stride halves behind) for gemm_hd_k; + 4: FRAGMENT-MAJOR planes for gemm_hf_k (rows % 32 == 0)
 // te[s][0:D] = cat(cos(t_s f), sin(t_s f))
 int mc_launch_timestep_embedding(const int* t_orig, float* te, int S, int D, hipStream_t s);
 int mc_launch_silu(const float* X, float* Y, long n, hipStream_t s);

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = silu_f((v[c][j] * rstd * g[j] + b[j]) * (1.0f + sc[j]) + sh[j]);
-            if (planes == 0) *reinterpret_cast<f32x4*>(A + r * D + ch * 4) = o;
+            if ((planes & 3) == 0) *reinterpret_cast<f32x4*>(A + r * D + ch * 4) = o;
             else {
                 // reduced-precision contexts: the GEMM that consumes `a` wants fp16 operand planes (hi, and lo = fp16(x - hi) in the
                 // split mode: the arithmetic of split8, mc_half.hip) -- written here ONCE instead of converted by every column tile
@@ -122,8 +122,12 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
                     lo[j] = (_Float16)(x - hxf);
                 }
                 _Float16* Ah = reinterpret_cast<_Float16*>(A);
-                *reinterpret_cast<h4*>(Ah + r * D + ch * 4) = hi;
-                if (planes == 2) *reinterpret_cast<h4*>(Ah + plane_stride + r * D + ch * 4) = lo;
+                // row-major [rows][D], or (planes & 4) FRAGMENT-MAJOR for gemm_hf_k: per 32-row block and 16-wide k-step the 64 lanes' MFMA operands
+                // contiguous -- [row block][k-step][lane = (row & 31) + 32 ((k >> 3) & 1)][8 halves]; rows local to this launch (rows % 32 == 0)
+                const int k = ch * 4;
+                const long off = (planes & 4) ? (((r >> 5) * (long)(D >> 4) + (k >> 4)) * 64 + (r & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 4) : r * D + k;
+                *reinterpret_cast<h4*>(Ah + off) = hi;
+                if ((planes & 3) == 2) *reinterpret_cast<h4*>(Ah + plane_stride + off) = lo;
             }
         }
     }
@@ -468,7 +472,8 @@ int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, co
                         const float* ss, float* A, long rows, int D, hipStream_t s, TwinAlias y1_alias, long row0, StepRef step,
                         int y1_parts, long y1_pstride, int planes, long plane_stride) {
     MC_REQUIRE(D % 4 == 0 && D <= FILM_MAXC * 256, "film_rows: unsupported D=%d", D);
-    MC_REQUIRE(planes >= 0 && planes <= 2, "film_rows: planes=%d", planes);
+    MC_REQUIRE(planes >= 0 && (planes & 3) <= 2 && (planes & ~7) == 0 && (!(planes & 4) || ((planes & 3) != 0 && rows % 32 == 0 && D % 16 == 0)),
+               "film_rows: planes=%d (rows=%ld D=%d)", planes, rows, D);
     if (rows <= 0) return MC_OK;
     hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step,
                        y1_parts < 1 ? 1 : y1_parts, y1_pstride, planes, plane_stride);

@@ -93,6 +93,8 @@ struct McOptions {
     //    B=32 3.98 -> 3.81 ms/step; f16x3 10.72 -> 10.62, 5.52 -> 5.45
     // 28 (round 6, OFF) plain f16 only: the accumulators START as R + bias instead (stores-only epilogue; f16 B=32 3.75 against bit 27's 3.81) -- another fp32
     //    summation order (2.6e-4 on h after one layer, 1.1e-3 on x0 against the exact order: inside plain f16's own error, but not free): a switch, not the default
+    // 29 (round 6) reduced-precision contexts: the FiLM operand planes are written FRAGMENT-MAJOR and the plane GEMM reads its A fragments straight into registers
+    //    (gemm_hf_k: only W rides the LDS-DMA ring; tools/gemm_h6_lab.hip ha_k); launches whose rows are whole 32-row blocks only; the same bits as gemm_hd_k
     int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26) | (1 << 27);     // (all but bits 3, 23 and 25)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
@@ -588,8 +590,11 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
     const long pstride = c->rows * D;
     float* a_rows = prologue_only ? deferred_a(c) : c->a;
     float* a_out = planes ? reinterpret_cast<float*>(reinterpret_cast<mc_half*>(c->a) + o) : a_rows + o;
+    // chain bit 29 (round 6): the planes of THIS launch's rows are written fragment-major and the GEMM reads its A fragments straight into registers
+    // (gemm_hf_k); needs whole 32-row blocks (a sample group of B x 196 frames with B % 8 == 0 has them), else the row-major planes + gemm_hd_k
+    const bool frag_major = planes && chain_on(c, 29) && row0 % 32 == 0 && nrows % 32 == 0 && D % 64 == 0 && D >= 192;
     if ((r = mc_launch_film_rows(y1_parts > 1 ? y1 : y1 + o, y2 ? y2 + o : nullptr, ln_g, ln_b, ss, a_out, nrows, D, s, y1_alias, row0, sref,
-                                 y1_parts, nrows * D, planes ? (c->prec == MC_PREC_F16X3 ? 2 : 1) : 0, pstride))) return r;
+                                 y1_parts, nrows * D, planes ? ((c->prec == MC_PREC_F16X3 ? 2 : 1) | (frag_major ? 4 : 0)) : 0, pstride))) return r;
     if (ev_after_rows) MC_HIP(hipEventRecord(ev_after_rows, s));
     if (prologue_only) return MC_OK;
     // h = h + Linear(a)          (st_attention.py:172 / stmogen.py:606)
@@ -598,6 +603,7 @@ int film_block(mc_ctx* c, float* hs, const float* y1, const float* y2, const flo
         g.Ah = reinterpret_cast<mc_half*>(c->a) + o; g.Al = g.Ah + pstride;
         g.Wh = hw->hi; g.Wl = hw->lo; g.bias = out_b; g.R = hs + o; g.ldr = D; g.C = hs + o; g.ldc = D;
         g.M = (int)nrows; g.N = D; g.K = D;
+        g.a_fm = frag_major ? 1 : 0;
         g.acc_init = (chain_on(c, 27) ? 1 : 0) | (chain_on(c, 28) ? 2 : 0);      // 1: residual rows prefetched into registers (same bits), 2: accumulators start as R + bias (plain f16 only)
         return mc_launch_gemm_h(g, c->prec == MC_PREC_F16X3, s);
     }

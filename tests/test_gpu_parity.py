@@ -1066,6 +1066,41 @@ def test_fp16_fused_body_kernel_and_plane_gemm_equal_the_separate_kernels(prec):
     nm.close()
 
 
+@pytest.mark.parametrize('prec', ['f16x3', 'f16'])
+def test_fragment_major_planes_and_register_fed_plane_gemm_are_bit_identical(prec):
+    """chain bit 29 (round 6): film_rows_k writes the FiLM operand planes fragment-major -- per 32-row block and 16-wide k-step the 64 lanes' MFMA
+    operands contiguous -- and gemm_hf_k reads its A fragments straight into registers (only W through LDS).  Same k order per output, the same
+    three products per operand pair in the split mode: the SAME BITS as the row-major planes + gemm_hd_k.  0.125b widths, B = 16 x 196 frames in the
+    two-stream schedule (sample groups of 3136 rows = 98 whole 32-row blocks) with ragged lengths; and B = 3 x 24 frames (72-row groups: no whole
+    blocks, the launcher must fall back to the row-major path by itself)."""
+    from motioncraft_amd.engine import NativeModel
+    from oracle import weights as W
+    dims = FULL
+    nm = NativeModel(dims, W.make_state_dict(dims, 0), cfg_scale=dims['scale'])
+    for B, T, lengths in ((16, 196, [196, 150, 64, 196, 100, 196, 77, 196, 196, 120, 196, 196, 90, 196, 196, 130]), (3, 24, [24, 20, 13])):
+        x, xf, mask = synth_inputs(dims, B, T, seed=7, lengths=lengths)
+        got = {}
+        for tag, chain in (('frag_major', DEFAULT_CHAIN | (1 << 29)), ('row_major', DEFAULT_CHAIN & ~(1 << 29))):
+            ctx = nm.context(B, T, max_steps=2)
+            if B == 3:
+                ctx.set_option('big_tokens', 0)
+                ctx.set_option('half_min_rows', 0)
+            ctx.set_option('chain', chain)
+            ctx.set_precision(prec)
+            ctx.set_timesteps([800, 30])
+            ctx.set_condition(xf.cuda(), mask.cuda())
+            out = ctx.denoise(x.cuda(), 1).clone()
+            ctx.denoise(x.cuda(), 0, stop_after_layers=1)
+            torch.cuda.synchronize()
+            got[tag] = (out, ctx.buffer('h').clone())
+            assert ctx.effective_precision == prec
+            ctx.close()
+        assert bool(torch.isfinite(got['frag_major'][0]).all())
+        for k, name in enumerate(('x0', 'h after layer 0')):
+            assert torch.equal(got['frag_major'][k], got['row_major'][k]), (prec, B, name, maxabs(got['frag_major'][k], got['row_major'][k]))
+    nm.close()
+
+
 @pytest.mark.parametrize('latent', [128, 64])
 def test_fp16_temporal_attention_kernel_vs_the_fp32_kernel(latent):
     """temporal_h_k (round 4: the temporal linear attention's two contractions on the fp16 MFMA, K / V chunks transposed while staging,

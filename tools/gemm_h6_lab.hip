@@ -309,6 +309,113 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void hr_k(HA
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ha_k: the A operand NEVER touches LDS.  The producer would write the activation planes FRAGMENT-MAJOR -- for every 32-row block and every 16-wide k-step the
+// 64 lanes' 16-byte MFMA operands contiguous (1 KB: [row block][k-step][lane][8 halves]) -- so a wave fetches the fragments of ITS 32 rows with one coalesced
+// global_load_dwordx4 per k-step, straight into VGPRs (no LDS-DMA piece, no ds_read, no barrier dependency for A).  TM / 32 waves, each 32 rows x TN columns;
+// only W rides the LDS-DMA ring (TN rows x BK halves per slot).  A fragments are requested two slabs ahead into a 3-deep register ring (inline asm, counted
+// vmcnt together with the W pieces: loads return in order).  Result identical to the library kernel (the same k order per output).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gload16(f16x8& dst, const half_t* base, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+
+template <int TM, int TN, int ST, int OCC, int FLAGS>
+__global__ __launch_bounds__(TM / 32 * 64, (OCC * (TM / 32) + 3) / 4) void ha_k(HArgs g, const half_t* __restrict__ Af) {
+    constexpr int BK = 64, NW = TM / 32, RB = BK * 2, RPI = 8, KS = BK / 16;
+    constexpr int SLOT = TN * RB, NP = TN / RPI, P = NP / NW;          // W pieces per slab, per wave
+    static_assert(NP % NW == 0, "W pieces must divide over the waves");
+    constexpr int D = ST - 1, NI = TN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int frow = lane & 31, hf = lane >> 5;
+    const int ntn = g.N / TN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * TM, nrows = min(TM, g.M - row0);
+    auto swz = [](int r) { return (r >> 1) & 7; };
+    const int dr = lane / 8, dpos = lane % 8;
+    unsigned goff[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int r = (wave_u * P + p) * RPI + dr;
+        goff[p] = (unsigned)(((long)(tn * TN + r) * g.K + (dpos ^ swz(r)) * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto issue_w = [&](int s) {
+        const unsigned slot = lds0 + (unsigned)((s % ST) * SLOT);
+#pragma unroll
+        for (int p = 0; p < P; ++p) dma16h(goff[p], g.W + s * BK, slot + (unsigned)((wave_u * P + p) * RPI * RB));
+    };
+    // fragment-major A: row block rb = (row0 + 32 wave) / 32 (rows past M: the last block, never stored), k-step ks -> 1 KB at ((rb * K/16 + ks) * 64 + lane) * 16 bytes
+    const int nrb = (g.M + 31) / 32;
+    const int rb = min((row0 >> 5) + wave_u, nrb - 1);
+    const unsigned abase = (unsigned)(((long)rb * (g.K / 16) * 64 + lane) * 16);
+    f16x8 fa[3][KS];
+    auto issue_a = [&](int s, int set) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) gload16(fa[set][k], Af, abase + (unsigned)((s * KS + k) * 1024));
+    };
+    f32x16 acc[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int ns = g.K / BK;
+    int wrow[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wrow[j] = j * 32 + frow;
+    // prologue: slabs 0 .. D - 1 of W and of the A fragments, interleaved in the order the loop keeps (W(s), A(s))
+    static_assert(D == 2, "ha_k: the register ring is written for two slabs in flight");
+    issue_w(0); issue_a(0, 0);
+    issue_w(1); issue_a(1, 1);
+    auto body = [&](int s, int set, int nset) {
+        // outstanding, oldest first: W(s) A(s) W(s + 1) A(s + 1): slab s has landed when at most P + KS younger operations remain
+        if (s + 1 < ns) wait_vm<P + KS>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < ns) { issue_w(s + 2); issue_a(s + 2, nset); }
+        const unsigned char* sl = smem + (s % ST) * SLOT;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            f16x8 fw[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fw[j] = *reinterpret_cast<const f16x8*>(sl + wrow[j] * RB + (((2 * k + hf) ^ swz(wrow[j])) * 16));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[set][k], acc[j], 0, 0, 0);
+        }
+    };
+    // (the register ring is indexed statically: three slabs per trip)
+    int s = 0;
+    for (; s + 2 < ns; s += 3) {
+        body(s, 0, 2);
+        body(s + 1, 1, 0);
+        body(s + 2, 2, 1);
+    }
+    if (s < ns) body(s, 0, 2);
+    if (s + 1 < ns) body(s + 1, 1, 0);
+    const int m = wave * 32 + frow;
+    if (m < nrows) {
+        float* crow = g.C + (long)(row0 + m) * g.N;
+        const float* rrow = g.R + (long)(row0 + m) * g.N;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tn * TN + j * 32 + 8 * q + 4 * hf;
+                f32x4 v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (FLAGS & 1) {
+                    if (v[0] == 1234.56789f) *reinterpret_cast<f32x4*>(crow + n) = v;
+                } else {
+                    v += *reinterpret_cast<const f32x4*>(rrow + n);
+                    *reinterpret_cast<f32x4*>(crow + n) = v;
+                }
+            }
+    }
+}
+
 // bare MFMA stream: no memory, no barrier -- the clock-limited ceiling of v_mfma_f32_32x32x16_f16 on operands that change every instruction
 __global__ __launch_bounds__(256, 2) void bare_k(float* out, int iters, const half_t* __restrict__ vals) {
     f32x16 acc[8];
@@ -339,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void bare_k(float* out, int iters, const ha
 // ---------------------------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------------------------
-static half_t *dA, *dW;
+static half_t *dA, *dW, *dAf;
 static float *dB, *dR, *dC, *dC2;
 static int NCU;
 
@@ -396,6 +503,24 @@ static void run_hr(const char* name, int M, bool check) {
 // run one kernel back to back for ~8 s so that rocm-smi can sample clock and power under it: 0 bare MFMA stream, 1 library kernel, 2 hr_k 256x128 without
 // epilogue traffic, 3 hr_k 256x128 MFMAs + fragment reads only
 static int power_loop(int which);
+template <int TM, int TN, int ST, int OCC, int FLAGS>
+static void run_ha(const char* name, int M, bool check) {
+    HArgs g{dA, dW, dB, dR, dC2, M, 1536, 1536};
+    const int grid = ((M + TM - 1) / TM) * (1536 / TN);
+    constexpr int lds = ST * TN * 64 * 2;
+    auto kern = ha_k<TM, TN, ST, OCC, FLAGS>;
+    static bool once = [&] { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); return true; }();
+    (void)once;
+    if (check) hipMemset(dC2, 0xff, (size_t)M * 1536 * 4);
+    const float us = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(TM / 32 * 64), lds, 0, g, dAf); });
+    char buf[160];
+    snprintf(buf, sizeof(buf), "ha_k %3dx%3d BK64 ring %d, %d x 1 waves, %d WG/CU, %3d KB LDS, A fragment-major -> registers%s", TM, TN, ST, TM / 32, OCC, lds / 1024, name);
+    report(buf, M, us);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("    !! %s\n", hipGetErrorString(e)); exit(1); }
+    if (check) compare(M, "vs the library kernel");
+}
+
 int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -416,6 +541,16 @@ int main(int argc, char** argv) {
     for (auto& x : hW) x = (half_t)(gauss() * 0.0255f);
     for (auto& x : hB) x = gauss();
     hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    {   // fragment-major copy of A: [row block of 32][k-step of 16][lane][8 halves], lane -> row lane & 31, k = 8 (lane >> 5) + i
+        std::vector<half_t> hAf(MMAX * K);
+        const size_t nks = K / 16;
+        for (size_t rb = 0; rb < MMAX / 32; ++rb)
+            for (size_t ks = 0; ks < nks; ++ks)
+                for (size_t l = 0; l < 64; ++l)
+                    for (size_t i = 0; i < 8; ++i) hAf[((rb * nks + ks) * 64 + l) * 8 + i] = hA[(rb * 32 + (l & 31)) * K + ks * 16 + 8 * (l >> 5) + i];
+        hipMalloc(&dAf, MMAX * K * 2);
+        hipMemcpy(dAf, hAf.data(), hAf.size() * 2, hipMemcpyHostToDevice);
+    }
     hipMemcpy(dR, hR.data(), hR.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
@@ -469,6 +604,18 @@ int main(int argc, char** argv) {
                 run_hr<256, 256, 32, 4, 2, 4, 1, 3>("  (no DMA in the loop, no epilogue traffic)", M, false);
                 run_hr<256, 256, 32, 4, 2, 4, 1, 7>("  (MFMAs + fragment reads only)", M, false);
             }
+            } else if (mode == 3) {
+            // ---- fourth experiment set: A fragments straight from a fragment-major plane into registers, only W through LDS
+            run_hr<128, 128, 64, 2, 2, 2, 2, 0>("", M, false);
+            run_ha<128, 128, 3, 2, 0>("", M, chk);
+            run_ha<128, 128, 3, 3, 0>("", M, chk);
+            run_ha<128, 128, 3, 4, 0>("", M, chk);
+            run_ha<128, 256, 3, 2, 0>("", M, chk);
+            run_ha<256, 128, 3, 2, 0>("", M, chk);
+            run_ha<256, 256, 3, 1, 0>("", M, chk);
+            run_ha<128, 128, 3, 3, 1>("  (no epilogue traffic)", M, false);
+            run_ha<128, 256, 3, 2, 1>("  (no epilogue traffic)", M, false);
+            run_hr<128, 128, 64, 2, 2, 2, 2, 1>("  (no epilogue traffic)", M, false);
             } else if (mode == 2) {
             // ---- third experiment set: smaller tiles for the launches of a sample group (6272 / 12544 rows: 2.3 / 4.6 tiles of 128 x 128 per CU)
             run_hr<128, 128, 64, 2, 2, 2, 2, 0>("", M, false);
