@@ -54,9 +54,18 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
                                                    const float* __restrict__ ss, float* __restrict__ A,
                                                    long rows, int D, TwinAlias y1_alias, long row0, StepRef step, int y1_parts,
                                                    long y1_pstride, int planes, long plane_stride) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 film_stage[];      // fragment-major mode only: [plane][4 rows][D + 8] halves
     if (step.ptr) ss += (long)(*step.ptr) * step.stride;
     const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (planes & 4) {
+        // fragment-major planes: a 32-row block is ONE 1 KB run per (k-step, plane), written 16 bytes per lane pair.  The eight workgroups that share a block are
+        // given the same XCD (workgroup b lands on XCD b % 8 -- speed only) and consecutive dispatch slots there, so their pieces meet in ONE L2 and leave it as
+        // whole lines: block = 8 (j / 8) + b % 8, rows 4 (j % 8) .. + 3 of it, j = b / 8 (the grid is padded to whole groups of 64: surplus workgroups leave)
+        const long j = blockIdx.x >> 3;
+        const long rb = (j >> 3) * 8 + (blockIdx.x & 7);
+        r = rb * 32 + (j & 7) * 4 + (threadIdx.x >> 6);
+    }
     if (r >= rows) return;
     // CFG twin aliasing (base layer 0): Y1 rows that were not produced are read from their twin
     long r1 = r;
@@ -122,14 +131,33 @@ __global__ __launch_bounds__(256, 6) void film_rows_k(const float* __restrict__ 
                     lo[j] = (_Float16)(x - hxf);
                 }
                 _Float16* Ah = reinterpret_cast<_Float16*>(A);
-                // row-major [rows][D], or (planes & 4) FRAGMENT-MAJOR for gemm_hf_k: per 32-row block and 16-wide k-step the 64 lanes' MFMA operands
-                // contiguous -- [row block][k-step][lane = (row & 31) + 32 ((k >> 3) & 1)][8 halves]; rows local to this launch (rows % 32 == 0)
-                const int k = ch * 4;
-                const long off = (planes & 4) ? (((r >> 5) * (long)(D >> 4) + (k >> 4)) * 64 + (r & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 4) : r * D + k;
-                *reinterpret_cast<h4*>(Ah + off) = hi;
-                if ((planes & 3) == 2) *reinterpret_cast<h4*>(Ah + plane_stride + off) = lo;
+                if (planes & 4) {
+                    // fragment-major planes: staged per workgroup (4 rows) and written out below in 64-byte runs
+                    _Float16* st = film_stage + (threadIdx.x >> 6) * (D + 8) + ch * 4;
+                    *reinterpret_cast<h4*>(st) = hi;
+                    if ((planes & 3) == 2) *reinterpret_cast<h4*>(st + 4 * (D + 8)) = lo;
+                } else {
+                    *reinterpret_cast<h4*>(Ah + r * D + ch * 4) = hi;
+                    if ((planes & 3) == 2) *reinterpret_cast<h4*>(Ah + plane_stride + r * D + ch * 4) = lo;
+                }
             }
         }
+    }
+    if (planes & 4) {
+        // FRAGMENT-MAJOR planes for gemm_hf_k: per 32-row block and 16-wide k-step the 64 lanes' MFMA operands contiguous -- [row block][k-step][lane = (row & 31) +
+        // 32 ((k >> 3) & 1)][8 halves], rows local to this launch.  The workgroup's 4 consecutive rows are 4 consecutive lanes of a block: every (k-step, half)
+        // slot gets one 64-byte run (4 threads x 16 bytes); the 8 workgroups of a block share an XCD (above) and complete the lines in its L2
+        __syncthreads();
+        const long rbase = r - (threadIdx.x >> 6);               // first row of this workgroup (a multiple of 4 inside one 32-row block)
+        _Float16* Ah = reinterpret_cast<_Float16*>(A);
+        const int npiece = 4 * (D >> 3);
+        for (int pl = 0; pl < (planes & 3); ++pl)
+            for (int p = threadIdx.x; p < npiece; p += 256) {
+                const int row = p & 3, slot = p >> 2, ks = slot >> 1, hfk = slot & 1;
+                const uint4 v = *reinterpret_cast<const uint4*>(film_stage + (pl * 4 + row) * (D + 8) + ks * 16 + hfk * 8);
+                const long rr = rbase + row;
+                *reinterpret_cast<uint4*>(Ah + pl * plane_stride + (((rr >> 5) * (long)(D >> 4) + ks) * 64 + (rr & 31) + 32 * hfk) * 8) = v;
+            }
     }
 }
 
@@ -475,7 +503,9 @@ int mc_launch_film_rows(const float* Y1, const float* Y2, const float* gamma, co
     MC_REQUIRE(planes >= 0 && (planes & 3) <= 2 && (planes & ~7) == 0 && (!(planes & 4) || ((planes & 3) != 0 && rows % 32 == 0 && D % 16 == 0)),
                "film_rows: planes=%d (rows=%ld D=%d)", planes, rows, D);
     if (rows <= 0) return MC_OK;
-    hipLaunchKernelGGL(film_rows_k, dim3(cdiv(rows, 4)), dim3(256), 0, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step,
+    const long nwg = (planes & 4) ? (long)cdiv(rows / 32, 8) * 64 : (long)cdiv(rows, 4);
+    const size_t lds = (planes & 4) ? (size_t)(planes & 3) * 4 * (D + 8) * 2 : 0;
+    hipLaunchKernelGGL(film_rows_k, dim3((unsigned)nwg), dim3(256), lds, s, Y1, Y2, gamma, beta, ss, A, rows, D, y1_alias, row0, step,
                        y1_parts < 1 ? 1 : y1_parts, y1_pstride, planes, plane_stride);
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -94,8 +94,10 @@ struct McOptions {
     // 28 (round 6, OFF) plain f16 only: the accumulators START as R + bias instead (stores-only epilogue; f16 B=32 3.75 against bit 27's 3.81) -- another fp32
     //    summation order (2.6e-4 on h after one layer, 1.1e-3 on x0 against the exact order: inside plain f16's own error, but not free): a switch, not the default
     // 29 (round 6) reduced-precision contexts: the FiLM operand planes are written FRAGMENT-MAJOR and the plane GEMM reads its A fragments straight into registers
-    //    (gemm_hf_k: only W rides the LDS-DMA ring; tools/gemm_h6_lab.hip ha_k); launches whose rows are whole 32-row blocks only; the same bits as gemm_hd_k
-    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26) | (1 << 27);     // (all but bits 3, 23 and 25)
+    //    (gemm_hf_k: only W rides the LDS-DMA ring; tools/gemm_h6_lab.hip ha_k); launches whose rows are whole 32-row blocks only; the same bits as gemm_hd_k.
+    //    film_rows_k stages the 4 rows of a workgroup in LDS and writes 64-byte runs, the 8 workgroups of a 32-row block share an XCD.  Serial schedule: the GEMM
+    //    198 -> 183 us (B=64 f16), the row kernel 74.7 -> 77.2; two-stream step, same-box A/B: f16x3 10.85 -> 10.56 (B=64), 5.50 -> 5.37 (B=32); f16 neutral (7.05 / 7.06, 3.76 / 3.75)
+    int chain = 65527 | (1 << 16) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 26) | (1 << 27) | (1 << 29);     // (all but bits 3, 23, 25 and 28)
     long small_gemm_rows = 5600;       // plain GEMMs of up to this many rows take the small-M kernels (round 4: 6400 -> 5600, measured per batch: at
                                        // 6272 rows -- a sample group of 32 x 196 frames -- gemm_wp_k / gemm_tail_k now win: B=32 step 10.21 -> 10.03 ms,
                                        // S2G at 32 per GPU 27.65 -> 27.14; at 4704 rows (B=24) the small kernels still do, 7.85 vs 7.91)

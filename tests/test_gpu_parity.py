@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-DEFAULT_CHAIN = 8388599 | (1 << 24) | (1 << 26) | (1 << 27)        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3, 23 and 25
+DEFAULT_CHAIN = 8388599 | (1 << 24) | (1 << 26) | (1 << 27) | (1 << 29)        # McOptions::chain (mc_model.hip): every schedule / fusion bit but 3, 23, 25 and 28
 
 from helpers import (CTRL, CTRL_COPY, CTRL_FEATS, FULL, HML_FULL, HML_SMALL, KIT_SMALL, SMALL, SMALL_SEED, load,
                      step_noise_from_seed, synth_inputs)

@@ -9,8 +9,8 @@ root=$(pwd)
 export TMPDIR=/tmp
 out=$root/gpurun_out
 mkdir -p $out
-# single-stream schedule = the default chain mask (McOptions::chain, 226492407) without bits 5, 6, 9, 16 (two sample groups on two streams)
-SERIAL=226426263
+# single-stream schedule = the default chain mask (McOptions::chain, 763363319) without bits 5, 6, 9, 16 (two sample groups on two streams)
+SERIAL=763297175
 COMMIT=${GIT_COMMIT:-unknown}
 BENCH="python $root/bench.py --no-cpu-baseline --no-extras --no-full-loop"
 run() {   # run <name> <rocprof args...> -- <cmd...>
